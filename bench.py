@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MSDeformAttn hot path on MI355X.
+
+Metric (BASELINE.json): MSDeformAttn fwd+bwd M-queries/s at T=6, L=4, K=4, C=256 (configs[2], the
+DeVIS decoder temporal attention: T=6 frames, 300 queries per frame, pyramid of the 360x640 DeVIS
+test size, M=8 heads x D=32).  One "step" = forward + backward of one decoder-layer temporal
+attention over a batch of `--clips` independent clips (synthetic, seeded), inputs resident in HBM.
+A query row = one (frame, query) producing C=256 outputs; M-queries/s = clips*T*300 / step time / 1e6.
+
+    python bench.py                       # 1 GPU, default K/W, prints ONE JSON line
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU (`--gpus N`): clip-parallel -- every rank runs the same per-GPU batch of clips (weak
+scaling), no collective on the data path; timing = barrier + synchronize on both sides, max over ranks.
+
+The JSON line also carries
+  roofline     -- for the dominant kernel (the longer of the fused forward / backward kernels):
+                  algorithmic bytes per launch / its average launch duration measured
+                  here with HIP events on the launch stream, against the 8 TB/s HBM peak;
+  cpu_baseline -- the reference's pure-PyTorch CPU path (oracle/ restatement of
+                  ms_deform_attn_core_pytorch, fwd+bwd through autograd, reference call pattern)
+                  timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PYRAMIDS = {
+    "A": [(45, 80), (23, 40), (12, 20), (6, 10)],        # 360x640 (DeVIS test size), S = 4820
+    "B": [(100, 167), (50, 84), (25, 42), (13, 21)],     # 800x1333, S = 22223
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable with a float4 copy)
+DTYPES = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--clips", type=int, default=16, help="clips per GPU per step")
+    ap.add_argument("--frames", type=int, default=6)
+    ap.add_argument("--queries", type=int, default=300, help="queries per frame")
+    ap.add_argument("--pyramid", choices=sorted(PYRAMIDS), default="A")
+    ap.add_argument("--dtype", choices=sorted(DTYPES), default="f32")
+    ap.add_argument("--locs", choices=["uniform", "clustered"], default="uniform",
+                    help="uniform: rand in [0,1) as the reference test.py; clustered: reference point + "
+                         "N(0, (3 px)^2) offsets per level, as a trained decoder produces")
+    ap.add_argument("--pattern", choices=["fused", "reference"], default="fused",
+                    help="fused: one launch per direction; reference: the 2*T calls per layer of the reference")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_clip_batch(args, device, dtype, seed):
+    """Synthetic decoder-layer inputs for `clips` clips.  Seeded; joint softmax over the 96 logits."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    T, q, M, D, P = args.frames, args.queries, 8, 32, 4
+    shapes = torch.tensor(PYRAMIDS[args.pyramid], dtype=torch.int64)
+    L, W = shapes.shape[0], T - 1
+    S = int(shapes.prod(1).sum())
+    G = args.clips * T
+    value = (torch.rand(G, S, M, D, generator=g) * 2 - 1)
+    if args.locs == "uniform":
+        loc_c = torch.rand(G, q, M, L, P, 2, generator=g)
+        loc_t = torch.rand(G, q, M, W * L, P, 2, generator=g)
+    else:
+        ref = torch.rand(G, q, 1, 1, 1, 2, generator=g)
+        wh = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()
+        loc_c = ref + torch.randn(G, q, M, L, P, 2, generator=g) * 3.0 / wh[None, None, None, :, None, :]
+        loc_t = ref + torch.randn(G, q, M, W * L, P, 2, generator=g) * 3.0 / wh.repeat(W, 1)[None, None, None, :, None, :]
+    aw = torch.softmax(torch.randn(G, q, M, L * P + W * L * P, generator=g), -1)
+    aw_c = aw[..., :L * P].reshape(G, q, M, L, P)
+    aw_t = aw[..., L * P:].reshape(G, q, M, W * L, P)
+    grad_out = torch.randn(G, q, M * D, generator=g)
+    ftab = torch.tensor([[f for f in range(T) if f != t] for t in range(T)], dtype=torch.int32)
+    dev = lambda x: x.to(device=device, dtype=dtype).contiguous()
+    return dict(value=dev(value), shapes=shapes.to(device), ftab=ftab.to(device),
+                lsi=torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1])).to(device),
+                loc_c=dev(loc_c), aw_c=dev(aw_c), loc_t=dev(loc_t), aw_t=dev(aw_t),
+                grad_out=dev(grad_out), dims=(T, q, M, D, L, P, W, S))
+
+
+def algorithmic_bytes(args, e):
+    """Per fused launch over ONE clip (DESIGN.md 'algorithmic bytes'): value read once,
+    (x, y, weight) per sampling point, one output row per query; backward adds grad_out, the
+    grad_loc/grad_aw writes and the read-modify-write of grad_value (fp32 accumulator)."""
+    T, q, M, D, P = args.frames, args.queries, 8, 32, 4
+    shapes = PYRAMIDS[args.pyramid]
+    L, W = len(shapes), T - 1
+    S = sum(h * w for h, w in shapes)
+    C = M * D
+    points = T * q * M * (L * P + W * L * P)
+    fwd = T * S * C * e + points * 3 * e + T * q * C * e
+    bwd = T * S * C * e + T * q * C * e + points * 3 * e + points * 3 * e + 2 * T * S * C * 4
+    return fwd, bwd
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)   # RCCL on ROCm
+
+    from devis_amd.functions import MSDeformAttnFunction, MSDeformAttnTemporalFunction
+    dtype = DTYPES[args.dtype]
+    b = make_clip_batch(args, device, dtype, seed=1234 + rank)
+    T, q, M, D, L, P, W, S = b["dims"]
+    leaves = [b[k].requires_grad_(True) for k in ("value", "loc_c", "aw_c", "loc_t", "aw_t")]
+    t_shapes, t_lsi = None, None
+    if args.pattern == "reference":
+        t_shapes = b["shapes"].repeat(W, 1)
+        t_lsi = torch.cat((t_shapes.new_zeros(1), t_shapes.prod(1).cumsum(0)[:-1]))
+
+    def forward():
+        if args.pattern == "fused":
+            return MSDeformAttnTemporalFunction.apply(b["value"], b["shapes"], b["lsi"], b["ftab"], b["loc_c"],
+                                                      b["aw_c"], b["loc_t"], b["aw_t"], args.clips)
+        outs = []   # the reference's per-frame loop (ms_deform_attn.py:325-364), clip by clip
+        for g in range(args.clips * T):
+            c, t = divmod(g, T)
+            o1 = MSDeformAttnFunction.apply(b["value"][g][None], b["shapes"], b["lsi"], b["loc_c"][g][None],
+                                            b["aw_c"][g][None], 64)
+            frames = b["ftab"][t].long() + c * T
+            stacked = b["value"][frames].flatten(0, 1)[None]
+            o2 = MSDeformAttnFunction.apply(stacked, t_shapes, t_lsi, b["loc_t"][g][None], b["aw_t"][g][None], 64)
+            outs.append(o1 + o2)
+        return torch.cat(outs, 0)
+
+    def step():
+        out = forward()
+        torch.autograd.grad(out, leaves, b["grad_out"])
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    ms_per_step = elapsed / args.steps * 1e3
+    rows_per_step = world * args.clips * T * q
+    value = rows_per_step / (ms_per_step * 1e-3) / 1e6
+
+    # ---- per-kernel durations with HIP events on the launch stream (fused pattern only) ----------
+    roofline, extra = None, {}
+    if rank == 0 and args.pattern == "fused":
+        from devis_amd import _native
+        stream = torch.cuda.current_stream()
+        out = torch.empty((args.clips * T, q, M * D), dtype=dtype, device=device)
+        acc = _native.acc_dtype(dtype)
+        gv = torch.zeros(b["value"].shape, dtype=acc, device=device)
+        gl_c, ga_c = torch.empty_like(b["loc_c"]), torch.empty_like(b["aw_c"])
+        gl_t, ga_t = torch.empty_like(b["loc_t"]), torch.empty_like(b["aw_t"])
+        dv = [x.detach() for x in (b["value"], b["loc_c"], b["aw_c"], b["loc_t"], b["aw_t"])]
+
+        def time_kernel(fn, reps):
+            for _ in range(3):
+                fn()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for s, e in ev:
+                s.record(stream)
+                fn()
+                e.record(stream)
+            torch.cuda.synchronize()
+            ts = sorted(s.elapsed_time(e) for s, e in ev)
+            return sum(ts) / len(ts), ts[len(ts) // 2]
+
+        fwd_ms, fwd_med = time_kernel(lambda: _native.temporal_forward(
+            dv[0], b["shapes"], b["lsi"], b["ftab"], dv[1], dv[2], dv[3], dv[4], args.clips, out), 20)
+        bwd_ms, bwd_med = time_kernel(lambda: _native.temporal_backward(
+            dv[0], b["shapes"], b["lsi"], b["ftab"], dv[1], dv[2], dv[3], dv[4], b["grad_out"], args.clips,
+            gv, gl_c, ga_c, gl_t, ga_t), 20)
+        e = b["value"].element_size()
+        fwd_b, bwd_b = algorithmic_bytes(args, e)
+        fwd_gbs = fwd_b * args.clips / (fwd_ms * 1e-3) / 1e9
+        bwd_gbs = bwd_b * args.clips / (bwd_ms * 1e-3) / 1e9
+        dom = "backward" if bwd_ms >= fwd_ms else "forward"
+        ach = bwd_gbs if dom == "backward" else fwd_gbs
+        roofline = {"bound": "hbm", "kernel": "msda_%s_tile_kernel (fused temporal %s)" % ("bwd" if dom == "backward" else "fwd", dom),
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": (bwd_b if dom == "backward" else fwd_b) * args.clips,
+                    "avg_launch_ms": round(bwd_ms if dom == "backward" else fwd_ms, 4)}
+        extra = {"forward_kernel": {"avg_ms": round(fwd_ms, 4), "median_ms": round(fwd_med, 4),
+                                    "algorithmic_GBps": round(fwd_gbs, 1), "frac_of_hbm_peak": round(fwd_gbs / HBM_PEAK_GBS, 4),
+                                    "M_queries_per_s": round(args.clips * T * q / (fwd_ms * 1e-3) / 1e6, 2)},
+                 "backward_kernel": {"avg_ms": round(bwd_ms, 4), "median_ms": round(bwd_med, 4),
+                                     "algorithmic_GBps": round(bwd_gbs, 1), "frac_of_hbm_peak": round(bwd_gbs / HBM_PEAK_GBS, 4)}}
+
+    # ---- CPU baseline: the reference's pure-PyTorch path on the host cores (bounded sample) -----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import msda_oracle as O
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        cb = {k: (v[:T].detach().float().cpu() if k in ("value", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out") else v.cpu())
+              for k, v in b.items() if k != "dims"}
+        c_shapes_t = cb["shapes"].repeat(W, 1)
+
+        def cpu_clip():
+            lv = [cb[k].clone().requires_grad_(True) for k in ("value", "loc_c", "aw_c", "loc_t", "aw_t")]
+            outs = []
+            for t in range(T):
+                o1 = O.grid_sample_forward(lv[0][t][None], cb["shapes"], lv[1][t][None], lv[2][t][None])
+                stacked = lv[0][cb["ftab"][t].long()].flatten(0, 1)[None]
+                o2 = O.grid_sample_forward(stacked, c_shapes_t, lv[3][t][None], lv[4][t][None])
+                outs.append(o1 + o2)
+            torch.autograd.grad(torch.cat(outs, 0), lv, cb["grad_out"])
+
+        cpu_clip()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < args.cpu_seconds:
+            cpu_clip()
+            n += 1
+        dt = time.perf_counter() - t0
+        cpu = {"value": round(n * T * q / dt / 1e6, 5), "unit": "M-queries/s", "cores": cores, "kind": "port",
+               "sample": "%d clip-layer fwd+bwd passes (T=%d, %d queries/frame, pyramid %s, fp32) of oracle."
+                         "grid_sample_forward in the reference's 2*T-call pattern, %.1f s" % (n, T, q, args.pyramid, dt)}
+
+    if rank == 0:
+        line = {
+            "metric": "MSDeformAttn fwd+bwd M-queries/s at T=6,L=4,K=4,C=256", "value": round(value, 3),
+            "unit": "M-queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "cfg3 DeVIS decoder temporal MSDeformAttn, one layer fwd+bwd: T=%d frames, "
+                                   "%d queries/frame, L=4, K=4, C=256 (M=8xD=32), pyramid %s (S=%d), %d clips/GPU/step, "
+                                   "%s call pattern, %s sampling locations"
+                                   % (T, q, args.pyramid, S, args.clips, args.pattern, args.locs),
+                       "clips_per_gpu": args.clips, "query_rows_per_step": rows_per_step,
+                       "parallelism": "clip-parallel x%d (no data-path collective)" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,135 @@
+"""ctypes binding of the C ABI in include/msda.h (libmsda_hip.so) -- the only door to the kernels.
+
+There is NO fallback: if the library is missing and cannot be built, or a call fails, this raises.
+torch is used here only as plumbing (device pointers, current stream).
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+from . import build as _build
+
+MSDA_ABI_VERSION = 1
+_DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.float16: 3}
+
+# every symbol include/msda.h declares (tests check the library exports each of them)
+EXPORTED_SYMBOLS = (
+    "msda_version", "msda_last_error", "msda_forward", "msda_backward",
+    "msda_temporal_forward", "msda_temporal_backward",
+)
+
+_lib = None
+_lock = threading.Lock()
+_vp, _ci = ctypes.c_void_p, ctypes.c_int
+
+
+def load():
+    """Load (building first if needed) libmsda_hip.so; raises RuntimeError when impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = _build.lib_path()
+        if not os.path.exists(path):
+            try:
+                _build.build()
+            except Exception as e:  # no hipcc on this box and no prebuilt library
+                raise RuntimeError(
+                    "devis_amd: the HIP library %s is missing and could not be built (%s). "
+                    "There is no CPU fallback for MSDeformAttn." % (path, e))
+        lib = ctypes.CDLL(path)
+        for name in EXPORTED_SYMBOLS:
+            if not hasattr(lib, name):
+                raise RuntimeError("devis_amd: %s does not export %s" % (path, name))
+        lib.msda_version.restype = _ci
+        lib.msda_last_error.restype = ctypes.c_char_p
+        if lib.msda_version() != MSDA_ABI_VERSION:
+            raise RuntimeError("devis_amd: ABI version mismatch (library %d, binding %d); rebuild with "
+                               "python -m devis_amd.build --force" % (lib.msda_version(), MSDA_ABI_VERSION))
+        lib.msda_forward.restype = _ci
+        lib.msda_forward.argtypes = [_ci] + [_vp] * 5 + [_ci] * 7 + [_vp, _vp]
+        lib.msda_backward.restype = _ci
+        lib.msda_backward.argtypes = [_ci] + [_vp] * 6 + [_ci] * 7 + [_vp] * 4
+        lib.msda_temporal_forward.restype = _ci
+        lib.msda_temporal_forward.argtypes = [_ci] + [_vp] * 8 + [_ci] * 10 + [_vp, _vp]
+        lib.msda_temporal_backward.restype = _ci
+        lib.msda_temporal_backward.argtypes = [_ci] + [_vp] * 9 + [_ci] * 10 + [_vp] * 6
+        _lib = lib
+    return _lib
+
+
+def dtype_code(dtype):
+    try:
+        return _DTYPE_CODE[dtype]
+    except KeyError:
+        raise RuntimeError("devis_amd: unsupported dtype %s (float32/float64/bfloat16/float16)" % dtype)
+
+
+def acc_dtype(dtype):
+    """dtype of the grad_value accumulation buffer (include/msda.h)."""
+    return torch.float64 if dtype == torch.float64 else torch.float32
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load().msda_last_error().decode("utf-8", "replace")
+        raise RuntimeError("devis_amd: %s failed (status %d): %s" % (what, rc, msg))
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def forward(value, shapes, lsi, loc, aw, out):
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    with torch.cuda.device(value.device):
+        rc = load().msda_forward(dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(aw),
+                                 N, S, M, D, L, Lq, P, _p(out), _stream(value))
+    _check(rc, "msda_forward")
+
+
+def backward(value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_aw):
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    with torch.cuda.device(value.device):
+        rc = load().msda_backward(dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(aw),
+                                  _p(grad_out), N, S, M, D, L, Lq, P,
+                                  _p(grad_value), _p(grad_loc), _p(grad_aw), _stream(value))
+    _check(rc, "msda_backward")
+
+
+def temporal_forward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, clips, out):
+    G, S, M, D = value.shape
+    frames = G // clips
+    _, Lq, _, L, Pc, _ = loc_c.shape
+    window = ftab.shape[1] if ftab is not None else 0
+    Pt = loc_t.shape[4] if window else 1
+    with torch.cuda.device(value.device):
+        rc = load().msda_temporal_forward(
+            dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(ftab), _p(loc_c), _p(aw_c),
+            _p(loc_t), _p(aw_t), clips, frames, window, S, M, D, L, Lq, Pc, Pt, _p(out), _stream(value))
+    _check(rc, "msda_temporal_forward")
+
+
+def temporal_backward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, grad_out, clips,
+                      grad_value, gloc_c, gaw_c, gloc_t, gaw_t):
+    G, S, M, D = value.shape
+    frames = G // clips
+    _, Lq, _, L, Pc, _ = loc_c.shape
+    window = ftab.shape[1] if ftab is not None else 0
+    Pt = loc_t.shape[4] if window else 1
+    with torch.cuda.device(value.device):
+        rc = load().msda_temporal_backward(
+            dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(ftab), _p(loc_c), _p(aw_c),
+            _p(loc_t), _p(aw_t), _p(grad_out), clips, frames, window, S, M, D, L, Lq, Pc, Pt,
+            _p(grad_value), _p(gloc_c), _p(gaw_c), _p(gloc_t), _p(gaw_t), _stream(value))
+    _check(rc, "msda_temporal_backward")

@@ -1,0 +1,825 @@
+// msda_hip.hip -- hand-written gfx950 (CDNA4, wave64) kernels for multi-scale deformable attention
+// and the extern "C" ABI declared in include/msda.h.
+//
+// What is computed (semantics of the reference kernels being replaced,
+// /root/reference/src/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:33-299 forward, :87-920 backward):
+//   out[n,q,m,:] = sum_{l,p} a[n,q,m,l,p] * bilinear(value_l[:, :, m, :], x*W_l-0.5, y*H_l-0.5)
+// with zero padding, a point contributing only if -1 < h < H_l and -1 < w < W_l (cuh:288), and the
+// matching gradients wrt value (scatter-add), sampling locations and attention weights.
+//
+// Design (MI355X-first, not a translation of the reference's one-thread-per-channel CUDA kernels):
+//   * "tile" kernels: ONE wave64 owns RPW = 64/G (query, head) rows of the same head, G lanes per row,
+//     each lane holding VEC contiguous channels (16 B: float4 or 8 x bf16/f16), so every bilinear
+//     corner is one coalesced D*sizeof(T) segment per row and one 16-B load per lane.
+//   * the wave first turns its rows' (x, y, weight) triples into "tap records" in LDS -- 4 element
+//     offsets + 4 premultiplied weights per sampling point, computed ONCE per point instead of once
+//     per channel lane -- then the gather loop is LDS-broadcast read + 4 global loads + FMAs.
+//   * out-of-range corners become (offset 0, weight 0): the gather loop is branch free.
+//   * a per-wave "virtual level" table in LDS holds (H, W, first pixel) for every level of every
+//     source frame, so the plain op (levels of one map) and the fused temporal op (current frame +
+//     `window` other frames of the clip, ms_deform_attn.py:325-364) are the SAME kernel.
+//   * blockIdx -> (query tile, head) with head = blockIdx % M: workgroups are dealt round-robin to the
+//     8 XCDs, so with M = 8 each XCD's private 4 MiB L2 only ever sees ONE head's 1/8 slice of the
+//     value maps (XCD-aware mapping; affects speed only, never results).
+//   * backward: per-point partial dot products <grad_out, corner_k> are reduced across the G lanes
+//     with DPP/shuffle butterflies (no LDS round trip, no serial thread-0 sum as in cuh:376-394);
+//     grad_value uses hardware fp32/fp64 global atomics (global_atomic_add_f32/f64, no CAS loop).
+//   * generic kernels (any D, any dtype incl. fp64) back the shapes the tile kernels do not take.
+//
+// No CUDA compatibility layer, no hipify output: this file targets gfx950 only.
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "msda.h"
+
+namespace {
+
+constexpr int kWave = 64;   // gfx950 wavefront
+constexpr int kPch = 16;    // sampling points per LDS chunk (= L*P of the DeVIS configs)
+
+// ------------------------------------------------------------------------------------------------
+// storage-type helpers: everything is computed in fp32 (fp64 for double)
+// ------------------------------------------------------------------------------------------------
+typedef __hip_bfloat16 bf16_t;
+typedef __half f16_t;
+
+template <typename T> struct Store;   // VEC = elements per 16-byte lane vector
+template <> struct Store<float> {
+    static constexpr int VEC = 4;
+    __device__ static float get(const float *p) { return *p; }
+    __device__ static void put(float *p, float v) { *p = v; }
+    __device__ static void load(const float *p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    __device__ static void store(float *p, const float (&v)[4]) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct Store<bf16_t> {
+    static constexpr int VEC = 8;
+    __device__ static float get(const bf16_t *p) { return __bfloat162float(*p); }
+    __device__ static void put(bf16_t *p, float v) { *p = __float2bfloat16(v); }
+    __device__ static void load(const bf16_t *p, float (&v)[8]) {
+        const uint4 t = *reinterpret_cast<const uint4 *>(p);
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {       // bf16 -> f32 is a 16-bit shift
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ static void store(bf16_t *p, const float (&v)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_t lo = __float2bfloat16(v[2 * i]), hi = __float2bfloat16(v[2 * i + 1]);
+            w[i] = (uint32_t)(*reinterpret_cast<const uint16_t *>(&lo)) |
+                   ((uint32_t)(*reinterpret_cast<const uint16_t *>(&hi)) << 16);
+        }
+        *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+template <> struct Store<f16_t> {
+    static constexpr int VEC = 8;
+    __device__ static float get(const f16_t *p) { return __half2float(*p); }
+    __device__ static void put(f16_t *p, float v) { *p = __float2half(v); }
+    __device__ static void load(const f16_t *p, float (&v)[8]) {
+        const uint4 t = *reinterpret_cast<const uint4 *>(p);
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const __half2 h = *reinterpret_cast<const __half2 *>(&w[i]);
+            const float2 f = __half22float2(h);
+            v[2 * i] = f.x;
+            v[2 * i + 1] = f.y;
+        }
+    }
+    __device__ static void store(f16_t *p, const float (&v)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const __half2 h = __floats2half2_rn(v[2 * i], v[2 * i + 1]);
+            w[i] = *reinterpret_cast<const uint32_t *>(&h);
+        }
+        *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+template <> struct Store<double> {
+    static constexpr int VEC = 2;
+    __device__ static double get(const double *p) { return *p; }
+    __device__ static void put(double *p, double v) { *p = v; }
+};
+
+// hardware float atomics (global_atomic_add_f32 / _f64, no return value, no CAS loop)
+__device__ __forceinline__ void atomic_accumulate(float *p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_accumulate(double *p, double v) { unsafeAtomicAdd(p, v); }
+
+// ------------------------------------------------------------------------------------------------
+// kernel parameters: one struct serves the plain op (frames = 1, window = 0, LB = 0) and the fused
+// temporal op (array A = current-frame points, array B = temporal points)
+// ------------------------------------------------------------------------------------------------
+struct Params {
+    const void *value;          // [groups, S, M, D]; groups = clips * frames
+    const int64_t *shapes;      // [L, 2] (H, W)
+    const int64_t *lsi;         // [L]
+    const int32_t *ftab;        // [frames, window] or null
+    const void *locA, *awA;     // [groups, Lq, M, LA, PA, 2], [groups, Lq, M, LA, PA]
+    const void *locB, *awB;     // [groups, Lq, M, LB, PB, 2], ...      (LB = window * L)
+    void *out;                  // fwd: [groups, Lq, M*D]
+    const void *grad_out;       // bwd
+    void *grad_value;           // bwd: acc type, pre-zeroed
+    void *glocA, *gawA, *glocB, *gawB;
+    int groups, frames, window;
+    int S, M, D, L, Lq;
+    int LA, PA, LB, PB;
+};
+
+struct Level { int H, W, start, pad; };   // start = first pixel of the level inside the CLIP slab
+
+// virtual level j of the wave's (clip, frame t):  j < LA -> level j of frame t (plain op: of the only
+// map); j >= LA -> temporal slot w = (j-LA)/L, level (j-LA)%L of frame ftab[t, w].
+__device__ __forceinline__ Level make_level(const Params &p, int t, int j)
+{
+    int l = j, f = t;
+    if (j >= p.LA) {
+        const int w = (j - p.LA) / p.L;
+        l = (j - p.LA) - w * p.L;
+        f = p.ftab[t * p.window + w];
+        f = min(max(f, 0), p.frames - 1);   // memory safety only; valid tables never clamp
+    }
+    Level lv;
+    lv.H = (int)p.shapes[2 * l];
+    lv.W = (int)p.shapes[2 * l + 1];
+    lv.start = f * p.S + (int)p.lsi[l];
+    lv.pad = 0;
+    return lv;
+}
+
+// One sampling point -> tap record.  Follows cuh:285-288 (pixel coords, range test), cuh:38-53
+// (floor, fractions, strides) and cuh:56-80 (per-corner validity, weights).
+struct Taps {
+    int off[4];        // element offsets (inside the clip slab, without m*D + c) of the 4 corners
+    float w[4];        // hh*hw, hh*lw, lh*hw, lh*lw  -- zero for corners outside the map
+    float lh, lw;
+    int valid;         // bit k set = corner k inside the map; 0 = point skipped
+};
+
+__device__ __forceinline__ Taps make_taps(float x, float y, const Level lv, int MD)
+{
+    Taps t;
+    t.off[0] = t.off[1] = t.off[2] = t.off[3] = 0;
+    t.w[0] = t.w[1] = t.w[2] = t.w[3] = 0.f;
+    t.lh = t.lw = 0.f;
+    t.valid = 0;
+    const float h_im = y * (float)lv.H - 0.5f;
+    const float w_im = x * (float)lv.W - 0.5f;
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)lv.H && w_im < (float)lv.W) {
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const int h_low = (int)hf, w_low = (int)wf;
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - hf, lw = w_im - wf;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const bool y0 = h_low >= 0, y1 = h_high <= lv.H - 1;
+        const bool x0 = w_low >= 0, x1 = w_high <= lv.W - 1;
+        const int r0 = (lv.start + h_low * lv.W) * MD, r1 = r0 + lv.W * MD;
+        const int c0 = w_low * MD, c1 = c0 + MD;
+        t.lh = lh; t.lw = lw;
+        if (y0 && x0) { t.off[0] = r0 + c0; t.w[0] = hh * hw; t.valid |= 1; }
+        if (y0 && x1) { t.off[1] = r0 + c1; t.w[1] = hh * lw; t.valid |= 2; }
+        if (y1 && x0) { t.off[2] = r1 + c0; t.w[2] = lh * hw; t.valid |= 4; }
+        if (y1 && x1) { t.off[3] = r1 + c1; t.w[3] = lh * lw; t.valid |= 8; }
+    }
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile kernels
+// ------------------------------------------------------------------------------------------------
+// LDS carve (dynamic, 16-byte aligned): [s_off RPW*(kPch+1) int4][s_w RPW*(kPch+1) float4]
+//                                       [s_e RPW*(kPch+1) float4 (bwd only)][levels nvl * Level]
+// Row stride kPch+1 (odd number of 16-B slots) keeps the RPW rows of a wave on different LDS slots
+// for the broadcast ds_read_b128 of the gather loop.
+constexpr int kRowSlots = kPch + 1;
+
+template <int RPW>
+__device__ __forceinline__ void tile_coords(const Params &p, int &m, int &group, int &q0)
+{
+    // head = blockIdx % M -> XCD affinity (see file header); tiles of one group are consecutive
+    m = blockIdx.x % p.M;
+    const int tile = blockIdx.x / p.M;
+    const int tiles_per_group = (p.Lq + RPW - 1) / RPW;
+    group = tile / tiles_per_group;
+    q0 = (tile - group * tiles_per_group) * RPW;
+}
+
+// Builds the tap records of one chunk (<= kPch points of every row of the wave) in LDS.
+template <typename T, int RPW, bool BWD>
+__device__ __forceinline__ void stage_chunk(const Params &p, const T *__restrict__ loc,
+                                            const T *__restrict__ aw, int LP, int P, int vl_base,
+                                            int p0, int64_t row0, int rows_valid, const Level *s_lvl,
+                                            int4 *s_off, float4 *s_w, float4 *s_e, int lane)
+{
+    const int MD = p.M * p.D;
+#pragma unroll
+    for (int i = lane; i < RPW * kPch; i += kWave) {
+        const int rr = i / kPch, pp = i % kPch, pt = p0 + pp;
+        int4 o = make_int4(0, 0, 0, 0);
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rr < rows_valid && pt < LP) {
+            const int64_t idx = (row0 + (int64_t)rr * p.M) * LP + pt;
+            const float x = Store<T>::get(loc + 2 * idx);
+            const float y = Store<T>::get(loc + 2 * idx + 1);
+            const float a = Store<T>::get(aw + idx);
+            const int vl = vl_base + pt / P;
+            const Taps t = make_taps(x, y, s_lvl[vl], MD);
+            o = make_int4(t.off[0], t.off[1], t.off[2], t.off[3]);
+            if (BWD) {
+                w = make_float4(t.w[0], t.w[1], t.w[2], t.w[3]);
+                // a, fractions, and (valid bits | level index << 4) for the final gradient lane
+                e = make_float4(a, t.lh, t.lw, __int_as_float(t.valid | (vl << 4)));
+            } else {
+                w = make_float4(t.w[0] * a, t.w[1] * a, t.w[2] * a, t.w[3] * a);
+            }
+        }
+        s_off[rr * kRowSlots + pp] = o;
+        s_w[rr * kRowSlots + pp] = w;
+        if (BWD) s_e[rr * kRowSlots + pp] = e;
+    }
+}
+
+template <typename T, int G>
+__global__ void __launch_bounds__(kWave)
+msda_fwd_tile_kernel(const Params p)
+{
+    constexpr int VEC = Store<T>::VEC;
+    constexpr int RPW = kWave / G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    int4 *s_off = reinterpret_cast<int4 *>(lds_raw);
+    float4 *s_w = reinterpret_cast<float4 *>(s_off + RPW * kRowSlots);
+    Level *s_lvl = reinterpret_cast<Level *>(s_w + RPW * kRowSlots);
+
+    const int lane = threadIdx.x;
+    int m, group, q0;
+    tile_coords<RPW>(p, m, group, q0);
+    const int clip = group / p.frames, t = group - clip * p.frames;
+    const int nvl = p.LA + p.LB;
+    for (int j = lane; j < nvl; j += kWave) s_lvl[j] = make_level(p, t, j);
+    __syncthreads();
+
+    const int r = lane / G, sub = lane % G;
+    const int rows_valid = min(RPW, p.Lq - q0);
+    const int MD = p.M * p.D;
+    const T *__restrict__ value =
+        static_cast<const T *>(p.value) + (int64_t)clip * p.frames * p.S * MD + (m * p.D + sub * VEC);
+    const int64_t row0 = ((int64_t)group * p.Lq + q0) * p.M + m;   // row of rr = 0; next row: + M
+
+    float acc[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[c] = 0.f;
+
+#pragma unroll 1
+    for (int arr = 0; arr < 2; ++arr) {
+        const T *loc = static_cast<const T *>(arr ? p.locB : p.locA);
+        const T *aw = static_cast<const T *>(arr ? p.awB : p.awA);
+        const int P = arr ? p.PB : p.PA;
+        const int LP = (arr ? p.LB : p.LA) * P;
+        const int vl_base = arr ? p.LA : 0;
+#pragma unroll 1
+        for (int p0 = 0; p0 < LP; p0 += kPch) {
+            stage_chunk<T, RPW, false>(p, loc, aw, LP, P, vl_base, p0, row0, rows_valid, s_lvl,
+                                       s_off, s_w, nullptr, lane);
+            __syncthreads();
+            const int np = min(kPch, LP - p0);
+            const int4 *ro = s_off + r * kRowSlots;
+            const float4 *rw = s_w + r * kRowSlots;
+#pragma unroll 4
+            for (int pp = 0; pp < np; ++pp) {
+                const int4 o = ro[pp];
+                const float4 w = rw[pp];
+                float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+                Store<T>::load(value + o.x, v0);
+                Store<T>::load(value + o.y, v1);
+                Store<T>::load(value + o.z, v2);
+                Store<T>::load(value + o.w, v3);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    acc[c] = fmaf(w.x, v0[c], acc[c]);
+                    acc[c] = fmaf(w.y, v1[c], acc[c]);
+                    acc[c] = fmaf(w.z, v2[c], acc[c]);
+                    acc[c] = fmaf(w.w, v3[c], acc[c]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (r < rows_valid) {
+        T *out = static_cast<T *>(p.out) + (row0 + (int64_t)r * p.M) * p.D + sub * VEC;
+        Store<T>::store(out, acc);
+    }
+}
+
+// sum over the G lanes of a row (G is a power of two <= 64): xor butterfly, DPP / ds_swizzle
+template <int G>
+__device__ __forceinline__ float row_sum(float v)
+{
+#pragma unroll
+    for (int s = 1; s < G; s <<= 1) v += __shfl_xor(v, s, kWave);
+    return v;
+}
+
+template <typename T, int G>
+__global__ void __launch_bounds__(kWave)
+msda_bwd_tile_kernel(const Params p)
+{
+    constexpr int VEC = Store<T>::VEC;
+    constexpr int RPW = kWave / G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    int4 *s_off = reinterpret_cast<int4 *>(lds_raw);
+    float4 *s_w = reinterpret_cast<float4 *>(s_off + RPW * kRowSlots);
+    float4 *s_e = s_w + RPW * kRowSlots;
+    Level *s_lvl = reinterpret_cast<Level *>(s_e + RPW * kRowSlots);
+
+    const int lane = threadIdx.x;
+    int m, group, q0;
+    tile_coords<RPW>(p, m, group, q0);
+    const int clip = group / p.frames, t = group - clip * p.frames;
+    const int nvl = p.LA + p.LB;
+    for (int j = lane; j < nvl; j += kWave) s_lvl[j] = make_level(p, t, j);
+    __syncthreads();
+
+    const int r = lane / G, sub = lane % G;
+    const int rows_valid = min(RPW, p.Lq - q0);
+    const int MD = p.M * p.D;
+    const int64_t lane_off = (int64_t)clip * p.frames * p.S * MD + (m * p.D + sub * VEC);
+    const T *__restrict__ value = static_cast<const T *>(p.value) + lane_off;
+    float *__restrict__ gvalue = static_cast<float *>(p.grad_value) + lane_off;
+    const int64_t row0 = ((int64_t)group * p.Lq + q0) * p.M + m;
+    const int64_t row = row0 + (int64_t)r * p.M;
+
+    float g[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) g[c] = 0.f;
+    if (r < rows_valid) Store<T>::load(static_cast<const T *>(p.grad_out) + row * p.D + sub * VEC, g);
+
+#pragma unroll 1
+    for (int arr = 0; arr < 2; ++arr) {
+        const T *loc = static_cast<const T *>(arr ? p.locB : p.locA);
+        const T *aw = static_cast<const T *>(arr ? p.awB : p.awA);
+        T *gloc = static_cast<T *>(arr ? p.glocB : p.glocA);
+        T *gaw = static_cast<T *>(arr ? p.gawB : p.gawA);
+        const int P = arr ? p.PB : p.PA;
+        const int LP = (arr ? p.LB : p.LA) * P;
+        const int vl_base = arr ? p.LA : 0;
+#pragma unroll 1
+        for (int p0 = 0; p0 < LP; p0 += kPch) {
+            stage_chunk<T, RPW, true>(p, loc, aw, LP, P, vl_base, p0, row0, rows_valid, s_lvl,
+                                      s_off, s_w, s_e, lane);
+            __syncthreads();
+            const int np = min(kPch, LP - p0);
+            const int4 *ro = s_off + r * kRowSlots;
+            const float4 *rw = s_w + r * kRowSlots;
+            const float4 *re = s_e + r * kRowSlots;
+#pragma unroll 2
+            for (int pp = 0; pp < np; ++pp) {
+                const int4 o = ro[pp];
+                const float4 w = rw[pp];
+                const float4 e = re[pp];
+                const int bits = __float_as_int(e.w);
+                float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+                Store<T>::load(value + o.x, v0);
+                Store<T>::load(value + o.y, v1);
+                Store<T>::load(value + o.z, v2);
+                Store<T>::load(value + o.w, v3);
+                // d_k = <grad_out row, corner k> over this lane's channels (0 for invalid corners:
+                // their weight is 0 in every formula below except the fraction terms, so mask here)
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    d0 = fmaf(g[c], v0[c], d0);
+                    d1 = fmaf(g[c], v1[c], d1);
+                    d2 = fmaf(g[c], v2[c], d2);
+                    d3 = fmaf(g[c], v3[c], d3);
+                }
+                d0 = (bits & 1) ? d0 : 0.f;
+                d1 = (bits & 2) ? d1 : 0.f;
+                d2 = (bits & 4) ? d2 : 0.f;
+                d3 = (bits & 8) ? d3 : 0.f;
+                // grad_value[corner k] += w_k * a * grad_out   (cuh:125,134,143,152)
+                const float a = e.x;
+                const float wa0 = w.x * a, wa1 = w.y * a, wa2 = w.z * a, wa3 = w.w * a;
+                if (bits & 1) {
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) atomic_accumulate(gvalue + o.x + c, wa0 * g[c]);
+                }
+                if (bits & 2) {
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) atomic_accumulate(gvalue + o.y + c, wa1 * g[c]);
+                }
+                if (bits & 4) {
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) atomic_accumulate(gvalue + o.z + c, wa2 * g[c]);
+                }
+                if (bits & 8) {
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) atomic_accumulate(gvalue + o.w + c, wa3 * g[c]);
+                }
+                d0 = row_sum<G>(d0);
+                d1 = row_sum<G>(d1);
+                d2 = row_sum<G>(d2);
+                d3 = row_sum<G>(d3);
+                // one lane per (row, point) finishes: cuh:123-158 rewritten on the reduced dots
+                if (sub == (pp % G) && r < rows_valid) {
+                    const float lh = e.y, lw = e.z, hh = 1.f - lh, hw = 1.f - lw;
+                    const Level lv = s_lvl[bits >> 4];
+                    const float g_aw = w.x * d0 + w.y * d1 + w.z * d2 + w.w * d3;
+                    const float g_w = hh * (d1 - d0) + lh * (d3 - d2);
+                    const float g_h = hw * (d2 - d0) + lw * (d3 - d1);
+                    const int64_t idx = row * LP + (p0 + pp);
+                    Store<T>::put(gaw + idx, g_aw);
+                    Store<T>::put(gloc + 2 * idx, (float)lv.W * g_w * a);
+                    Store<T>::put(gloc + 2 * idx + 1, (float)lv.H * g_h * a);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic kernels: any D / M / L / P, any dtype (fp64 included).  Correctness path for shapes the
+// tile kernels do not take (D not a power-of-two multiple of the 16-B lane vector, fp64 gradcheck).
+// ------------------------------------------------------------------------------------------------
+template <typename A> struct GTaps { int64_t off[4]; A w[4]; A lh, lw; int valid; };
+
+template <typename A>
+__device__ __forceinline__ GTaps<A> make_gtaps(A x, A y, const Level lv, int MD)
+{
+    GTaps<A> t;
+    for (int k = 0; k < 4; ++k) { t.off[k] = 0; t.w[k] = 0; }
+    t.lh = t.lw = 0; t.valid = 0;
+    const A h_im = y * (A)lv.H - (A)0.5, w_im = x * (A)lv.W - (A)0.5;
+    if (h_im > -1 && w_im > -1 && h_im < lv.H && w_im < lv.W) {
+        const A hf = floor(h_im), wf = floor(w_im);
+        const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+        const A lh = h_im - hf, lw = w_im - wf, hh = 1 - lh, hw = 1 - lw;
+        const bool y0 = h_low >= 0, y1 = h_high <= lv.H - 1, x0 = w_low >= 0, x1 = w_high <= lv.W - 1;
+        const int64_t r0 = ((int64_t)lv.start + (int64_t)h_low * lv.W) * MD, r1 = r0 + (int64_t)lv.W * MD;
+        const int64_t c0 = (int64_t)w_low * MD, c1 = c0 + MD;
+        t.lh = lh; t.lw = lw;
+        if (y0 && x0) { t.off[0] = r0 + c0; t.w[0] = hh * hw; t.valid |= 1; }
+        if (y0 && x1) { t.off[1] = r0 + c1; t.w[1] = hh * lw; t.valid |= 2; }
+        if (y1 && x0) { t.off[2] = r1 + c0; t.w[2] = lh * hw; t.valid |= 4; }
+        if (y1 && x1) { t.off[3] = r1 + c1; t.w[3] = lh * lw; t.valid |= 8; }
+    }
+    return t;
+}
+
+template <typename T, typename A>
+__global__ void __launch_bounds__(256)
+msda_fwd_generic_kernel(const Params p, int64_t total)
+{
+    const int MD = p.M * p.D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % p.D);
+        const int64_t row = i / p.D;                      // (group, q, m)
+        const int m = (int)(row % p.M);
+        const int group = (int)(row / ((int64_t)p.M * p.Lq));
+        const int clip = group / p.frames, t = group - clip * p.frames;
+        const T *value = static_cast<const T *>(p.value) + (int64_t)clip * p.frames * p.S * MD + m * p.D + c;
+        A acc = 0;
+        for (int arr = 0; arr < 2; ++arr) {
+            const T *loc = static_cast<const T *>(arr ? p.locB : p.locA);
+            const T *aw = static_cast<const T *>(arr ? p.awB : p.awA);
+            const int P = arr ? p.PB : p.PA, nl = arr ? p.LB : p.LA, LP = nl * P;
+            for (int pt = 0; pt < LP; ++pt) {
+                const Level lv = make_level(p, t, (arr ? p.LA : 0) + pt / P);
+                const int64_t idx = row * LP + pt;
+                const GTaps<A> tp = make_gtaps<A>((A)Store<T>::get(loc + 2 * idx),
+                                                  (A)Store<T>::get(loc + 2 * idx + 1), lv, MD);
+                if (!tp.valid) continue;
+                A val = 0;
+                for (int k = 0; k < 4; ++k)
+                    if (tp.valid & (1 << k)) val += tp.w[k] * (A)Store<T>::get(value + tp.off[k]);
+                acc += val * (A)Store<T>::get(aw + idx);
+            }
+        }
+        Store<T>::put(static_cast<T *>(p.out) + i, acc);
+    }
+}
+
+template <typename A>
+__device__ __forceinline__ A wave_sum(A v)
+{
+#pragma unroll
+    for (int s = 1; s < kWave; s <<= 1) v += __shfl_xor(v, s, kWave);
+    return v;
+}
+
+// one wave per (group, q, m) row; lanes stride over the D channels
+template <typename T, typename A>
+__global__ void __launch_bounds__(kWave)
+msda_bwd_generic_kernel(const Params p, int64_t rows)
+{
+    const int MD = p.M * p.D;
+    const int lane = threadIdx.x;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int m = (int)(row % p.M);
+        const int group = (int)(row / ((int64_t)p.M * p.Lq));
+        const int clip = group / p.frames, t = group - clip * p.frames;
+        const int64_t base = (int64_t)clip * p.frames * p.S * MD + m * p.D;
+        const T *value = static_cast<const T *>(p.value) + base;
+        A *gvalue = static_cast<A *>(p.grad_value) + base;
+        const T *go = static_cast<const T *>(p.grad_out) + row * p.D;
+        for (int arr = 0; arr < 2; ++arr) {
+            const T *loc = static_cast<const T *>(arr ? p.locB : p.locA);
+            const T *aw = static_cast<const T *>(arr ? p.awB : p.awA);
+            T *gloc = static_cast<T *>(arr ? p.glocB : p.glocA);
+            T *gaw = static_cast<T *>(arr ? p.gawB : p.gawA);
+            const int P = arr ? p.PB : p.PA, nl = arr ? p.LB : p.LA, LP = nl * P;
+            for (int pt = 0; pt < LP; ++pt) {
+                const Level lv = make_level(p, t, (arr ? p.LA : 0) + pt / P);
+                const int64_t idx = row * LP + pt;
+                const A a = (A)Store<T>::get(aw + idx);
+                const GTaps<A> tp = make_gtaps<A>((A)Store<T>::get(loc + 2 * idx),
+                                                  (A)Store<T>::get(loc + 2 * idx + 1), lv, MD);
+                A d[4] = {0, 0, 0, 0};
+                if (tp.valid) {
+                    for (int c = lane; c < p.D; c += kWave) {
+                        const A gc = (A)Store<T>::get(go + c);
+                        for (int k = 0; k < 4; ++k) {
+                            if (tp.valid & (1 << k)) {
+                                d[k] += gc * (A)Store<T>::get(value + tp.off[k] + c);
+                                atomic_accumulate(gvalue + tp.off[k] + c, tp.w[k] * a * gc);
+                            }
+                        }
+                    }
+                }
+                for (int k = 0; k < 4; ++k) d[k] = wave_sum<A>(d[k]);
+                if (lane == 0) {
+                    const A hh = 1 - tp.lh, hw = 1 - tp.lw;
+                    const A g_aw = tp.w[0] * d[0] + tp.w[1] * d[1] + tp.w[2] * d[2] + tp.w[3] * d[3];
+                    const A g_w = hh * (d[1] - d[0]) + tp.lh * (d[3] - d[2]);
+                    const A g_h = hw * (d[2] - d[0]) + tp.lw * (d[3] - d[1]);
+                    Store<T>::put(gaw + idx, g_aw);
+                    Store<T>::put(gloc + 2 * idx, (A)lv.W * g_w * a);
+                    Store<T>::put(gloc + 2 * idx + 1, (A)lv.H * g_h * a);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, const char *detail = "")
+{
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+int check_launch(const char *what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return MSDA_ERR_HIP;
+    }
+    return MSDA_OK;
+}
+
+bool aligned16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
+
+size_t tile_lds_bytes(int rpw, int nvl, bool bwd)
+{
+    return (size_t)rpw * kRowSlots * 16 * (bwd ? 3 : 2) + (size_t)nvl * sizeof(Level);
+}
+
+template <typename T, int G>
+int launch_tile(const Params &p, bool bwd, hipStream_t stream)
+{
+    constexpr int RPW = kWave / G;
+    const int64_t tiles = (int64_t)p.groups * ((p.Lq + RPW - 1) / RPW);
+    const int64_t blocks = tiles * p.M;
+    if (blocks > 0x7fffffffLL) return fail(MSDA_ERR_ARG, "msda: problem too large for one launch%s");
+    const size_t lds = tile_lds_bytes(RPW, p.LA + p.LB, bwd);
+    if (bwd)
+        hipLaunchKernelGGL((msda_bwd_tile_kernel<T, G>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
+    else
+        hipLaunchKernelGGL((msda_fwd_tile_kernel<T, G>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
+    return check_launch(bwd ? "msda backward (tile kernel)" : "msda forward (tile kernel)");
+}
+
+template <typename T>
+int dispatch_tile(const Params &p, bool bwd, hipStream_t stream, bool &taken)
+{
+    constexpr int VEC = Store<T>::VEC;
+    taken = false;
+    if (p.D % VEC) return MSDA_OK;
+    const int G = p.D / VEC;
+    // every 16-B lane vector must be aligned: bases 16-B aligned and D a multiple of VEC
+    if (!aligned16(p.value) || (!bwd && !aligned16(p.out)) ||
+        (bwd && (!aligned16(p.grad_out) || !aligned16(p.grad_value))))
+        return MSDA_OK;
+    // element offsets inside one clip slab are 32-bit in the tap records
+    if ((int64_t)p.frames * p.S * p.M * p.D >= 0x7fffffffLL) return MSDA_OK;
+    if (tile_lds_bytes(kWave / (G > 0 ? G : 1), p.LA + p.LB, bwd) > 60 * 1024) return MSDA_OK;
+    taken = true;
+    switch (G) {
+        case 1: return launch_tile<T, 1>(p, bwd, stream);
+        case 2: return launch_tile<T, 2>(p, bwd, stream);
+        case 4: return launch_tile<T, 4>(p, bwd, stream);
+        case 8: return launch_tile<T, 8>(p, bwd, stream);
+        case 16: return launch_tile<T, 16>(p, bwd, stream);
+        case 32: return launch_tile<T, 32>(p, bwd, stream);
+        case 64: return launch_tile<T, 64>(p, bwd, stream);
+        default: taken = false; return MSDA_OK;
+    }
+}
+
+template <typename T, typename A>
+int launch_generic(const Params &p, bool bwd, hipStream_t stream)
+{
+    const int64_t rows = (int64_t)p.groups * p.Lq * p.M;
+    if (bwd) {
+        const unsigned blocks = (unsigned)(rows < 65536 * 16 ? rows : 65536 * 16);
+        hipLaunchKernelGGL((msda_bwd_generic_kernel<T, A>), dim3(blocks), dim3(kWave), 0, stream, p, rows);
+        return check_launch("msda backward (generic kernel)");
+    }
+    const int64_t total = rows * p.D;
+    const int64_t want = (total + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 65536 * 8 ? want : 65536 * 8);
+    hipLaunchKernelGGL((msda_fwd_generic_kernel<T, A>), dim3(blocks), dim3(256), 0, stream, p, total);
+    return check_launch("msda forward (generic kernel)");
+}
+
+int env_force_generic()
+{
+    const char *e = getenv("MSDA_FORCE_GENERIC");   // test hook: exercise the generic kernels
+    return e && e[0] == '1';
+}
+
+int run(int dtype, const Params &p, bool bwd, hipStream_t stream)
+{
+    if (p.groups == 0 || p.Lq == 0) return MSDA_OK;
+    bool taken = false;
+    int rc = MSDA_OK;
+    const bool force_generic = env_force_generic();
+    switch (dtype) {
+        case MSDA_F32:
+            if (!force_generic) rc = dispatch_tile<float>(p, bwd, stream, taken);
+            if (!taken) rc = launch_generic<float, float>(p, bwd, stream);
+            return rc;
+        case MSDA_BF16:
+            if (!force_generic) rc = dispatch_tile<bf16_t>(p, bwd, stream, taken);
+            if (!taken) rc = launch_generic<bf16_t, float>(p, bwd, stream);
+            return rc;
+        case MSDA_F16:
+            if (!force_generic) rc = dispatch_tile<f16_t>(p, bwd, stream, taken);
+            if (!taken) rc = launch_generic<f16_t, float>(p, bwd, stream);
+            return rc;
+        case MSDA_F64:
+            return launch_generic<double, double>(p, bwd, stream);
+        default:
+            return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
+    }
+}
+
+int check_common(const void *value, const int64_t *shapes, const int64_t *lsi, int groups, int S,
+                 int M, int D, int L, int Lq)
+{
+    if (!value || !shapes || !lsi) return fail(MSDA_ERR_ARG, "msda: null pointer argument%s");
+    if (groups < 0 || Lq < 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0)
+        return fail(MSDA_ERR_ARG, "msda: sizes must be positive%s");
+    return MSDA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msda_version(void) { return MSDA_ABI_VERSION; }
+
+const char *msda_last_error(void) { return g_err; }
+
+int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,
+                 const int64_t *level_start_index, const void *sampling_loc, const void *attn_weight,
+                 int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                 int num_query, int num_point, void *out, void *stream)
+{
+    g_err[0] = 0;
+    int rc = check_common(value, spatial_shapes, level_start_index, batch, spatial_size, num_heads,
+                          channels, num_levels, num_query);
+    if (rc) return rc;
+    if (batch == 0 || num_query == 0) return MSDA_OK;
+    if (!sampling_loc || !attn_weight || !out || num_point <= 0)
+        return fail(MSDA_ERR_ARG, "msda_forward: null pointer or non-positive num_point%s");
+    Params p;
+    memset(&p, 0, sizeof(p));
+    p.value = value; p.shapes = spatial_shapes; p.lsi = level_start_index;
+    p.locA = sampling_loc; p.awA = attn_weight; p.out = out;
+    p.groups = batch; p.frames = 1; p.window = 0;
+    p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
+    p.LA = num_levels; p.PA = num_point; p.LB = 0; p.PB = 1;
+    return run(dtype, p, false, static_cast<hipStream_t>(stream));
+}
+
+int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
+                  const int64_t *level_start_index, const void *sampling_loc,
+                  const void *attn_weight, const void *grad_out,
+                  int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                  int num_query, int num_point,
+                  void *grad_value, void *grad_sampling_loc, void *grad_attn_weight, void *stream)
+{
+    g_err[0] = 0;
+    int rc = check_common(value, spatial_shapes, level_start_index, batch, spatial_size, num_heads,
+                          channels, num_levels, num_query);
+    if (rc) return rc;
+    if (batch == 0 || num_query == 0) return MSDA_OK;
+    if (!sampling_loc || !attn_weight || !grad_out || !grad_value || !grad_sampling_loc ||
+        !grad_attn_weight || num_point <= 0)
+        return fail(MSDA_ERR_ARG, "msda_backward: null pointer or non-positive num_point%s");
+    Params p;
+    memset(&p, 0, sizeof(p));
+    p.value = value; p.shapes = spatial_shapes; p.lsi = level_start_index;
+    p.locA = sampling_loc; p.awA = attn_weight; p.grad_out = grad_out;
+    p.grad_value = grad_value; p.glocA = grad_sampling_loc; p.gawA = grad_attn_weight;
+    p.groups = batch; p.frames = 1; p.window = 0;
+    p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
+    p.LA = num_levels; p.PA = num_point; p.LB = 0; p.PB = 1;
+    return run(dtype, p, true, static_cast<hipStream_t>(stream));
+}
+
+int msda_temporal_forward(int dtype, const void *value, const int64_t *spatial_shapes,
+                          const int64_t *level_start_index, const int32_t *frame_table,
+                          const void *loc_curr, const void *aw_curr,
+                          const void *loc_temp, const void *aw_temp,
+                          int clips, int frames, int window, int spatial_size, int num_heads,
+                          int channels, int num_levels, int num_query,
+                          int num_curr_point, int num_temp_point, void *out, void *stream)
+{
+    g_err[0] = 0;
+    int rc = check_common(value, spatial_shapes, level_start_index, clips, spatial_size, num_heads,
+                          channels, num_levels, num_query);
+    if (rc) return rc;
+    if (frames <= 0 || window < 0 || num_curr_point <= 0 || (window > 0 && num_temp_point <= 0))
+        return fail(MSDA_ERR_ARG, "msda_temporal_forward: bad frames/window/points%s");
+    if (clips == 0 || num_query == 0) return MSDA_OK;
+    if (!loc_curr || !aw_curr || !out || (window > 0 && (!frame_table || !loc_temp || !aw_temp)))
+        return fail(MSDA_ERR_ARG, "msda_temporal_forward: null pointer argument%s");
+    Params p;
+    memset(&p, 0, sizeof(p));
+    p.value = value; p.shapes = spatial_shapes; p.lsi = level_start_index; p.ftab = frame_table;
+    p.locA = loc_curr; p.awA = aw_curr; p.locB = loc_temp; p.awB = aw_temp; p.out = out;
+    p.groups = clips * frames; p.frames = frames; p.window = window;
+    p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
+    p.LA = num_levels; p.PA = num_curr_point;
+    p.LB = window * num_levels; p.PB = window > 0 ? num_temp_point : 1;
+    return run(dtype, p, false, static_cast<hipStream_t>(stream));
+}
+
+int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_shapes,
+                           const int64_t *level_start_index, const int32_t *frame_table,
+                           const void *loc_curr, const void *aw_curr,
+                           const void *loc_temp, const void *aw_temp, const void *grad_out,
+                           int clips, int frames, int window, int spatial_size, int num_heads,
+                           int channels, int num_levels, int num_query,
+                           int num_curr_point, int num_temp_point,
+                           void *grad_value, void *grad_loc_curr, void *grad_aw_curr,
+                           void *grad_loc_temp, void *grad_aw_temp, void *stream)
+{
+    g_err[0] = 0;
+    int rc = check_common(value, spatial_shapes, level_start_index, clips, spatial_size, num_heads,
+                          channels, num_levels, num_query);
+    if (rc) return rc;
+    if (frames <= 0 || window < 0 || num_curr_point <= 0 || (window > 0 && num_temp_point <= 0))
+        return fail(MSDA_ERR_ARG, "msda_temporal_backward: bad frames/window/points%s");
+    if (clips == 0 || num_query == 0) return MSDA_OK;
+    if (!loc_curr || !aw_curr || !grad_out || !grad_value || !grad_loc_curr || !grad_aw_curr ||
+        (window > 0 && (!frame_table || !loc_temp || !aw_temp || !grad_loc_temp || !grad_aw_temp)))
+        return fail(MSDA_ERR_ARG, "msda_temporal_backward: null pointer argument%s");
+    Params p;
+    memset(&p, 0, sizeof(p));
+    p.value = value; p.shapes = spatial_shapes; p.lsi = level_start_index; p.ftab = frame_table;
+    p.locA = loc_curr; p.awA = aw_curr; p.locB = loc_temp; p.awB = aw_temp; p.grad_out = grad_out;
+    p.grad_value = grad_value; p.glocA = grad_loc_curr; p.gawA = grad_aw_curr;
+    p.glocB = grad_loc_temp; p.gawB = grad_aw_temp;
+    p.groups = clips * frames; p.frames = frames; p.window = window;
+    p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
+    p.LA = num_levels; p.PA = num_curr_point;
+    p.LB = window * num_levels; p.PB = window > 0 ? num_temp_point : 1;
+    return run(dtype, p, true, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

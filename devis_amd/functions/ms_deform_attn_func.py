@@ -1,0 +1,192 @@
+"""Host side of the operator: same names and contracts as the reference's
+``src/models/ops/functions/ms_deform_attn_func.py``, calling the HIP library through the C ABI.
+
+* ``MSDeformAttnFunction``          -- drop-in for the reference autograd.Function (:21-38).
+* ``MSDeformAttnTemporalFunction``  -- fused current+temporal call used by the temporal modules.
+* ``ms_deform_attn_core_pytorch``   -- the reference's "for debug and test only" pure-PyTorch function
+  (:102-122), kept as part of the import surface.  The operator never routes through it.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _native
+
+
+def _require(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _check_inputs(named):
+    # same preconditions as ms_deform_attn_cuda.cu:28-38 (contiguity, device) -- RuntimeError like
+    # AT_ASSERTM; CPU tensors fail the way ms_deform_attn.h:38,60 does.
+    for name, t in named:
+        _require(isinstance(t, torch.Tensor), "%s must be a tensor" % name)
+        if not t.is_cuda:
+            raise RuntimeError("Not implemented on the CPU (%s is not a GPU tensor)" % name)
+        _require(t.is_contiguous(), "%s tensor has to be contiguous" % name)
+    dev = named[0][1].device
+    for name, t in named:
+        _require(t.device == dev, "%s must be on the same device as value" % name)
+
+
+def _check_op_shapes(value, shapes, lsi, loc, aw):
+    _require(value.dim() == 4 and loc.dim() == 6 and aw.dim() == 5, "bad ranks for value/loc/attn")
+    N, S, M, D = value.shape
+    N2, Lq, M2, L, P, two = loc.shape
+    _require((N2, M2, two) == (N, M, 2), "sampling_locations does not match value")
+    _require(tuple(aw.shape) == (N, Lq, M, L, P), "attention_weights does not match sampling_locations")
+    _require(shapes.dtype == torch.int64 and lsi.dtype == torch.int64,
+             "spatial_shapes / level_start_index must be int64")
+    _require(tuple(shapes.shape) == (L, 2) and tuple(lsi.shape) == (L,), "bad spatial_shapes/level_start_index")
+    _require(loc.dtype == value.dtype and aw.dtype == value.dtype, "value/loc/attn must share one dtype")
+    _native.dtype_code(value.dtype)
+
+
+def _im2col_step(batch, im2col_step):
+    # ms_deform_attn_cuda.cu:50-52
+    step = min(batch, int(im2col_step))
+    _require(step > 0 and batch % step == 0, "batch(%d) must divide im2col_step(%d)" % (batch, step))
+    return step
+
+
+class MSDeformAttnFunction(Function):
+    """Same call contract as the reference (``ms_deform_attn_func.py:21-38``):
+    ``apply(value[N,S,M,D], spatial_shapes[L,2] i64, level_start_index[L] i64,
+    sampling_locations[N,Lq,M,L,P,2], attention_weights[N,Lq,M,L,P], im2col_step) -> [N,Lq,M*D]``;
+    gradients for arguments 0, 3 and 4 only; ``once_differentiable``."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step):
+        _check_inputs([("value", value), ("spatial_shapes", value_spatial_shapes),
+                       ("level_start_index", value_level_start_index),
+                       ("sampling_loc", sampling_locations), ("attn_weight", attention_weights)])
+        _check_op_shapes(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                         attention_weights)
+        N, S, M, D = value.shape
+        Lq = sampling_locations.shape[1]
+        ctx.im2col_step = im2col_step
+        output = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+        if N > 0 and Lq > 0:
+            step = _im2col_step(N, im2col_step)
+            # the reference launches once per chunk of `step` batch rows (cu:61-75); result-neutral
+            for n in range(0, N, step):
+                _native.forward(value[n:n + step], value_spatial_shapes, value_level_start_index,
+                                sampling_locations[n:n + step], attention_weights[n:n + step],
+                                output[n:n + step])
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
+                              sampling_locations, attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, loc, aw = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        N = value.shape[0]
+        acc = _native.acc_dtype(value.dtype)
+        grad_value = torch.zeros(value.shape, dtype=acc, device=value.device)   # cu:121
+        grad_loc = torch.empty_like(loc)        # fully written by the kernel (skipped points -> 0)
+        grad_aw = torch.empty_like(aw)
+        if N > 0 and loc.shape[1] > 0:
+            step = _im2col_step(N, ctx.im2col_step)
+            for n in range(0, N, step):
+                _native.backward(value[n:n + step], shapes, lsi, loc[n:n + step], aw[n:n + step],
+                                 grad_output[n:n + step], grad_value[n:n + step],
+                                 grad_loc[n:n + step], grad_aw[n:n + step])
+        if acc != value.dtype:
+            grad_value = grad_value.to(value.dtype)
+        return grad_value, None, None, grad_loc, grad_aw, None
+
+
+class MSDeformAttnTemporalFunction(Function):
+    """Fused form of the per-frame loop of the temporal modules
+    (``ms_deform_attn.py:325-364, 366-404, 435-460``): for each frame t of each clip
+
+        out[t] = MSDeformAttn(value[t], loc_curr[t], aw_curr[t])
+               + MSDeformAttn(cat_w value[frame_table[t, w]], loc_temp[t], aw_temp[t])
+
+    in ONE launch over ``value [clips*T, S, M, D]``, with no ``value[temporal_frames]`` copies.
+
+    ``apply(value, spatial_shapes[L,2], level_start_index[L], frame_table[T,W] int32,
+    loc_curr[G,Lq,M,L,Pc,2], aw_curr[G,Lq,M,L,Pc], loc_temp[G,Lq,M,W*L,Pt,2], aw_temp[G,Lq,M,W*L,Pt],
+    clips) -> [G, Lq, M*D]`` with ``G = clips*T``."""
+
+    @staticmethod
+    def forward(ctx, value, spatial_shapes, level_start_index, frame_table, loc_curr, aw_curr,
+                loc_temp, aw_temp, clips):
+        _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+                       ("level_start_index", level_start_index), ("frame_table", frame_table),
+                       ("loc_curr", loc_curr), ("aw_curr", aw_curr),
+                       ("loc_temp", loc_temp), ("aw_temp", aw_temp)])
+        _check_op_shapes(value, spatial_shapes, level_start_index, loc_curr, aw_curr)
+        G, S, M, D = value.shape
+        L = spatial_shapes.shape[0]
+        Lq = loc_curr.shape[1]
+        _require(clips > 0 and G % clips == 0, "value.shape[0] must be clips * frames")
+        T = G // clips
+        _require(frame_table.dtype == torch.int32 and frame_table.dim() == 2 and
+                 frame_table.shape[0] == T, "frame_table must be int32 [frames, window]")
+        W = frame_table.shape[1]
+        _require(W > 0, "frame_table needs at least one temporal slot")
+        _require(loc_temp.dim() == 6 and tuple(loc_temp.shape[:4]) == (G, Lq, M, W * L) and
+                 loc_temp.shape[5] == 2, "loc_temp must be [G, Lq, M, window*L, Pt, 2]")
+        _require(tuple(aw_temp.shape) == tuple(loc_temp.shape[:5]), "aw_temp does not match loc_temp")
+        _require(loc_temp.dtype == value.dtype and aw_temp.dtype == value.dtype,
+                 "value/loc/attn must share one dtype")
+        out = torch.empty((G, Lq, M * D), dtype=value.dtype, device=value.device)
+        _native.temporal_forward(value, spatial_shapes, level_start_index, frame_table, loc_curr,
+                                 aw_curr, loc_temp, aw_temp, clips, out)
+        ctx.clips = clips
+        ctx.save_for_backward(value, spatial_shapes, level_start_index, frame_table, loc_curr,
+                              aw_curr, loc_temp, aw_temp)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        acc = _native.acc_dtype(value.dtype)
+        grad_value = torch.zeros(value.shape, dtype=acc, device=value.device)
+        gloc_c, gaw_c = torch.empty_like(loc_c), torch.empty_like(aw_c)
+        gloc_t, gaw_t = torch.empty_like(loc_t), torch.empty_like(aw_t)
+        _native.temporal_backward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, grad_output,
+                                  ctx.clips, grad_value, gloc_c, gaw_c, gloc_t, gaw_t)
+        if acc != value.dtype:
+            grad_value = grad_value.to(value.dtype)
+        return grad_value, None, None, None, gloc_c, gaw_c, gloc_t, gaw_t, None
+
+
+def ms_deform_attn_core_pytorch(value, value_spatial_shapes, sampling_locations, attention_weights):
+    """The reference's debug/test helper (``ms_deform_attn_func.py:102-122``: "for debug and test
+    only, need to use cuda version instead"), kept because ``functions/__init__.py`` exports it.
+
+    Written here as an explicit bilinear gather in torch ops (no ``grid_sample``), so it also runs in
+    bf16/fp16 and on any device.  NOT used by ``MSDeformAttnFunction`` or any module: those call the
+    HIP kernels or raise.  Same signature, same result, same return layout ``[N, Lq, M*D]``."""
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_locations.shape
+    shapes = [(int(h), int(w)) for h, w in value_spatial_shapes.tolist()]
+    out = value.new_zeros((N, Lq, M, D))
+    n_idx = torch.arange(N, device=value.device).view(N, 1, 1, 1)
+    m_idx = torch.arange(M, device=value.device).view(1, 1, M, 1)
+    start = 0
+    for lvl, (H, W) in enumerate(shapes):
+        fmap = value[:, start:start + H * W].reshape(N, H, W, M, D)
+        x = sampling_locations[:, :, :, lvl, :, 0] * W - 0.5      # [N, Lq, M, P]
+        y = sampling_locations[:, :, :, lvl, :, 1] * H - 0.5
+        x0, y0 = torch.floor(x), torch.floor(y)
+        lx, ly = x - x0, y - y0
+        a = attention_weights[:, :, :, lvl]
+        for dy, wy in ((0, 1 - ly), (1, ly)):
+            for dx, wx in ((0, 1 - lx), (1, lx)):
+                xi, yi = (x0 + dx).long(), (y0 + dy).long()
+                inside = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+                tap = fmap[n_idx, yi.clamp(0, H - 1), xi.clamp(0, W - 1), m_idx]   # [N,Lq,M,P,D]
+                wgt = (wy * wx * a * inside.to(value.dtype)).unsqueeze(-1)
+                out = out + (tap * wgt).sum(3)
+        start += H * W
+    return out.reshape(N, Lq, M * D).contiguous()

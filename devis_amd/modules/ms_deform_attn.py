@@ -1,0 +1,293 @@
+"""Host-side mirror of the reference attention modules
+(``/root/reference/src/models/ops/modules/ms_deform_attn.py``): same class names, constructor
+signatures, sub-module names (= state-dict keys, so reference checkpoints load), attributes
+(``im2col_step``), return contracts and parameter initialisation.
+
+What differs is how the operator is driven: the temporal modules build the sampling locations of ALL
+frames at once and make ONE fused call (``MSDeformAttnTemporalFunction``) instead of the reference's
+Python loop of ``2*T`` operator calls plus ``T`` ``value[temporal_frames]`` gather copies
+(ref ``:325-364``, ``:366-404``, ``:435-460``).  Setting ``module.fused = False`` replays the
+reference's call pattern (``2*T`` calls of ``MSDeformAttnFunction``) -- same results, used by tests
+and by the benchmark's "reference call pattern" line.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import constant_, xavier_uniform_
+
+from ..functions import MSDeformAttnFunction, MSDeformAttnTemporalFunction
+
+
+def _is_power_of_2(n):
+    if (not isinstance(n, int)) or (n < 0):
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return (n & (n - 1) == 0) and n != 0
+
+
+def _check_heads(d_model, n_heads):
+    # ref :40-48 / :157-165
+    if d_model % n_heads != 0:
+        raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
+    if not _is_power_of_2(d_model // n_heads):
+        warnings.warn("You'd better set d_model in MSDeformAttn to make the dimension of each attention "
+                      "head a power of 2 which is more efficient in our CUDA implementation.")
+
+
+def _ring_directions(n_heads):
+    """Per-head unit directions on the L-inf ring: (cos, sin)(2*pi*m/M) / max(|cos|, |sin|) (ref :66-68)."""
+    thetas = torch.arange(n_heads, dtype=torch.float32) * (2.0 * math.pi / n_heads)
+    grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+    return grid / grid.abs().max(-1, keepdim=True)[0]
+
+
+def _offset_bias(n_heads, mid_shape, n_points):
+    """Bias of a sampling-offset Linear laid out [heads, *mid_shape, points, 2]: point i of every head
+    starts (i+1) steps along the head's direction (ref :69-76, :177-199)."""
+    steps = torch.arange(1, n_points + 1, dtype=torch.float32).view(n_points, 1)
+    per_head = _ring_directions(n_heads).view(n_heads, 1, 2) * steps            # [M, P, 2]
+    per_head = per_head.view((n_heads,) + (1,) * len(mid_shape) + (n_points, 2))
+    return per_head.expand((n_heads,) + tuple(mid_shape) + (n_points, 2)).reshape(-1)
+
+
+def _normalizer(spatial_shapes):
+    """(W_l, H_l) per level: divides pixel offsets into normalised coordinates (ref :113-114)."""
+    return torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+
+
+def _locations(reference, offsets, normalizer, n_points):
+    """Sampling locations from reference points broadcastable to [..., Lq, 1, L, 1, 2|4] and offsets
+    [..., Lq, M, L, P, 2] (ref :112-121): 2-d refs add offsets in pixels of each level, 4-d refs (boxes)
+    add offsets as a fraction of half the box size."""
+    if reference.shape[-1] == 2:
+        return reference + offsets / normalizer[None, None, None, :, None, :]
+    if reference.shape[-1] == 4:
+        return reference[..., :2] + offsets / n_points * reference[..., 2:] * 0.5
+    raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+        reference.shape[-1]))
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        """Multi-Scale Deformable Attention Module (ref ``ms_deform_attn.py:30-132``).
+        :param d_model      hidden dimension
+        :param n_levels     number of feature levels
+        :param n_heads      number of attention heads
+        :param n_points     number of sampling points per attention head per feature level
+        """
+        super().__init__()
+        _check_heads(d_model, n_heads)
+        self.im2col_step = 64
+        self.d_model = d_model
+        self.n_levels = n_levels
+        self.n_heads = n_heads
+        self.n_points = n_points
+
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        constant_(self.sampling_offsets.weight.data, 0.)
+        with torch.no_grad():
+            self.sampling_offsets.bias.copy_(_offset_bias(self.n_heads, (self.n_levels,), self.n_points))
+        constant_(self.attention_weights.weight.data, 0.)
+        constant_(self.attention_weights.bias.data, 0.)
+        xavier_uniform_(self.value_proj.weight.data)
+        constant_(self.value_proj.bias.data, 0.)
+        xavier_uniform_(self.output_proj.weight.data)
+        constant_(self.output_proj.bias.data, 0.)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
+                input_level_start_index, input_padding_mask):
+        """
+        :param query                    (N, Length_{query}, C)
+        :param reference_points         (N, Length_{query}, n_levels, 2) in [0, 1], or (..., 4) boxes
+        :param input_flatten            (N, sum_l H_l*W_l, C)
+        :param input_spatial_shapes     (n_levels, 2) [(H_0, W_0), ...]
+        :param input_level_start_index  (n_levels,)
+        :param input_padding_mask       (N, sum_l H_l*W_l), True for padding elements
+        :return (output (N, Length_{query}, C), None)
+        """
+        N, Len_q, _ = query.shape
+        N, Len_in, _ = input_flatten.shape
+        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, Len_in, M, self.d_model // M)
+        offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
+        weights = F.softmax(self.attention_weights(query).view(N, Len_q, M, L * P), -1)
+        weights = weights.view(N, Len_q, M, L, P)
+        locations = _locations(reference_points[:, :, None, :, None, :], offsets,
+                               _normalizer(input_spatial_shapes), P)
+        output = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes,
+                                            input_level_start_index, locations.contiguous(),
+                                            weights.contiguous(), self.im2col_step)
+        return self.output_proj(output), None
+
+
+class TemporalMSDeformAttnBase(nn.Module):
+    """Shared part of the temporal modules (ref ``:137-285``)."""
+
+    fused = True   # False: replay the reference's 2*T-call pattern (same results)
+
+    def __init__(self, n_frames=36, d_model=256, n_levels=4, t_window=2, n_heads=8, n_curr_points=4,
+                 n_temporal_points=2):
+        """
+        :param n_curr_points      sampling points per head per level in the query's own frame
+        :param n_temporal_points  sampling points per head per level in each of the t_window other frames
+        """
+        super().__init__()
+        _check_heads(d_model, n_heads)
+        self.im2col_step = 64
+        self.d_model = d_model
+        self.n_frames = n_frames
+        self.n_levels = n_levels
+        self.t_window = t_window
+        self.n_heads = n_heads
+        self.n_curr_points = n_curr_points
+        self.n_temporal_points = n_temporal_points
+
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_curr_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_curr_points)
+        self.temporal_sampling_offsets = nn.Linear(
+            d_model, n_heads * n_levels * t_window * n_temporal_points * 2)
+        self.temporal_attention_weights = nn.Linear(
+            d_model, n_heads * n_levels * t_window * n_temporal_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        constant_(self.sampling_offsets.weight.data, 0.)
+        constant_(self.temporal_sampling_offsets.weight.data, 0.)
+        with torch.no_grad():
+            self.sampling_offsets.bias.copy_(
+                _offset_bias(self.n_heads, (self.n_levels,), self.n_curr_points))
+            self.temporal_sampling_offsets.bias.copy_(
+                _offset_bias(self.n_heads, (self.t_window, self.n_levels), self.n_temporal_points))
+        for lin in (self.attention_weights, self.temporal_attention_weights):
+            constant_(lin.weight.data, 0.)
+            constant_(lin.bias.data, 0.)
+        for lin in (self.value_proj, self.output_proj):
+            xavier_uniform_(lin.weight.data)
+            constant_(lin.bias.data, 0.)
+
+    def _compute_deformable_attention(self, query, input_flatten):
+        """value [T,S,M,D]; current offsets [T,Lq,M,L,Pc,2]; temporal offsets [T,Lq,M,W*L,Pt,2]
+        (slot-major, level-minor); attention weights from ONE softmax over the Pc*L + W*L*Pt logits of
+        a (frame, query, head), split back into current [T,Lq,M,L,Pc] and temporal [T,Lq,M,W*L,Pt]
+        (ref :225-266; note: no padding mask on value, ref :229-230)."""
+        T, Len_q, _ = query.shape
+        M, L, W = self.n_heads, self.n_levels, self.t_window
+        Pc, Pt = self.n_curr_points, self.n_temporal_points
+        value = self.value_proj(input_flatten).view(T, input_flatten.shape[1], M, self.d_model // M)
+        temporal_offsets = self.temporal_sampling_offsets(query).view(T, Len_q, M, W * L, Pt, 2)
+        logits = torch.cat([self.attention_weights(query).view(T, Len_q, M, L * Pc),
+                            self.temporal_attention_weights(query).view(T, Len_q, M, W * L * Pt)], 3)
+        weights = F.softmax(logits, -1)
+        weights_curr = weights[..., :L * Pc].reshape(T, Len_q, M, L, Pc)
+        weights_temporal = weights[..., L * Pc:].reshape(T, Len_q, M, W * L, Pt)
+        curr_offsets = self.sampling_offsets(query).view(T, Len_q, M, L, Pc, 2)
+        return value, curr_offsets, temporal_offsets, weights_curr, weights_temporal
+
+    @staticmethod
+    def _frame_table(temporal_offsets, n_frames, device):
+        """[T, W] absolute frame indices: frame_table[t] = temporal_offsets[t] + t (ref :339, :445)."""
+        table = torch.stack([o.to(device) for o in temporal_offsets]) \
+            + torch.arange(n_frames, device=device)[:, None]
+        return table.to(torch.int32).contiguous()
+
+    def _attend(self, value, shapes, level_start, temporal_offsets, loc_curr, w_curr, loc_temp, w_temp):
+        """[T, Lq, C]: current-frame + temporal attention for every frame."""
+        T = value.shape[0]
+        if self.fused:
+            table = self._frame_table(temporal_offsets, T, value.device)
+            return MSDeformAttnTemporalFunction.apply(
+                value.contiguous(), shapes[0], level_start[0], table, loc_curr.contiguous(),
+                w_curr.contiguous(), loc_temp.contiguous(), w_temp.contiguous(), 1)
+        # the reference's call pattern: per frame one current call and one call on the stacked frames
+        frames = []
+        for t in range(T):
+            out_curr = MSDeformAttnFunction.apply(
+                value[t][None].contiguous(), shapes[0], level_start[0], loc_curr[t][None].contiguous(),
+                w_curr[t][None].contiguous(), self.im2col_step)
+            stacked = value[temporal_offsets[t] + t].flatten(0, 1)[None]
+            out_temp = MSDeformAttnFunction.apply(
+                stacked.contiguous(), shapes[1], level_start[1], loc_temp[t][None].contiguous(),
+                w_temp[t][None].contiguous(), self.im2col_step)
+            frames.append(out_curr + out_temp)
+        return torch.cat(frames, dim=0)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
+                input_level_start_index, temporal_offsets):
+        raise NotImplementedError
+
+
+class TemporalMSDeformAttnDecoder(TemporalMSDeformAttnBase):
+    """Ref ``:288-414``.  Returns the 5-tuple ``(output [1, T*q, C], [T x current locations
+    [1,q,M,L,Pc,2]], [T x temporal locations [1,q,M,W*L,Pt,2]], weights_curr [T,q,M,L,Pc],
+    weights_temporal [T,q,M,W*L,Pt])`` that ``visualize_att_maps.py:158-169`` hooks."""
+
+    def __init__(self, n_frames=36, d_model=256, n_levels=4, t_window=2, n_heads=8, n_curr_points=4,
+                 n_temporal_points=2, dec_instance_aware_att=True):
+        super().__init__(n_frames=n_frames, d_model=d_model, n_levels=n_levels, t_window=t_window,
+                         n_heads=n_heads, n_curr_points=n_curr_points,
+                         n_temporal_points=n_temporal_points)
+        self.dec_instance_aware_att = dec_instance_aware_att
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
+                input_level_start_index, temporal_offsets):
+        T = input_flatten.shape[0]
+        per_frame = query.shape[1] // T
+        query = query.reshape(T, per_frame, query.shape[-1])
+        if reference_points.shape[0] != T:
+            reference_points = reference_points.reshape((T, per_frame) + reference_points.shape[-2:])
+        if reference_points.shape[-1] not in (2, 4):
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+                reference_points.shape[-1]))
+        value, off_curr, off_temp, w_curr, w_temp = self._compute_deformable_attention(query, input_flatten)
+
+        W = self.t_window
+        normalizer = _normalizer(input_spatial_shapes[0])
+        loc_curr = _locations(reference_points[:, :, None, :, None, :], off_curr, normalizer,
+                              self.n_curr_points)
+        if self.dec_instance_aware_att:
+            # reference point of the SAME instance in each of the other frames (ref :342-344)
+            table = self._frame_table(temporal_offsets, T, reference_points.device).long()
+            ref_t = reference_points[table].permute(0, 2, 1, 3, 4).flatten(2, 3)      # [T, q, W*L, d]
+        else:
+            ref_t = reference_points.repeat(1, 1, W, 1)                               # ref :346-347
+        loc_temp = _locations(ref_t[:, :, None, :, None, :], off_temp, normalizer.repeat(W, 1),
+                              self.n_temporal_points)
+
+        output = self._attend(value, input_spatial_shapes, input_level_start_index, temporal_offsets,
+                              loc_curr, w_curr, loc_temp, w_temp)
+        output = self.output_proj(output.flatten(0, 1)[None])
+        return (output, [loc_curr[t][None] for t in range(T)], [loc_temp[t][None] for t in range(T)],
+                w_curr, w_temp)
+
+
+class TemporalMSDeformAttnEncoder(TemporalMSDeformAttnBase):
+    """Ref ``:417-464``: queries are the pixels themselves (Lq = S); temporal sampling in the other
+    frames starts from the level-0 reference point (ref :447).  Returns ``(output [T, S, C], None)``."""
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
+                input_level_start_index, temporal_offsets):
+        assert reference_points.shape[-1] == 2
+        value, off_curr, off_temp, w_curr, w_temp = self._compute_deformable_attention(query, input_flatten)
+        normalizer = _normalizer(input_spatial_shapes[0])
+        loc_curr = _locations(reference_points[:, :, None, :, None, :], off_curr, normalizer,
+                              self.n_curr_points)
+        ref_t = reference_points[:, :, 0][:, :, None, None, None, :]
+        loc_temp = _locations(ref_t, off_temp, normalizer.repeat(self.t_window, 1), self.n_temporal_points)
+        output = self._attend(value, input_spatial_shapes, input_level_start_index, temporal_offsets,
+                              loc_curr, w_curr, loc_temp, w_temp)
+        return self.output_proj(output), None

@@ -1,0 +1,141 @@
+/*
+ * msda.h -- C ABI of the MI355X-native multi-scale deformable attention library (libmsda_hip.so).
+ *
+ * This is the drop-in boundary for DeVIS's only native component.  It replaces the two functions the
+ * reference's pybind module `MultiScaleDeformableAttention` exports
+ *     ms_deform_attn_forward / ms_deform_attn_backward
+ *         (/root/reference/src/models/ops/src/vision.cpp:13-16, src/ms_deform_attn.h:20-60,
+ *          src/cuda/ms_deform_attn_cuda.cu:20-153)
+ * and adds one fused entry point pair for the per-frame loop of the temporal modules
+ *         (src/models/ops/modules/ms_deform_attn.py:325-364, 366-404, 435-460).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer (HBM) unless stated;
+ *   - tensors are dense row-major ("contiguous") in the layouts named below;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue work,
+ *     they never allocate, never synchronise and keep no global state, so they are re-entrant
+ *     (forward on the Python thread, backward on an autograd worker -- as in the reference);
+ *   - return value: MSDA_OK (0) or a negative msda_status; on failure msda_last_error() returns a
+ *     thread-local message.  Unlike the reference (errors only printf'd,
+ *     ms_deform_im2col_cuda.cuh:948-952,1321-1325) launch failures ARE reported;
+ *   - `dtype` names the storage type of value / sampling_loc / attn_weight / out / grad_out /
+ *     grad_sampling_loc / grad_attn_weight.  Arithmetic is fp32 for f32/bf16/f16 and fp64 for f64.
+ *     `grad_value` is ALWAYS an accumulation buffer in the arithmetic type (float for f32/bf16/f16,
+ *     double for f64), must be zero-filled by the caller (the reference does at::zeros_like,
+ *     ms_deform_attn_cuda.cu:121) and is accumulated into with hardware float atomics.
+ *
+ * Symbols:  N batch, S = sum_l H_l*W_l, M heads, D channels per head, Lq queries, L levels,
+ *           P points;  spatial_shapes[l] = (H_l, W_l);  sampling_loc[..., 0] = x (width), 1 = y.
+ */
+#ifndef MSDA_H_
+#define MSDA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSDA_ABI_VERSION 1
+
+enum msda_dtype { MSDA_F32 = 0, MSDA_F64 = 1, MSDA_BF16 = 2, MSDA_F16 = 3 };
+
+enum msda_status {
+    MSDA_OK = 0,
+    MSDA_ERR_ARG = -1,     /* null pointer, non-positive size, unsupported combination */
+    MSDA_ERR_DTYPE = -2,   /* unknown dtype code */
+    MSDA_ERR_HIP = -3      /* HIP runtime / launch error (message carries hipGetErrorString) */
+};
+
+/* ABI version of the loaded library (== MSDA_ABI_VERSION it was built with). */
+int msda_version(void);
+
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char *msda_last_error(void);
+
+/*
+ * Forward of one MSDeformAttnFunction call.
+ * Replaces ms_deform_attn_forward (vision.cpp:14 -> ms_deform_attn_cuda.cu:20-80 ->
+ * ms_deformable_im2col_gpu_kernel, ms_deform_im2col_cuda.cuh:237-299).
+ *
+ *   value             [N, S, M, D]         dtype
+ *   spatial_shapes    [L, 2]  int64 (H,W)  device (dereferenced in-kernel, as cuh:274-277)
+ *   level_start_index [L]     int64        device
+ *   sampling_loc      [N, Lq, M, L, P, 2]  dtype
+ *   attn_weight       [N, Lq, M, L, P]     dtype
+ *   out               [N, Lq, M*D]         dtype, fully overwritten (need not be zeroed)
+ *
+ * The whole batch is one launch: the reference's im2col_step only chunks the batch into
+ * pointer-offset launches (ms_deform_attn_cuda.cu:50-75) and is result-neutral; the host side
+ * validates it (same divisibility error) and may pass a sub-batch here to reproduce the chunking.
+ */
+int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,
+                 const int64_t *level_start_index, const void *sampling_loc, const void *attn_weight,
+                 int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                 int num_query, int num_point, void *out, void *stream);
+
+/*
+ * Backward of one MSDeformAttnFunction call.
+ * Replaces ms_deform_attn_backward (vision.cpp:15 -> ms_deform_attn_cuda.cu:83-153 -> every
+ * ms_deformable_col2im_gpu_kernel_* variant, ms_deform_im2col_cuda.cuh:301-920,956-1326).
+ *
+ *   grad_out          [N, Lq, M*D]         dtype
+ *   grad_value        [N, S, M, D]         float (double for MSDA_F64); caller zero-fills; accumulated
+ *   grad_sampling_loc [N, Lq, M, L, P, 2]  dtype, fully overwritten (skipped points get 0)
+ *   grad_attn_weight  [N, Lq, M, L, P]     dtype, fully overwritten
+ */
+int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
+                  const int64_t *level_start_index, const void *sampling_loc,
+                  const void *attn_weight, const void *grad_out,
+                  int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                  int num_query, int num_point,
+                  void *grad_value, void *grad_sampling_loc, void *grad_attn_weight, void *stream);
+
+/*
+ * Fused temporal forward: for every frame t of every clip, current-frame attention on value[t] PLUS
+ * temporal attention on the `window` frames frame_table[t, :], summed -- one launch instead of the
+ * reference's 2*T launches and T gather-copies `value[temporal_frames].flatten(0,1)` per layer
+ * (ms_deform_attn.py:333,340,358 / 374,381,397 / 441,446,454).  Result equals
+ *     out[c,t] = MSDA(value[c,t], shapes, lsi, loc_curr[c,t], aw_curr[c,t])
+ *              + MSDA(cat_w value[c, frame_table[t,w]], shapes.repeat(window), ...,
+ *                     loc_temp[c,t], aw_temp[c,t])
+ *
+ *   value        [clips*frames, S, M, D]                      dtype
+ *   spatial_shapes / level_start_index   [L,2] / [L] int64    the CURRENT-frame pyramid
+ *   frame_table  [frames, window] int32   device; absolute frame index inside the clip (repeats allowed,
+ *                                         devis_transformer.py:103-113 mirrors frames at clip borders)
+ *   loc_curr     [clips*frames, Lq, M, L, Pc, 2]              dtype
+ *   aw_curr      [clips*frames, Lq, M, L, Pc]                 dtype
+ *   loc_temp     [clips*frames, Lq, M, window*L, Pt, 2]       dtype (slot-major, level-minor:
+ *                                                             ms_deform_attn.py:232-238 flatten(3,4))
+ *   aw_temp      [clips*frames, Lq, M, window*L, Pt]          dtype
+ *   out          [clips*frames, Lq, M*D]                      dtype, fully overwritten
+ */
+int msda_temporal_forward(int dtype, const void *value, const int64_t *spatial_shapes,
+                          const int64_t *level_start_index, const int32_t *frame_table,
+                          const void *loc_curr, const void *aw_curr,
+                          const void *loc_temp, const void *aw_temp,
+                          int clips, int frames, int window, int spatial_size, int num_heads,
+                          int channels, int num_levels, int num_query,
+                          int num_curr_point, int num_temp_point, void *out, void *stream);
+
+/*
+ * Fused temporal backward.  grad_value [clips*frames, S, M, D] is the accumulation buffer (float /
+ * double, zero-filled by the caller): contributions of the current-frame and of every temporal slot
+ * land in it directly, replacing the reference's index_put-add backward of value[temporal_frames].
+ * The four grad_loc / grad_aw outputs have the shapes of their inputs and are fully overwritten.
+ */
+int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_shapes,
+                           const int64_t *level_start_index, const int32_t *frame_table,
+                           const void *loc_curr, const void *aw_curr,
+                           const void *loc_temp, const void *aw_temp, const void *grad_out,
+                           int clips, int frames, int window, int spatial_size, int num_heads,
+                           int channels, int num_levels, int num_query,
+                           int num_curr_point, int num_temp_point,
+                           void *grad_value, void *grad_loc_curr, void *grad_aw_curr,
+                           void *grad_loc_temp, void *grad_aw_temp, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSDA_H_ */

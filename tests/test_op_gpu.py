@@ -1,0 +1,240 @@
+"""GPU parity tests of the operator: HIP kernels (through the C ABI, via the reference-shaped
+autograd.Function) against the CPU oracle and the committed golden vectors.
+
+Tolerances: BASELINE.json asks <= 1e-4 max-abs in fp32 and <= 1e-2 in bf16 vs the reference oracle on
+identical (already rounded) inputs; the bounds used here are much tighter and written per test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import OP_FIXTURES, golden
+from helpers import (PYR_A, make_inputs, make_temporal_inputs, oracle_fwd_bwd, round_to,
+                     temporal_reference)
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _run_op(d, dtype, step=64):
+    from devis_amd.functions import MSDeformAttnFunction
+    v, l, a = (torch.from_numpy(np.asarray(d[k], dtype=np.float64)).to(DEV, dtype).requires_grad_(True)
+               for k in ("value", "loc", "aw"))
+    shapes = torch.from_numpy(d["shapes"]).to(DEV)
+    lsi = torch.from_numpy(d["lsi"]).to(DEV)
+    out = MSDeformAttnFunction.apply(v, shapes, lsi, l, a, step)
+    go = torch.from_numpy(np.asarray(d["grad_out"], dtype=np.float64)).to(DEV, dtype)
+    gv, gl, ga = torch.autograd.grad(out, (v, l, a), go)
+    torch.cuda.synchronize()
+    return [t.detach().double().cpu().numpy() for t in (out, gv, gl, ga)]
+
+
+def _golden_dict(name):
+    g = golden(name)
+    return g, dict(value=g["value"], shapes=g["spatial_shapes"], lsi=g["level_start_index"],
+                   loc=g["sampling_locations"], aw=g["attention_weights"], grad_out=g["grad_output"])
+
+
+def _maxabs(a, b):
+    return float(np.abs(a - b).max()) if a.size else 0.0
+
+
+@pytest.mark.parametrize("name", OP_FIXTURES)
+def test_fp64_matches_golden(name):
+    """Reference test.py:30-42 (fp64 forward allclose) + gradients, on every golden fixture."""
+    g, d = _golden_dict(name)
+    out, gv, gl, ga = _run_op(d, torch.float64)
+    np.testing.assert_allclose(out, g["out"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(gv, g["grad_value"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(ga, g["grad_attn_weight"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(gl, g["grad_sampling_loc"], rtol=1e-8, atol=1e-11)
+
+
+@pytest.mark.parametrize("name", OP_FIXTURES)
+def test_fp32_matches_golden(name):
+    g, d = _golden_dict(name)
+    out, gv, gl, ga = _run_op(d, torch.float32)
+    assert _maxabs(out, g["out"]) <= 1e-6          # BASELINE bar: 1e-4
+    scale = lambda x: max(1.0, float(np.abs(x).max()))
+    assert _maxabs(gv, g["grad_value"]) <= 2e-5 * scale(g["grad_value"])
+    assert _maxabs(ga, g["grad_attn_weight"]) <= 2e-5 * scale(g["grad_attn_weight"])
+    assert _maxabs(gl, g["grad_sampling_loc"]) <= 2e-5 * scale(g["grad_sampling_loc"])
+
+
+@pytest.mark.parametrize("name", ["op_devis_small", "op_cfg1", "op_generic_D64", "op_out_of_range"])
+def test_generic_kernels_fp32(name, monkeypatch):
+    """MSDA_FORCE_GENERIC=1 routes fp32 through the any-shape kernels."""
+    monkeypatch.setenv("MSDA_FORCE_GENERIC", "1")
+    g, d = _golden_dict(name)
+    out, gv, gl, ga = _run_op(d, torch.float32)
+    assert _maxabs(out, g["out"]) <= 1e-6
+    assert _maxabs(gv, g["grad_value"]) <= 2e-5 * max(1.0, np.abs(g["grad_value"]).max())
+    assert _maxabs(gl, g["grad_sampling_loc"]) <= 2e-5 * max(1.0, np.abs(g["grad_sampling_loc"]).max())
+    assert _maxabs(ga, g["grad_attn_weight"]) <= 2e-5 * max(1.0, np.abs(g["grad_attn_weight"]).max())
+
+
+@pytest.mark.parametrize("dtype,tol_out,tol_rel", [(torch.bfloat16, 1e-2, 2e-2), (torch.float16, 1e-3, 4e-3)])
+@pytest.mark.parametrize("D", [32, 64, 8])
+def test_reduced_precision_vs_fp64_oracle_on_rounded_inputs(dtype, tol_out, tol_rel, D):
+    """bf16/f16 storage, fp32 arithmetic.  The oracle runs in fp64 on the SAME rounded inputs."""
+    d = make_inputs(7, 2, 8, D, 33, [(12, 20), (6, 10), (3, 5), (2, 3)], 4, "wide", np.float64, value_scale=1.0)
+    d = round_to(d, dtype)
+    ref = oracle_fwd_bwd(d, np.float64)
+    got = _run_op(d, dtype)
+    assert _maxabs(got[0], ref[0]) <= tol_out * max(1.0, np.abs(ref[0]).max())
+    for a, b in zip(got[1:], ref[1:]):
+        assert _maxabs(a, b) <= tol_rel * max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("step", [1, 2, 3, 6, 64])
+def test_im2col_step_is_result_neutral(step):
+    """ms_deform_attn_cuda.cu:50-75: chunked launches with pointer offsets."""
+    g, d = _golden_dict("op_batched_im2col")
+    out, gv, gl, ga = _run_op(d, torch.float64, step=step)
+    np.testing.assert_allclose(out, g["out"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(gv, g["grad_value"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(gl, g["grad_sampling_loc"], rtol=1e-8, atol=1e-11)
+
+
+def test_im2col_step_must_divide_batch():
+    """cu:52: batch % min(batch, im2col_step) != 0 raises."""
+    from devis_amd.functions import MSDeformAttnFunction
+    _, d = _golden_dict("op_batched_im2col")      # N = 6
+    args = [torch.from_numpy(d[k]).to(DEV) for k in ("value", "shapes", "lsi", "loc", "aw")]
+    with pytest.raises(RuntimeError, match="must divide"):
+        MSDeformAttnFunction.apply(*args, 4)
+
+
+def test_error_contract():
+    from devis_amd.functions import MSDeformAttnFunction
+    _, d = _golden_dict("op_testpy_shape")
+    v, s, i, l, a = [torch.from_numpy(d[k]) for k in ("value", "shapes", "lsi", "loc", "aw")]
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):       # ms_deform_attn.h:38
+        MSDeformAttnFunction.apply(v, s, i, l, a, 2)
+    v, s, i, l, a = [t.to(DEV) for t in (v, s, i, l, a)]
+    with pytest.raises(RuntimeError, match="contiguous"):                       # cu:28-32
+        MSDeformAttnFunction.apply(v.transpose(2, 3).contiguous().transpose(2, 3), s, i, l, a, 2)
+    with pytest.raises(RuntimeError):
+        MSDeformAttnFunction.apply(v, s, i, l.double(), a, 2)
+
+
+def test_gradcheck_fp64_reference_procedure():
+    """Reference test.py:61-84: gradcheck at D in {30,32,64,71,1025} on its shapes (2048/3096 only
+    repeat the D>1024 kernel classes of the reference and are skipped for time)."""
+    from devis_amd.functions import MSDeformAttnFunction
+    N, M, Lq, L, P = 1, 2, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long, device=DEV)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = 30
+    torch.manual_seed(3)
+    for D in (30, 32, 64, 71, 1025):
+        value = (torch.rand(N, S, M, D, device=DEV) * 0.01).double().requires_grad_(True)
+        loc = torch.rand(N, Lq, M, L, P, 2, device=DEV).double().requires_grad_(True)
+        aw = torch.rand(N, Lq, M, L, P, device=DEV) + 1e-5
+        aw = (aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)).double().requires_grad_(True)
+        assert torch.autograd.gradcheck(MSDeformAttnFunction.apply, (value, shapes, lsi, loc, aw, 2))
+
+
+def test_tail_tile_and_empty():
+    """Query counts that do not fill a wave tile, and empty inputs."""
+    from devis_amd.functions import MSDeformAttnFunction
+    for Lq in (1, 7, 9, 65):
+        d = make_inputs(100 + Lq, 2, 8, 32, Lq, [(5, 7), (3, 4)], 3, "wide", np.float32)
+        ref = oracle_fwd_bwd(d, np.float64)
+        got = _run_op(d, torch.float32)
+        assert _maxabs(got[0], ref[0]) <= 1e-6
+        assert _maxabs(got[1], ref[1]) <= 1e-4 and _maxabs(got[2], ref[2]) <= 1e-3 and _maxabs(got[3], ref[3]) <= 1e-4
+    d = make_inputs(1, 1, 8, 32, 1, [(5, 7)], 2)
+    v, s, i = (torch.from_numpy(d[k]).to(DEV) for k in ("value", "shapes", "lsi"))
+    out = MSDeformAttnFunction.apply(v, s, i, torch.zeros(1, 0, 8, 1, 2, 2, device=DEV),
+                                     torch.zeros(1, 0, 8, 1, 2, device=DEV), 64)
+    assert out.shape == (1, 0, 256)
+
+
+def test_devis_decoder_call_shapes_fp32():
+    """cfg3 per-frame calls at full size: current (L=4) and temporal (L=20, S_in=5S), 300 queries."""
+    for L_rep, seed in ((1, 5), (5, 6)):
+        d = make_inputs(seed, 1, 8, 32, 300, PYR_A * L_rep, 4, "wide", np.float32)
+        ref = oracle_fwd_bwd(d, np.float64)
+        got = _run_op(d, torch.float32)
+        assert _maxabs(got[0], ref[0]) <= 1e-6
+        assert _maxabs(got[1], ref[1]) <= 1e-4
+        assert _maxabs(got[2], ref[2]) <= 1e-4 * max(1.0, np.abs(ref[2]).max())
+        assert _maxabs(got[3], ref[3]) <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# fused temporal op
+# ---------------------------------------------------------------------------------------------
+def _run_temporal(d, dtype, clips=1):
+    from devis_amd.functions import MSDeformAttnTemporalFunction
+    f = lambda k: torch.from_numpy(np.asarray(d[k], dtype=np.float64)).to(DEV, dtype).requires_grad_(True)
+    v, lc, ac, lt, at = f("value"), f("loc_c"), f("aw_c"), f("loc_t"), f("aw_t")
+    shapes = torch.from_numpy(d["shapes"]).to(DEV)
+    lsi = torch.from_numpy(d["lsi"]).to(DEV)
+    ftab = torch.from_numpy(d["ftab"]).to(DEV)
+    out = MSDeformAttnTemporalFunction.apply(v, shapes, lsi, ftab, lc, ac, lt, at, clips)
+    go = torch.from_numpy(np.asarray(d["grad_out"], dtype=np.float64)).to(DEV, dtype)
+    grads = torch.autograd.grad(out, (v, lc, ac, lt, at), go)
+    torch.cuda.synchronize()
+    return [t.detach().double().cpu().numpy() for t in (out,) + tuple(grads)]
+
+
+@pytest.mark.parametrize("dtype,D", [(torch.float64, 32), (torch.float32, 32), (torch.float32, 20),
+                                     (torch.float64, 7)])
+def test_temporal_fused_equals_reference_call_pattern(dtype, D):
+    d = make_temporal_inputs(21, T=4, W=3, M=8, D=D, Lq=19, shapes=[(6, 5), (3, 3)], Pc=4, Pt=2)
+    ref = temporal_reference(*(np.asarray(d[k], dtype=np.float64) if d[k].dtype.kind == "f" else d[k]
+                               for k in ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t",
+                                         "grad_out")))
+    got = _run_temporal(d, dtype)
+    tol = 1e-11 if dtype == torch.float64 else 2e-5
+    for a, b in zip(got, ref):
+        assert _maxabs(a, b) <= tol * max(1.0, np.abs(b).max())
+
+
+def test_temporal_fused_window_with_repeated_frames_and_clips():
+    """Mirrored window (devis_transformer.py:103-113: repeated frame ids) and a batch of clips."""
+    T, W = 5, 2
+    ftab = np.array([[1, 1], [0, 2], [1, 3], [2, 4], [3, 3]], dtype=np.int32)
+    clips = 3
+    ds = [make_temporal_inputs(30 + c, T, W, 8, 32, 11, [(6, 5), (3, 3)], 3, 2, ftab=ftab) for c in range(clips)]
+    cat = {k: (np.concatenate([x[k] for x in ds], 0) if k not in ("shapes", "lsi", "ftab") else ds[0][k])
+           for k in ds[0]}
+    got = _run_temporal(cat, torch.float32, clips=clips)
+    for c, d in enumerate(ds):
+        ref = temporal_reference(*(np.asarray(d[k], dtype=np.float64) if d[k].dtype.kind == "f" else d[k]
+                                   for k in ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t",
+                                             "grad_out")))
+        for a, b in zip(got, ref):
+            assert _maxabs(a[c * T:(c + 1) * T], b) <= 2e-5 * max(1.0, np.abs(b).max())
+
+
+def test_full_size_properties_cfg3():
+    """BASELINE cfg3 at full size (T=6, q=300, pyramid A, L=4, K=4, C=256), through size-independent
+    properties: linearity in value, the sum rule for constant value maps, and fwd/bwd adjointness."""
+    from devis_amd.functions import MSDeformAttnTemporalFunction
+    d = make_temporal_inputs(77, T=6, W=5, M=8, D=32, Lq=300, shapes=PYR_A, Pc=4, Pt=4)
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in d.items()}
+    # in-range locations only for the constant-map rule
+    run = lambda v, lc, lt: MSDeformAttnTemporalFunction.apply(
+        v, t["shapes"], t["lsi"], t["ftab"], lc, t["aw_c"], lt, t["aw_t"], 1)
+    out1 = run(t["value"], t["loc_c"], t["loc_t"])
+    v2 = torch.randn_like(t["value"])
+    out2 = run(v2, t["loc_c"], t["loc_t"])
+    out12 = run(t["value"] * 0.5 + v2 * 2.0, t["loc_c"], t["loc_t"])
+    assert (out12 - (0.5 * out1 + 2.0 * out2)).abs().max().item() <= 1e-4
+    # constant value = 1 and interior locations: out = sum of attention weights = 1 (joint softmax)
+    lc = t["loc_c"].clamp(0.2, 0.8)
+    lt = t["loc_t"].clamp(0.2, 0.8)
+    ones = run(torch.ones_like(t["value"]), lc, lt)
+    assert (ones - 1.0).abs().max().item() <= 1e-5
+    # adjointness: <out(value), g> == <value, grad_value(g)>
+    v = t["value"].clone().requires_grad_(True)
+    out = run(v, t["loc_c"], t["loc_t"])
+    (gv,) = torch.autograd.grad(out, v, t["grad_out"])
+    lhs = (out.double() * t["grad_out"].double()).sum().item()
+    rhs = (v.double() * gv.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
