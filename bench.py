@@ -221,31 +221,33 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import msda_oracle as O
-        cores = os.cpu_count() or 1
+        # grid_sample's backward degrades badly when oversubscribed (256 threads: >300 s per clip);
+        # 16 threads is near its best on this host -- `cores` reports what was actually used
+        cores = min(os.cpu_count() or 1, 16)
         torch.set_num_threads(cores)
         cb = {k: (v[:T].detach().float().cpu() if k in ("value", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out") else v.cpu())
               for k, v in b.items() if k != "dims"}
         c_shapes_t = cb["shapes"].repeat(W, 1)
 
-        def cpu_clip():
+        def cpu_frame(t):
+            """one frame of the reference's loop (ms_deform_attn.py:325-364): current + temporal call,
+            forward and backward through autograd"""
             lv = [cb[k].clone().requires_grad_(True) for k in ("value", "loc_c", "aw_c", "loc_t", "aw_t")]
-            outs = []
-            for t in range(T):
-                o1 = O.grid_sample_forward(lv[0][t][None], cb["shapes"], lv[1][t][None], lv[2][t][None])
-                stacked = lv[0][cb["ftab"][t].long()].flatten(0, 1)[None]
-                o2 = O.grid_sample_forward(stacked, c_shapes_t, lv[3][t][None], lv[4][t][None])
-                outs.append(o1 + o2)
-            torch.autograd.grad(torch.cat(outs, 0), lv, cb["grad_out"])
+            o1 = O.grid_sample_forward(lv[0][t][None], cb["shapes"], lv[1][t][None], lv[2][t][None])
+            stacked = lv[0][cb["ftab"][t].long()].flatten(0, 1)[None]
+            o2 = O.grid_sample_forward(stacked, c_shapes_t, lv[3][t][None], lv[4][t][None])
+            torch.autograd.grad(o1 + o2, lv, cb["grad_out"][t][None])
 
-        cpu_clip()
+        cpu_frame(0)                                   # warm-up
         n, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < args.cpu_seconds:
-            cpu_clip()
+            cpu_frame(n % T)
             n += 1
         dt = time.perf_counter() - t0
-        cpu = {"value": round(n * T * q / dt / 1e6, 5), "unit": "M-queries/s", "cores": cores, "kind": "port",
-               "sample": "%d clip-layer fwd+bwd passes (T=%d, %d queries/frame, pyramid %s, fp32) of oracle."
-                         "grid_sample_forward in the reference's 2*T-call pattern, %.1f s" % (n, T, q, args.pyramid, dt)}
+        cpu = {"value": round(n * q / dt / 1e6, 6), "unit": "M-queries/s", "cores": cores, "kind": "port",
+               "sample": "%d frame passes (each: current + temporal call, fwd+bwd, %d queries, pyramid %s, fp32) of "
+                         "oracle.grid_sample_forward in the reference's call pattern, %.1f s, %d torch threads"
+                         % (n, q, args.pyramid, dt, cores)}
 
     if rank == 0:
         line = {

@@ -136,6 +136,7 @@ struct Params {
     const void *grad_out;       // bwd
     void *grad_value;           // bwd: acc type, pre-zeroed
     void *glocA, *gawA, *glocB, *gawB;
+    unsigned *workspace;        // bwd: [0] = bits of max|grad_out|, [1] = bits of max|attn| (zeroed by caller)
     int groups, frames, window;
     int S, M, D, L, Lq;
     int LA, PA, LB, PB;
@@ -178,8 +179,11 @@ __device__ __forceinline__ Taps make_taps(float x, float y, const Level lv, int 
     t.w[0] = t.w[1] = t.w[2] = t.w[3] = 0.f;
     t.lh = t.lw = 0.f;
     t.valid = 0;
-    const float h_im = y * (float)lv.H - 0.5f;
-    const float w_im = x * (float)lv.W - 0.5f;
+    // rounded multiply THEN subtract (no FMA contraction): the reference evaluates
+    // `loc * spatial - 0.5` with a float product (cuh:285-286), and which pixel cell a point falls
+    // in must not depend on the compiler's contraction choices.
+    const float h_im = __fsub_rn(__fmul_rn(y, (float)lv.H), 0.5f);
+    const float w_im = __fsub_rn(__fmul_rn(x, (float)lv.W), 0.5f);
     if (h_im > -1.f && w_im > -1.f && h_im < (float)lv.H && w_im < (float)lv.W) {
         const float hf = floorf(h_im), wf = floorf(w_im);
         const int h_low = (int)hf, w_low = (int)wf;
@@ -326,6 +330,20 @@ msda_fwd_tile_kernel(const Params p)
     }
 }
 
+// running abs-max that treats NaN/Inf as +huge (so a non-finite input is never hidden)
+__device__ __forceinline__ float absmax_key(float cur, float v)
+{
+    const float a = fabsf(v);
+    return (a <= 3.0e38f) ? fmaxf(cur, a) : 3.4e38f;
+}
+
+__device__ __forceinline__ float wave_absmax(float v)
+{
+#pragma unroll
+    for (int s = 1; s < kWave; s <<= 1) v = fmaxf(v, __shfl_xor(v, s, kWave));
+    return v;
+}
+
 // sum over the G lanes of a row (G is a power of two <= 64): xor butterfly, DPP / ds_swizzle
 template <int G>
 __device__ __forceinline__ float row_sum(float v)
@@ -335,7 +353,11 @@ __device__ __forceinline__ float row_sum(float v)
     return v;
 }
 
-template <typename T, int G>
+// ATOMICS = true : also scatters grad_value with global float atomics (one-kernel backward; used when
+//                  the LDS scatter kernel below cannot take the shape).
+// ATOMICS = false: computes grad_sampling_loc / grad_attn_weight only; grad_value comes from
+//                  msda_bwd_value_lds_kernel.
+template <typename T, int G, bool ATOMICS>
 __global__ void __launch_bounds__(kWave)
 msda_bwd_tile_kernel(const Params p)
 {
@@ -368,6 +390,13 @@ msda_bwd_tile_kernel(const Params p)
 #pragma unroll
     for (int c = 0; c < VEC; ++c) g[c] = 0.f;
     if (r < rows_valid) Store<T>::load(static_cast<const T *>(p.grad_out) + row * p.D + sub * VEC, g);
+    // abs-max of grad_out and of the attention weights seen by this wave: the LDS scatter kernel
+    // derives its fixed-point scale from them (NaN/Inf map to a huge key, which selects its float path)
+    float amax_g = 0.f, amax_a = 0.f;
+    if (!ATOMICS) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) amax_g = absmax_key(amax_g, g[c]);
+    }
 
 #pragma unroll 1
     for (int arr = 0; arr < 2; ++arr) {
@@ -383,6 +412,10 @@ msda_bwd_tile_kernel(const Params p)
             stage_chunk<T, RPW, true>(p, loc, aw, LP, P, vl_base, p0, row0, rows_valid, s_lvl,
                                       s_off, s_w, s_e, lane);
             __syncthreads();
+            if (!ATOMICS) {     // every staged weight is seen by lanes sub == pp % G below; cheaper here:
+                for (int i = lane; i < RPW * kPch; i += kWave)
+                    amax_a = absmax_key(amax_a, s_e[(i / kPch) * kRowSlots + (i % kPch)].x);
+            }
             const int np = min(kPch, LP - p0);
             const int4 *ro = s_off + r * kRowSlots;
             const float4 *rw = s_w + r * kRowSlots;
@@ -415,21 +448,23 @@ msda_bwd_tile_kernel(const Params p)
                 // grad_value[corner k] += w_k * a * grad_out   (cuh:125,134,143,152)
                 const float a = e.x;
                 const float wa0 = w.x * a, wa1 = w.y * a, wa2 = w.z * a, wa3 = w.w * a;
-                if (bits & 1) {
+                if (ATOMICS) {
+                    if (bits & 1) {
 #pragma unroll
-                    for (int c = 0; c < VEC; ++c) atomic_accumulate(gvalue + o.x + c, wa0 * g[c]);
-                }
-                if (bits & 2) {
+                        for (int c = 0; c < VEC; ++c) atomic_accumulate(gvalue + o.x + c, wa0 * g[c]);
+                    }
+                    if (bits & 2) {
 #pragma unroll
-                    for (int c = 0; c < VEC; ++c) atomic_accumulate(gvalue + o.y + c, wa1 * g[c]);
-                }
-                if (bits & 4) {
+                        for (int c = 0; c < VEC; ++c) atomic_accumulate(gvalue + o.y + c, wa1 * g[c]);
+                    }
+                    if (bits & 4) {
 #pragma unroll
-                    for (int c = 0; c < VEC; ++c) atomic_accumulate(gvalue + o.z + c, wa2 * g[c]);
-                }
-                if (bits & 8) {
+                        for (int c = 0; c < VEC; ++c) atomic_accumulate(gvalue + o.z + c, wa2 * g[c]);
+                    }
+                    if (bits & 8) {
 #pragma unroll
-                    for (int c = 0; c < VEC; ++c) atomic_accumulate(gvalue + o.w + c, wa3 * g[c]);
+                        for (int c = 0; c < VEC; ++c) atomic_accumulate(gvalue + o.w + c, wa3 * g[c]);
+                    }
                 }
                 d0 = row_sum<G>(d0);
                 d1 = row_sum<G>(d1);
@@ -450,6 +485,227 @@ msda_bwd_tile_kernel(const Params p)
             }
             __syncthreads();
         }
+    }
+    if (!ATOMICS) {
+        amax_g = wave_absmax(amax_g);
+        amax_a = wave_absmax(amax_a);
+        if (lane == 0) {
+            // non-negative floats order like their bit patterns; skip the atomic when not a new maximum
+            const unsigned kg = __float_as_uint(amax_g), ka = __float_as_uint(amax_a);
+            if (kg > __hip_atomic_load(p.workspace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.workspace, kg);
+            if (ka > __hip_atomic_load(p.workspace + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.workspace + 1, ka);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// grad_value by LDS-privatised scatter in 64-bit fixed point
+// ------------------------------------------------------------------------------------------------
+// Measured on MI355X (scripts/ubench/lds_atomics.hip): global fp32 atomics ~80 G lane-op/s (34 ms for
+// 16 clips of the DeVIS decoder layer); LDS *float* atomics (ds_add_f32, ds_add_rtn_f32,
+// ds_pk_add_f16) 193 clk per wave instruction; LDS *integer* atomics ds_add_u32 / ds_add_u64 6.2 /
+// 7.5 clk per wave instruction.  So grad_value is accumulated with ds_add_u64 in fixed point:
+//
+//   work item = (clip, source frame f, head m, band); a band is a run of pixel ROWS of one level map
+//   whose [rows, W, D] accumulator (8 bytes per channel) fits the workgroup's LDS budget.
+//   The workgroup zeroes the band, scans every sampling point that reads (f, m, level) -- the
+//   current-frame points of frame f and the temporal points of every (t, w) with
+//   frame_table[t, w] == f --, and adds each bilinear corner that falls on a row it OWNS:
+//       term  = fp32 product  w_corner * attn * grad_out[c]          (exactly the reference's
+//               atomicAdd operand, cuh:125-152)
+//       LDS  += llrint(term * 2^k)                                   (ds_add_u64, exact integer sum)
+//   then streams the band to grad_value as float(sum * 2^-k) with plain coalesced 16-byte stores.
+//   2^k is chosen so that the largest possible |term| (max|attn| * max|grad_out|, produced on the
+//   device by the gather pass -- no host sync) times the largest possible number of terms per
+//   accumulator stays below 2^62; the quantum is <= 2^-37 of the largest term.  The sum is therefore
+//   exact up to that quantum, independent of summation order (bit-reproducible, which the
+//   reference's float atomicAdd is not), and rounded to fp32 once.
+//   Every (pixel, head) of grad_value belongs to exactly one band, so the kernel OVERWRITES
+//   grad_value; a point whose two rows straddle two bands is visited by both owners, each adding only
+//   its own row.  Non-finite inputs (max key = huge) and levels whose single row does not fit the
+//   budget take the float global-atomic branch of the same loop ("direct"), so any input is handled.
+//
+//   lane mapping: stage 1 -- one lane per candidate point (tap arithmetic once per point, band test,
+//   __ballot); stage 2 -- the hits are dealt to teams of G lanes (one team per point, RPW points per
+//   wave pass) which fetch the tap record from the finder lane by ds_bpermute.  Lane i of team k adds
+//   channel ((c + k) % VEC) * G + i at step c, so the teams of one half-wave hit disjoint LDS banks.
+//
+//   The grid is persistent (one 1024-thread workgroup per CU striding over the items) because the
+//   number of bands depends on spatial_shapes, which lives in device memory (no host sync allowed);
+//   item % M = head keeps the head -> XCD affinity of the gather kernels.
+constexpr int kScatterThreads = 1024;
+constexpr int kScatterMaxLevels = 32;
+typedef unsigned long long u64;
+
+template <typename T, int G>
+__global__ void __launch_bounds__(kScatterThreads)
+msda_bwd_value_lds_kernel(const Params p, int cap_slots, int headroom_bits, int dbg)
+{
+    constexpr int VEC = Store<T>::VEC;
+    constexpr int RPW = kWave / G;
+    constexpr int kWaves = kScatterThreads / kWave;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    u64 *band = reinterpret_cast<u64 *>(lds_raw);
+    __shared__ int s_H[kScatterMaxLevels], s_W[kScatterMaxLevels], s_R[kScatterMaxLevels],
+        s_first[kScatterMaxLevels + 1], s_lsi[kScatterMaxLevels];
+
+    const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+    const int D = p.D, MD = p.M * p.D;
+    const int L = p.L;      // levels of ONE source map (temporal virtual levels share them)
+    if (tid == 0) {
+        int first = 0;
+        for (int l = 0; l < L; ++l) {
+            const int H = (int)p.shapes[2 * l], W = (int)p.shapes[2 * l + 1];
+            const int R = min(H, cap_slots / max(1, W * D));     // rows per band; 0 = "direct" level
+            s_H[l] = H; s_W[l] = W; s_R[l] = R; s_lsi[l] = (int)p.lsi[l];
+            s_first[l] = first;
+            first += (R > 0) ? (H + R - 1) / R : 1;
+        }
+        s_first[L] = first;
+    }
+    __syncthreads();
+    const int NB = s_first[L];
+    const int clips = p.groups / p.frames;
+    const int64_t n_items = (int64_t)clips * p.frames * p.M * NB;
+    const int team = lane / G, sub = lane % G;
+
+    // fixed-point scale 2^k from the device-side abs-max keys (see header comment)
+    const float vmax = __uint_as_float(p.workspace[0]) * __uint_as_float(p.workspace[1]);
+    const bool finite = vmax <= 3.0e38f;           // false for NaN too
+    int e = 0;
+    (void)frexpf(fmaxf(vmax, 1e-30f), &e);          // vmax < 2^e
+    const int k = 62 - headroom_bits - e;
+    const double scale = ldexp(1.0, k), inv_scale = ldexp(1.0, -k);
+
+    for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int m = (int)(item % p.M);
+        int64_t rest = item / p.M;
+        const int part = (int)(rest % NB); rest /= NB;
+        const int f = (int)(rest % p.frames);
+        const int clip = (int)(rest / p.frames);
+        int l = 0;
+        while (l + 1 < L && s_first[l + 1] <= part) ++l;
+        const int H = s_H[l], W = s_W[l], R = s_R[l];
+        const bool whole_level = (R == 0);
+        const bool direct = whole_level || !finite;
+        const int r0 = whole_level ? 0 : (part - s_first[l]) * R;
+        const int r1 = whole_level ? H - 1 : min(H, r0 + R) - 1;
+        const int band_slots = direct ? 0 : (r1 - r0 + 1) * W * D;
+        for (int i = tid * 2; i < band_slots; i += kScatterThreads * 2)
+            *reinterpret_cast<uint4 *>(band + i) = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+
+        // pixel (0, 0) of the level inside grad_value, for head m
+        float *gmap = static_cast<float *>(p.grad_value) +
+                      (((int64_t)clip * p.frames + f) * p.S + s_lsi[l]) * MD + m * D;
+
+        const int n_src = (dbg & 4) ? 0 : 1 + p.frames * p.window;
+        for (int src = 0; src < n_src; ++src) {
+            int t = f, vl = l, P = p.PA, LP = p.LA * p.PA;
+            const T *loc = static_cast<const T *>(p.locA);
+            const T *aw = static_cast<const T *>(p.awA);
+            if (src > 0) {
+                t = (src - 1) / p.window;
+                const int w = (src - 1) - t * p.window;
+                if (p.ftab[t * p.window + w] != f) continue;
+                vl = w * L + l; P = p.PB; LP = p.LB * p.PB;
+                loc = static_cast<const T *>(p.locB);
+                aw = static_cast<const T *>(p.awB);
+            }
+            const int64_t group = (int64_t)clip * p.frames + t;
+            const int npts = p.Lq * P;
+            for (int base = wave * kWave; base < npts; base += kWaves * kWave) {
+                const int i = base + lane;
+                // ---- stage 1: one lane per candidate point
+                int pix00 = 0, bits = 0, qrow = 0;
+                float wa0 = 0.f, wa1 = 0.f, wa2 = 0.f, wa3 = 0.f;
+                if (i < npts) {
+                    const int q = i / P, pt = i - q * P;
+                    const int64_t row = (group * p.Lq + q) * p.M + m;
+                    const int64_t idx = row * LP + vl * P + pt;
+                    const float x = Store<T>::get(loc + 2 * idx);
+                    const float y = Store<T>::get(loc + 2 * idx + 1);
+                    const float h_im = __fsub_rn(__fmul_rn(y, (float)H), 0.5f);
+                    const float w_im = __fsub_rn(__fmul_rn(x, (float)W), 0.5f);
+                    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                        const float hf = floorf(h_im), wf = floorf(w_im);
+                        const int h_low = (int)hf, w_low = (int)wf;
+                        // rows this band owns among the point's two rows
+                        const bool top = h_low >= max(r0, 0) && h_low <= r1;
+                        const bool bot = h_low + 1 >= r0 && h_low + 1 <= min(r1, H - 1);
+                        const bool x0 = w_low >= 0, x1 = w_low + 1 <= W - 1;
+                        bits = (top && x0 ? 1 : 0) | (top && x1 ? 2 : 0) | (bot && x0 ? 4 : 0) | (bot && x1 ? 8 : 0);
+                        if (bits) {
+                            const float a = Store<T>::get(aw + idx);
+                            const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+                            wa0 = hh * hw * a; wa1 = hh * lw * a; wa2 = lh * hw * a; wa3 = lh * lw * a;
+                            pix00 = (h_low - r0) * W + w_low;       // may be "virtual" for unowned corners
+                            qrow = (int)(group * p.Lq + q);
+                        }
+                    }
+                }
+                u64 mask = __ballot(bits != 0);
+                if (dbg & 2) mask = 0;
+                // ---- stage 2: RPW hits per pass, one team of G lanes per hit
+                while (mask) {
+                    u64 mm = mask;
+#pragma unroll
+                    for (int j = 0; j < RPW - 1; ++j)
+                        if (j < team) mm &= mm - 1;
+                    const bool has = mm != 0;
+                    const int from = has ? __builtin_ctzll(mm) : 0;
+                    const int h_pix = __shfl(pix00, from, kWave);
+                    const int b_all = __shfl(bits, from, kWave);
+                    const int h_bits = has ? b_all : 0;
+                    const int h_q = __shfl(qrow, from, kWave);
+                    const float h_w0 = __shfl(wa0, from, kWave), h_w1 = __shfl(wa1, from, kWave);
+                    const float h_w2 = __shfl(wa2, from, kWave), h_w3 = __shfl(wa3, from, kWave);
+                    if (h_bits) {
+                        const T *go = static_cast<const T *>(p.grad_out) + (int64_t)h_q * MD + m * D;
+                        float gc[VEC];
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c)       // all channel loads in flight before the adds
+                            gc[c] = Store<T>::get(go + ((c + team) % VEC) * G + sub);
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c) {
+                            const int ch = ((c + team) % VEC) * G + sub;
+                            if (direct) {
+                                float *dst = gmap + (int64_t)h_pix * MD + ch;
+                                if (h_bits & 1) atomic_accumulate(dst, h_w0 * gc[c]);
+                                if (h_bits & 2) atomic_accumulate(dst + MD, h_w1 * gc[c]);
+                                if (h_bits & 4) atomic_accumulate(dst + (int64_t)W * MD, h_w2 * gc[c]);
+                                if (h_bits & 8) atomic_accumulate(dst + (int64_t)(W + 1) * MD, h_w3 * gc[c]);
+                            } else if (!(dbg & 1)) {
+                                u64 *dst = band + h_pix * D + ch;
+                                // fp32 product (the reference's atomicAdd operand) -> exact fixed point
+                                if (h_bits & 1) atomicAdd(dst, (u64)__double2ll_rn((double)(h_w0 * gc[c]) * scale));
+                                if (h_bits & 2) atomicAdd(dst + D, (u64)__double2ll_rn((double)(h_w1 * gc[c]) * scale));
+                                if (h_bits & 4) atomicAdd(dst + W * D, (u64)__double2ll_rn((double)(h_w2 * gc[c]) * scale));
+                                if (h_bits & 8) atomicAdd(dst + (W + 1) * D, (u64)__double2ll_rn((double)(h_w3 * gc[c]) * scale));
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < RPW; ++j) mask &= mask - 1;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- flush the band: fixed point -> fp32, plain coalesced stores (D floats per pixel at stride M*D)
+        const int vec_per_pix = D / 4;
+        const int n_vec = band_slots / 4;
+        float *gband = gmap + (int64_t)r0 * W * MD;
+        for (int i = tid; i < n_vec; i += kScatterThreads) {
+            const int pix = i / vec_per_pix, c4 = i - pix * vec_per_pix;
+            const long long *src = reinterpret_cast<const long long *>(band) + i * 4;
+            float4 v;
+            v.x = (float)((double)src[0] * inv_scale);
+            v.y = (float)((double)src[1] * inv_scale);
+            v.z = (float)((double)src[2] * inv_scale);
+            v.w = (float)((double)src[3] * inv_scale);
+            *reinterpret_cast<float4 *>(gband + (int64_t)pix * MD + c4 * 4) = v;
+        }
+        __syncthreads();
     }
 }
 
@@ -606,6 +862,36 @@ size_t tile_lds_bytes(int rpw, int nvl, bool bwd)
     return (size_t)rpw * kRowSlots * 16 * (bwd ? 3 : 2) + (size_t)nvl * sizeof(Level);
 }
 
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return (e && e[0]) ? atoi(e) : dflt;
+}
+
+int device_cus()
+{
+    static int cus = 0;     // benign race: every thread computes the same value
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
+// Can grad_value go through the LDS scatter kernel?  MSDA_BWD_MODE=atomic forces the one-kernel
+// backward with global atomics (kept for A/B measurements and as the any-shape path).
+bool scatter_applicable(const Params &p)
+{
+    const char *mode = getenv("MSDA_BWD_MODE");
+    if (mode && !strcmp(mode, "atomic")) return false;
+    if (p.L > kScatterMaxLevels || (p.D % 4) != 0 || !p.workspace) return false;
+    if (p.window == 0 && p.LA != p.L) return false;
+    return true;
+}
+
 template <typename T, int G>
 int launch_tile(const Params &p, bool bwd, hipStream_t stream)
 {
@@ -614,11 +900,36 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     const int64_t blocks = tiles * p.M;
     if (blocks > 0x7fffffffLL) return fail(MSDA_ERR_ARG, "msda: problem too large for one launch%s");
     const size_t lds = tile_lds_bytes(RPW, p.LA + p.LB, bwd);
-    if (bwd)
-        hipLaunchKernelGGL((msda_bwd_tile_kernel<T, G>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
-    else
+    if (!bwd) {
         hipLaunchKernelGGL((msda_fwd_tile_kernel<T, G>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
-    return check_launch(bwd ? "msda backward (tile kernel)" : "msda forward (tile kernel)");
+        return check_launch("msda forward (tile kernel)");
+    }
+    if (!scatter_applicable(p)) {
+        hipLaunchKernelGGL((msda_bwd_tile_kernel<T, G, true>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
+        return check_launch("msda backward (tile kernel, global atomics)");
+    }
+    hipLaunchKernelGGL((msda_bwd_tile_kernel<T, G, false>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
+    int rc = check_launch("msda backward (tile kernel, grad_loc/grad_attn)");
+    if (rc) return rc;
+    // LDS budget: one 1024-thread workgroup per CU with 144 KiB of 8-byte accumulators
+    const int cap_bytes = env_int("MSDA_SCATTER_LDS_KB", 144) * 1024;
+    const int per_cu = env_int("MSDA_SCATTER_WG_PER_CU", 1);
+    unsigned grid = (unsigned)(device_cus() * per_cu);
+    grid -= grid % 8;                                   // multiple of the XCD count: item % M stays put
+    // headroom: an accumulator can receive at most one term per sampling point that reads its map
+    const int64_t max_terms = (int64_t)(1 + (int64_t)p.frames * p.window) * p.Lq * (p.PA > p.PB ? p.PA : p.PB);
+    int headroom_bits = 1;
+    while (((int64_t)1 << headroom_bits) < max_terms && headroom_bits < 40) ++headroom_bits;
+    static int lds_limit_set = 0;      // per instantiation; dynamic LDS above 64 KiB must be opted into
+    if (cap_bytes > lds_limit_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_value_lds_kernel<T, G>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, cap_bytes) != hipSuccess)
+            return fail(MSDA_ERR_HIP, "msda backward: cannot reserve the requested LDS budget%s");
+        lds_limit_set = cap_bytes;
+    }
+    hipLaunchKernelGGL((msda_bwd_value_lds_kernel<T, G>), dim3(grid), dim3(kScatterThreads),
+                       (size_t)cap_bytes, stream, p, cap_bytes / 8, headroom_bits, env_int("MSDA_SCATTER_DBG", 0));
+    return check_launch("msda backward (LDS scatter kernel)");
 }
 
 template <typename T>
@@ -740,7 +1051,8 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
                   const void *attn_weight, const void *grad_out,
                   int batch, int spatial_size, int num_heads, int channels, int num_levels,
                   int num_query, int num_point,
-                  void *grad_value, void *grad_sampling_loc, void *grad_attn_weight, void *stream)
+                  void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
+                  void *workspace, void *stream)
 {
     g_err[0] = 0;
     int rc = check_common(value, spatial_shapes, level_start_index, batch, spatial_size, num_heads,
@@ -755,6 +1067,7 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
     p.value = value; p.shapes = spatial_shapes; p.lsi = level_start_index;
     p.locA = sampling_loc; p.awA = attn_weight; p.grad_out = grad_out;
     p.grad_value = grad_value; p.glocA = grad_sampling_loc; p.gawA = grad_attn_weight;
+    p.workspace = static_cast<unsigned *>(workspace);
     p.groups = batch; p.frames = 1; p.window = 0;
     p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
     p.LA = num_levels; p.PA = num_point; p.LB = 0; p.PB = 1;
@@ -797,7 +1110,7 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
                            int channels, int num_levels, int num_query,
                            int num_curr_point, int num_temp_point,
                            void *grad_value, void *grad_loc_curr, void *grad_aw_curr,
-                           void *grad_loc_temp, void *grad_aw_temp, void *stream)
+                           void *grad_loc_temp, void *grad_aw_temp, void *workspace, void *stream)
 {
     g_err[0] = 0;
     int rc = check_common(value, spatial_shapes, level_start_index, clips, spatial_size, num_heads,
@@ -815,6 +1128,7 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
     p.locA = loc_curr; p.awA = aw_curr; p.locB = loc_temp; p.awB = aw_temp; p.grad_out = grad_out;
     p.grad_value = grad_value; p.glocA = grad_loc_curr; p.gawA = grad_aw_curr;
     p.glocB = grad_loc_temp; p.gawB = grad_aw_temp;
+    p.workspace = static_cast<unsigned *>(workspace);
     p.groups = clips * frames; p.frames = frames; p.window = window;
     p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
     p.LA = num_levels; p.PA = num_curr_point;

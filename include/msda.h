@@ -22,7 +22,8 @@
  *     grad_sampling_loc / grad_attn_weight.  Arithmetic is fp32 for f32/bf16/f16 and fp64 for f64.
  *     `grad_value` is ALWAYS an accumulation buffer in the arithmetic type (float for f32/bf16/f16,
  *     double for f64), must be zero-filled by the caller (the reference does at::zeros_like,
- *     ms_deform_attn_cuda.cu:121) and is accumulated into with hardware float atomics.
+ *     ms_deform_attn_cuda.cu:121); kernels either accumulate into it with hardware float atomics or
+ *     overwrite whole level-row bands they own exclusively.
  *
  * Symbols:  N batch, S = sum_l H_l*W_l, M heads, D channels per head, Lq queries, L levels,
  *           P points;  spatial_shapes[l] = (H_l, W_l);  sampling_loc[..., 0] = x (width), 1 = y.
@@ -36,7 +37,8 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 1
+#define MSDA_ABI_VERSION 2
+#define MSDA_BWD_WORKSPACE_BYTES 64   /* device scratch the backward entry points need */
 
 enum msda_dtype { MSDA_F32 = 0, MSDA_F64 = 1, MSDA_BF16 = 2, MSDA_F16 = 3 };
 
@@ -83,13 +85,18 @@ int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,
  *   grad_value        [N, S, M, D]         float (double for MSDA_F64); caller zero-fills; accumulated
  *   grad_sampling_loc [N, Lq, M, L, P, 2]  dtype, fully overwritten (skipped points get 0)
  *   grad_attn_weight  [N, Lq, M, L, P]     dtype, fully overwritten
+ *   workspace         MSDA_BWD_WORKSPACE_BYTES of device scratch, zero-filled by the caller, private to
+ *                     this call until it completes (the gather pass leaves max|grad_out| and
+ *                     max|attn_weight| there; the scatter pass derives its fixed-point scale from them).
+ *                     NULL is allowed: grad_value then goes through global float atomics (slow).
  */
 int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
                   const int64_t *level_start_index, const void *sampling_loc,
                   const void *attn_weight, const void *grad_out,
                   int batch, int spatial_size, int num_heads, int channels, int num_levels,
                   int num_query, int num_point,
-                  void *grad_value, void *grad_sampling_loc, void *grad_attn_weight, void *stream);
+                  void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
+                  void *workspace, void *stream);
 
 /*
  * Fused temporal forward: for every frame t of every clip, current-frame attention on value[t] PLUS
@@ -124,6 +131,7 @@ int msda_temporal_forward(int dtype, const void *value, const int64_t *spatial_s
  * double, zero-filled by the caller): contributions of the current-frame and of every temporal slot
  * land in it directly, replacing the reference's index_put-add backward of value[temporal_frames].
  * The four grad_loc / grad_aw outputs have the shapes of their inputs and are fully overwritten.
+ * `workspace`: as for msda_backward.
  */
 int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_shapes,
                            const int64_t *level_start_index, const int32_t *frame_table,
@@ -133,7 +141,7 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
                            int channels, int num_levels, int num_query,
                            int num_curr_point, int num_temp_point,
                            void *grad_value, void *grad_loc_curr, void *grad_aw_curr,
-                           void *grad_loc_temp, void *grad_aw_temp, void *stream);
+                           void *grad_loc_temp, void *grad_aw_temp, void *workspace, void *stream);
 
 #ifdef __cplusplus
 }

@@ -157,12 +157,17 @@ def test_devis_decoder_call_shapes_fp32():
     """cfg3 per-frame calls at full size: current (L=4) and temporal (L=20, S_in=5S), 300 queries."""
     for L_rep, seed in ((1, 5), (5, 6)):
         d = make_inputs(seed, 1, 8, 32, 300, PYR_A * L_rep, 4, "wide", np.float32)
-        ref = oracle_fwd_bwd(d, np.float64)
+        ref64 = oracle_fwd_bwd(d, np.float64)
+        # grad_loc is discontinuous where a pixel coordinate crosses an integer, so a point within one
+        # fp32 ulp of a cell border may legitimately land in the other cell than in fp64 arithmetic:
+        # gradients are compared with the oracle evaluated in the SAME (fp32) arithmetic, whose
+        # x*W-0.5 rounding the kernel reproduces bit for bit; the output (continuous) also vs fp64.
+        ref32 = oracle_fwd_bwd(d, np.float32)
         got = _run_op(d, torch.float32)
-        assert _maxabs(got[0], ref[0]) <= 1e-6
-        assert _maxabs(got[1], ref[1]) <= 1e-4
-        assert _maxabs(got[2], ref[2]) <= 1e-4 * max(1.0, np.abs(ref[2]).max())
-        assert _maxabs(got[3], ref[3]) <= 1e-4
+        assert _maxabs(got[0], ref64[0]) <= 1e-6
+        assert _maxabs(got[1], ref32[1]) <= 1e-4
+        assert _maxabs(got[2], ref32[2]) <= 1e-4 * max(1.0, np.abs(ref32[2]).max())
+        assert _maxabs(got[3], ref32[3]) <= 1e-4
 
 
 # ---------------------------------------------------------------------------------------------
