@@ -92,18 +92,20 @@ def make_clip_batch(args, device, dtype, seed):
 
 
 def algorithmic_bytes(args, e):
-    """Per fused launch over ONE clip (DESIGN.md 'algorithmic bytes'): value read once,
-    (x, y, weight) per sampling point, one output row per query; backward adds grad_out, the
-    grad_loc/grad_aw writes and the read-modify-write of grad_value (fp32 accumulator)."""
+    """Per launch over ONE clip (DESIGN.md 'algorithmic bytes'): every tensor a kernel
+    must touch counted once -- value read once (not once per gathered corner), (x, y, weight) per
+    sampling point, one row per query.  The backward is two kernels: the gather pass reads value,
+    grad_out, loc/attn and writes grad_loc/grad_attn; the scatter pass reads loc/attn and grad_out and
+    writes grad_value once (fp32; accumulation happens in LDS, so there is no read-modify-write traffic)."""
     T, q, M, D, P = args.frames, args.queries, 8, 32, 4
     shapes = PYRAMIDS[args.pyramid]
     L, W = len(shapes), T - 1
     S = sum(h * w for h, w in shapes)
     C = M * D
     points = T * q * M * (L * P + W * L * P)
-    fwd = T * S * C * e + points * 3 * e + T * q * C * e
-    bwd = T * S * C * e + T * q * C * e + points * 3 * e + points * 3 * e + 2 * T * S * C * 4
-    return fwd, bwd
+    return {"fwd": T * S * C * e + points * 3 * e + T * q * C * e,
+            "bwd_gather": T * S * C * e + T * q * C * e + points * 3 * e + points * 3 * e,
+            "bwd_scatter": points * 3 * e + T * q * C * e + T * S * C * 4}
 
 
 def main():
@@ -197,25 +199,34 @@ def main():
 
         fwd_ms, fwd_med = time_kernel(lambda: _native.temporal_forward(
             dv[0], b["shapes"], b["lsi"], b["ftab"], dv[1], dv[2], dv[3], dv[4], args.clips, out), 20)
-        bwd_ms, bwd_med = time_kernel(lambda: _native.temporal_backward(
+        # the backward entry point launches two kernels; MSDA_BWD_PHASES lets each be timed alone
+        ws = _native.bwd_workspace(device)
+        bwd = lambda: _native.temporal_backward(
             dv[0], b["shapes"], b["lsi"], b["ftab"], dv[1], dv[2], dv[3], dv[4], b["grad_out"], args.clips,
-            gv, gl_c, ga_c, gl_t, ga_t), 20)
+            gv, gl_c, ga_c, gl_t, ga_t, workspace=ws)
+        os.environ["MSDA_BWD_PHASES"] = "1"
+        gat_ms, gat_med = time_kernel(bwd, 20)
+        os.environ["MSDA_BWD_PHASES"] = "2"
+        sca_ms, sca_med = time_kernel(bwd, 20)
+        os.environ.pop("MSDA_BWD_PHASES")
         e = b["value"].element_size()
-        fwd_b, bwd_b = algorithmic_bytes(args, e)
-        fwd_gbs = fwd_b * args.clips / (fwd_ms * 1e-3) / 1e9
-        bwd_gbs = bwd_b * args.clips / (bwd_ms * 1e-3) / 1e9
-        dom = "backward" if bwd_ms >= fwd_ms else "forward"
-        ach = bwd_gbs if dom == "backward" else fwd_gbs
-        roofline = {"bound": "hbm", "kernel": "msda_%s_tile_kernel (fused temporal %s)" % ("bwd" if dom == "backward" else "fwd", dom),
-                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        ab = algorithmic_bytes(args, e)
+        kernels = {
+            "msda_fwd_tile_kernel": (fwd_ms, fwd_med, ab["fwd"]),
+            "msda_bwd_tile_kernel (grad_loc/grad_attn gather pass)": (gat_ms, gat_med, ab["bwd_gather"]),
+            "msda_bwd_value_lds_kernel (grad_value scatter)": (sca_ms, sca_med, ab["bwd_scatter"]),
+        }
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        d_ms, _, d_bytes = kernels[dom]
+        ach = d_bytes * args.clips / (d_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                    "algorithmic_bytes_per_launch": (bwd_b if dom == "backward" else fwd_b) * args.clips,
-                    "avg_launch_ms": round(bwd_ms if dom == "backward" else fwd_ms, 4)}
-        extra = {"forward_kernel": {"avg_ms": round(fwd_ms, 4), "median_ms": round(fwd_med, 4),
-                                    "algorithmic_GBps": round(fwd_gbs, 1), "frac_of_hbm_peak": round(fwd_gbs / HBM_PEAK_GBS, 4),
-                                    "M_queries_per_s": round(args.clips * T * q / (fwd_ms * 1e-3) / 1e6, 2)},
-                 "backward_kernel": {"avg_ms": round(bwd_ms, 4), "median_ms": round(bwd_med, 4),
-                                     "algorithmic_GBps": round(bwd_gbs, 1), "frac_of_hbm_peak": round(bwd_gbs / HBM_PEAK_GBS, 4)}}
+                    "algorithmic_bytes_per_launch": d_bytes * args.clips, "avg_launch_ms": round(d_ms, 4)}
+        extra = {"kernels": {k: {"avg_ms": round(v[0], 4), "median_ms": round(v[1], 4),
+                                 "algorithmic_GBps": round(v[2] * args.clips / (v[0] * 1e-3) / 1e9, 1),
+                                 "frac_of_hbm_peak": round(v[2] * args.clips / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                             for k, v in kernels.items()},
+                 "forward_M_queries_per_s": round(args.clips * T * q / (fwd_ms * 1e-3) / 1e6, 2)}
 
     # ---- CPU baseline: the reference's pure-PyTorch path on the host cores (bounded sample) -----
     cpu = None

@@ -128,14 +128,14 @@ def temporal_forward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, clips, 
 
 
 def temporal_backward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, grad_out, clips,
-                      grad_value, gloc_c, gaw_c, gloc_t, gaw_t):
+                      grad_value, gloc_c, gaw_c, gloc_t, gaw_t, workspace=None):
     G, S, M, D = value.shape
     frames = G // clips
     _, Lq, _, L, Pc, _ = loc_c.shape
     window = ftab.shape[1] if ftab is not None else 0
     Pt = loc_t.shape[4] if window else 1
     with torch.cuda.device(value.device):
-        ws = bwd_workspace(value.device)
+        ws = workspace if workspace is not None else bwd_workspace(value.device)
         rc = load().msda_temporal_backward(
             dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(ftab), _p(loc_c), _p(aw_c),
             _p(loc_t), _p(aw_t), _p(grad_out), clips, frames, window, S, M, D, L, Lq, Pc, Pt,

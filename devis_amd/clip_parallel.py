@@ -1,0 +1,87 @@
+"""Multi-GPU forms of the temporal attention (one process per GPU, torch.distributed; backend "nccl"
+is RCCL over xGMI on ROCm).
+
+Mode 1 -- clip-parallel replicas: independent clips per GPU, no collective inside the operator.  This is
+what the reference does (DDP, 1 clip per GPU: main.py:131,142) and what bench.py --gpus N measures;
+nothing in this file is needed for it.
+
+Mode 2 -- one clip sharded over the ranks (BASELINE.json configs[3]).  Every output row (frame, query)
+depends on its own sampling locations / weights and on the read-only value maps of ALL frames of the
+clip, so:
+  * the flattened pixel axis (T*S rows of `value`) is cut into `world` contiguous chunks: each rank runs
+    value_proj on its chunk only, then ONE all-gather rebuilds value [T, S, M, D] on every rank
+    (shard = T*S*C*e/world bytes: 3.7 MB fp32 for T=6 on the 360x640 pyramid at 8 ranks);
+  * the queries of every frame are cut into `world` ranges: each rank runs the fused kernel on its own
+    rows; outputs stay sharded (output_proj is row-local);
+  * backward: each rank's kernel produces a partial grad_value for the whole clip; ONE reduce-scatter
+    (sum) returns to every rank the gradient of its own chunk.
+T = 6 frames on 8 GPUs does not divide, which is why the cut is on pixels/queries, not on frames.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): the all-gather of such small shards is
+latency-bound (~tens of us), comparable to the kernel itself, so Mode 2 only pays when one clip's
+per-layer work must be spread (large S, encoder attention) -- throughput scaling is Mode 1.
+"""
+import torch
+import torch.distributed as dist
+from torch.autograd import Function
+
+from .functions import MSDeformAttnTemporalFunction
+
+
+def shard_range(n, world, rank):
+    """Balanced contiguous range [start, stop) of n items for `rank` of `world` (sizes differ by <= 1)."""
+    base, extra = divmod(n, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def padded_chunk(n, world):
+    """Rows per rank when n rows are padded up to a multiple of world (all-gather needs equal shards)."""
+    return (n + world - 1) // world
+
+
+class _AllGatherRows(Function):
+    """forward: all-gather equal row-chunks [chunk, ...] -> [world*chunk, ...];
+    backward: reduce-scatter (sum) of the gradient back to the owners."""
+
+    @staticmethod
+    def forward(ctx, chunk, group):
+        ctx.group = group
+        world = dist.get_world_size(group)
+        chunk = chunk.contiguous()
+        out = chunk.new_empty((world * chunk.shape[0],) + tuple(chunk.shape[1:]))
+        dist.all_gather_into_tensor(out, chunk, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        group = ctx.group
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        grad = grad.contiguous()
+        rows = grad.shape[0] // world
+        if dist.get_backend(group) == "gloo":
+            # gloo (the CPU test backend) has no reduce-scatter: all-reduce and keep the own rows
+            dist.all_reduce(grad, group=group)
+            return grad[rank * rows:(rank + 1) * rows].clone(), None
+        mine = grad.new_empty((rows,) + tuple(grad.shape[1:]))
+        dist.reduce_scatter_tensor(mine, grad, op=dist.ReduceOp.SUM, group=group)
+        return mine, None
+
+
+def gather_value(value_chunk, n_frames, spatial_size, group=None):
+    """value_chunk: this rank's [chunk, M, D] rows of the flattened [T*S, M, D] value tensor (chunk =
+    padded_chunk(T*S, world); the last rank's tail rows beyond T*S are padding).  Returns the full
+    [T, S, M, D] tensor on every rank; differentiable (reduce-scatter in backward)."""
+    full = _AllGatherRows.apply(value_chunk, group)
+    return full[: n_frames * spatial_size].reshape((n_frames, spatial_size) + tuple(value_chunk.shape[1:]))
+
+
+def sharded_temporal_attention(value_chunk, n_frames, spatial_size, spatial_shapes, level_start_index,
+                               frame_table, loc_curr, aw_curr, loc_temp, aw_temp, group=None):
+    """Mode 2 for one clip.  value_chunk: this rank's rows of the flattened value (see gather_value);
+    loc_*/aw_* hold this rank's query range of every frame ([T, Lq_local, M, ...]).  Returns this rank's
+    output rows [T, Lq_local, M*D].  One all-gather forward, one reduce-scatter backward."""
+    value = gather_value(value_chunk, n_frames, spatial_size, group)
+    return MSDeformAttnTemporalFunction.apply(value.contiguous(), spatial_shapes, level_start_index,
+                                              frame_table, loc_curr.contiguous(), aw_curr.contiguous(),
+                                              loc_temp.contiguous(), aw_temp.contiguous(), 1)
+

@@ -908,9 +908,16 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
         hipLaunchKernelGGL((msda_bwd_tile_kernel<T, G, true>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
         return check_launch("msda backward (tile kernel, global atomics)");
     }
-    hipLaunchKernelGGL((msda_bwd_tile_kernel<T, G, false>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
-    int rc = check_launch("msda backward (tile kernel, grad_loc/grad_attn)");
-    if (rc) return rc;
+    // MSDA_BWD_PHASES (measurement hook for bench.py): 1 = gather pass only, 2 = scatter pass only
+    // (needs the workspace a previous gather pass filled), 3 = both (default)
+    const int phases = env_int("MSDA_BWD_PHASES", 3);
+    int rc = MSDA_OK;
+    if (phases & 1) {
+        hipLaunchKernelGGL((msda_bwd_tile_kernel<T, G, false>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
+        rc = check_launch("msda backward (tile kernel, grad_loc/grad_attn)");
+        if (rc) return rc;
+    }
+    if (!(phases & 2)) return rc;
     // LDS budget: one 1024-thread workgroup per CU with 144 KiB of 8-byte accumulators
     const int cap_bytes = env_int("MSDA_SCATTER_LDS_KB", 144) * 1024;
     const int per_cu = env_int("MSDA_SCATTER_WG_PER_CU", 1);

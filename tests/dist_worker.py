@@ -1,0 +1,83 @@
+"""Worker for the multi-process tests (spawned by test_dist_cpu.py / test_dist_gpu.py).
+
+Checks Mode 2 (one clip sharded over the ranks, devis_amd/clip_parallel.py): outputs of the ranks
+concatenated == the unsharded result, and after the reduce-scatter every rank holds exactly the
+gradient of its own value chunk.  On CPU (gloo) the kernels are replaced by the oracle-backed test
+double; on GPU (nccl = RCCL) the real HIP path runs."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+class _Patch:
+    def setattr(self, obj, name, val):
+        setattr(obj, name, val)
+
+
+def main():
+    backend = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        device = torch.device("cuda", torch.cuda.current_device())
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        device = torch.device("cpu")
+        dist.init_process_group("gloo")
+        import fake_native
+        fake_native.install(_Patch())
+    from helpers import make_temporal_inputs, temporal_reference
+    from devis_amd import clip_parallel as cp
+
+    T, W, M, D, Lq = 3, 2, 4, 8, 11
+    d = make_temporal_inputs(9, T, W, M, D, Lq, [(6, 5), (3, 3)], 3, 2, dtype=np.float64)
+    ref = temporal_reference(*(d[k] for k in ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t",
+                                              "aw_t", "grad_out")))
+    S = d["value"].shape[1]
+    dt = torch.float64
+    # this rank's chunk of the flattened value rows (padded to equal shards) and its query range
+    rows = T * S
+    chunk = cp.padded_chunk(rows, world)
+    flat = np.zeros((chunk * world, M, D))
+    flat[:rows] = d["value"].reshape(rows, M, D)
+    v_chunk = torch.from_numpy(flat[rank * chunk:(rank + 1) * chunk]).to(device, dt).requires_grad_(True)
+    q0, q1 = cp.shard_range(Lq, world, rank)
+    cut = lambda k: torch.from_numpy(np.ascontiguousarray(d[k][:, q0:q1])).to(device, dt).requires_grad_(True)
+    lc, ac, lt, at = cut("loc_c"), cut("aw_c"), cut("loc_t"), cut("aw_t")
+    shapes = torch.from_numpy(d["shapes"]).to(device)
+    lsi = torch.from_numpy(d["lsi"]).to(device)
+    ftab = torch.from_numpy(d["ftab"]).to(device)
+
+    out = cp.sharded_temporal_attention(v_chunk, T, S, shapes, lsi, ftab, lc, ac, lt, at)
+    go = torch.from_numpy(np.ascontiguousarray(d["grad_out"][:, q0:q1])).to(device, dt)
+    gv, glc, gac, glt, gat = torch.autograd.grad(out, (v_chunk, lc, ac, lt, at), go)
+
+    def close(a, b, what):
+        err = float(np.abs(a.detach().cpu().numpy() - b).max())
+        assert err <= 1e-9 * max(1.0, float(np.abs(b).max())), (what, rank, err)
+
+    close(out, ref[0][:, q0:q1], "out")
+    gv_ref = np.zeros_like(flat)
+    gv_ref[:rows] = ref[1].reshape(rows, M, D)
+    close(gv, gv_ref[rank * chunk:(rank + 1) * chunk], "grad_value chunk")     # summed over ranks
+    close(glc, ref[2][:, q0:q1], "grad_loc_c")
+    close(gac, ref[3][:, q0:q1], "grad_aw_c")
+    close(glt, ref[4][:, q0:q1], "grad_loc_t")
+    close(gat, ref[5][:, q0:q1], "grad_aw_t")
+    # the ranges tile the query axis
+    r = [cp.shard_range(Lq, world, k) for k in range(world)]
+    assert r[0][0] == 0 and r[-1][1] == Lq and all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d ok" % rank)
+
+
+if __name__ == "__main__":
+    main()
