@@ -140,6 +140,7 @@ struct Params {
     int groups, frames, window;
     int S, M, D, L, Lq;
     int LA, PA, LB, PB;
+    int dbg;                    // measurement hooks (MSDA_DBG env), 0 in production
 };
 
 struct Level { int H, W, start, pad; };   // start = first pixel of the level inside the CLIP slab
@@ -223,44 +224,81 @@ __device__ __forceinline__ void tile_coords(const Params &p, int &m, int &group,
     q0 = (tile - group * tiles_per_group) * RPW;
 }
 
+// The wave walks its rows' sampling points in chunks of kPch: first the chunks of array A (current
+// frame / plain op), then those of array B (temporal points).
+template <typename T> struct ChunkRef {
+    const T *loc, *aw;
+    int LP, P, vl_base, p0, arr;
+};
+
+template <typename T>
+__device__ __forceinline__ ChunkRef<T> get_chunk(const Params &p, int c, int nA)
+{
+    ChunkRef<T> r;
+    r.arr = (c >= nA);
+    r.loc = static_cast<const T *>(r.arr ? p.locB : p.locA);
+    r.aw = static_cast<const T *>(r.arr ? p.awB : p.awA);
+    r.P = r.arr ? p.PB : p.PA;
+    r.LP = (r.arr ? p.LB : p.LA) * r.P;
+    r.vl_base = r.arr ? p.LA : 0;
+    r.p0 = (r.arr ? c - nA : c) * kPch;
+    return r;
+}
+
+__device__ __forceinline__ int n_chunks(int levels, int points) { return (levels * points + kPch - 1) / kPch; }
+
+// (x, y, weight) of the points this lane stages for one chunk: RPW*kPch/64 points per lane, all loads
+// issued before any tap arithmetic.
+template <int NPL> struct Staged { float x[NPL], y[NPL], a[NPL]; };
+
+template <typename T, int RPW>
+__device__ __forceinline__ void load_chunk(const Params &p, const ChunkRef<T> &c, int64_t row0,
+                                           int rows_valid, int lane, Staged<RPW * kPch / kWave> &st)
+{
+#pragma unroll
+    for (int k = 0; k < RPW * kPch / kWave; ++k) {
+        const int i = lane + k * kWave;
+        const int rr = i / kPch, pt = c.p0 + i % kPch;
+        st.x[k] = st.y[k] = -10.f;      // far outside every map: yields an all-zero tap record
+        st.a[k] = 0.f;
+        if (rr < rows_valid && pt < c.LP) {
+            const int64_t idx = (row0 + (int64_t)rr * p.M) * c.LP + pt;
+            st.x[k] = Store<T>::get(c.loc + 2 * idx);
+            st.y[k] = Store<T>::get(c.loc + 2 * idx + 1);
+            st.a[k] = Store<T>::get(c.aw + idx);
+        }
+    }
+}
+
 // Builds the tap records of one chunk (<= kPch points of every row of the wave) in LDS.
 template <typename T, int RPW, bool BWD>
-__device__ __forceinline__ void stage_chunk(const Params &p, const T *__restrict__ loc,
-                                            const T *__restrict__ aw, int LP, int P, int vl_base,
-                                            int p0, int64_t row0, int rows_valid, const Level *s_lvl,
+__device__ __forceinline__ void build_chunk(const Params &p, const ChunkRef<T> &c,
+                                            const Staged<RPW * kPch / kWave> &st, const Level *s_lvl,
                                             int4 *s_off, float4 *s_w, float4 *s_e, int lane)
 {
     const int MD = p.M * p.D;
 #pragma unroll
-    for (int i = lane; i < RPW * kPch; i += kWave) {
-        const int rr = i / kPch, pp = i % kPch, pt = p0 + pp;
-        int4 o = make_int4(0, 0, 0, 0);
-        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rr < rows_valid && pt < LP) {
-            const int64_t idx = (row0 + (int64_t)rr * p.M) * LP + pt;
-            const float x = Store<T>::get(loc + 2 * idx);
-            const float y = Store<T>::get(loc + 2 * idx + 1);
-            const float a = Store<T>::get(aw + idx);
-            const int vl = vl_base + pt / P;
-            const Taps t = make_taps(x, y, s_lvl[vl], MD);
-            o = make_int4(t.off[0], t.off[1], t.off[2], t.off[3]);
-            if (BWD) {
-                w = make_float4(t.w[0], t.w[1], t.w[2], t.w[3]);
-                // a, fractions, and (valid bits | level index << 4) for the final gradient lane
-                e = make_float4(a, t.lh, t.lw, __int_as_float(t.valid | (vl << 4)));
-            } else {
-                w = make_float4(t.w[0] * a, t.w[1] * a, t.w[2] * a, t.w[3] * a);
-            }
+    for (int k = 0; k < RPW * kPch / kWave; ++k) {
+        const int i = lane + k * kWave;
+        const int rr = i / kPch, pp = i % kPch;
+        const int vl = c.vl_base + min(c.p0 + pp, c.LP - 1) / c.P;
+        const float a = st.a[k];
+        const Taps t = make_taps(st.x[k], st.y[k], s_lvl[vl], MD);
+        s_off[rr * kRowSlots + pp] = make_int4(t.off[0], t.off[1], t.off[2], t.off[3]);
+        if (BWD) {
+            s_w[rr * kRowSlots + pp] = make_float4(t.w[0], t.w[1], t.w[2], t.w[3]);
+            // a, fractions, and (valid bits | level index << 4) for the final gradient lane
+            s_e[rr * kRowSlots + pp] = make_float4(a, t.lh, t.lw, __int_as_float(t.valid | (vl << 4)));
+        } else {
+            s_w[rr * kRowSlots + pp] = make_float4(t.w[0] * a, t.w[1] * a, t.w[2] * a, t.w[3] * a);
         }
-        s_off[rr * kRowSlots + pp] = o;
-        s_w[rr * kRowSlots + pp] = w;
-        if (BWD) s_e[rr * kRowSlots + pp] = e;
     }
 }
 
-template <typename T, int G>
-__global__ void __launch_bounds__(kWave)
+// NB = sampling points whose 4*NB corner loads are issued back to back before any FMA consumes them
+// (memory-level parallelism per wave); more points in flight cost VGPRs, i.e. waves per SIMD.
+template <typename T, int G, int NB>
+__global__ void __launch_bounds__(kWave, (NB <= 2 && kPch / G <= 2) ? 8 : 4)
 msda_fwd_tile_kernel(const Params p)
 {
     constexpr int VEC = Store<T>::VEC;
@@ -289,40 +327,47 @@ msda_fwd_tile_kernel(const Params p)
 #pragma unroll
     for (int c = 0; c < VEC; ++c) acc[c] = 0.f;
 
+    const int nA = n_chunks(p.LA, p.PA), n_all = nA + n_chunks(p.LB, p.PB);
+    // No cross-chunk prefetch on purpose: vector-memory loads return in order, so an HBM-latency load of
+    // the next chunk's (x, y, weight) issued ahead of the gathers only makes every gather wait for it
+    // (measured: 0.73 -> 0.82 ms); the other waves of the SIMD cover the stage phase instead.
+    Staged<RPW * kPch / kWave> st;
 #pragma unroll 1
-    for (int arr = 0; arr < 2; ++arr) {
-        const T *loc = static_cast<const T *>(arr ? p.locB : p.locA);
-        const T *aw = static_cast<const T *>(arr ? p.awB : p.awA);
-        const int P = arr ? p.PB : p.PA;
-        const int LP = (arr ? p.LB : p.LA) * P;
-        const int vl_base = arr ? p.LA : 0;
+    for (int ci = 0; ci < n_all; ++ci) {
+        const ChunkRef<T> c = get_chunk<T>(p, ci, nA);
+        load_chunk<T, RPW>(p, c, row0, rows_valid, lane, st);
+        build_chunk<T, RPW, false>(p, c, st, s_lvl, s_off, s_w, nullptr, lane);
+        __syncthreads();
+        const int np = min(kPch, c.LP - c.p0);
+        const int4 *ro = s_off + r * kRowSlots;
+        const float4 *rw = s_w + r * kRowSlots;
+        // slots np..kPch-1 hold zero-weight records (offset 0), so a batch may run past np
 #pragma unroll 1
-        for (int p0 = 0; p0 < LP; p0 += kPch) {
-            stage_chunk<T, RPW, false>(p, loc, aw, LP, P, vl_base, p0, row0, rows_valid, s_lvl,
-                                       s_off, s_w, nullptr, lane);
-            __syncthreads();
-            const int np = min(kPch, LP - p0);
-            const int4 *ro = s_off + r * kRowSlots;
-            const float4 *rw = s_w + r * kRowSlots;
-#pragma unroll 4
-            for (int pp = 0; pp < np; ++pp) {
-                const int4 o = ro[pp];
-                const float4 w = rw[pp];
-                float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
-                Store<T>::load(value + o.x, v0);
-                Store<T>::load(value + o.y, v1);
-                Store<T>::load(value + o.z, v2);
-                Store<T>::load(value + o.w, v3);
+        for (int pp = 0; pp < np; pp += NB) {
+            int4 o[NB];
+            float4 w[NB];
+            float v[NB][4][VEC];
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) {
-                    acc[c] = fmaf(w.x, v0[c], acc[c]);
-                    acc[c] = fmaf(w.y, v1[c], acc[c]);
-                    acc[c] = fmaf(w.z, v2[c], acc[c]);
-                    acc[c] = fmaf(w.w, v3[c], acc[c]);
+            for (int b = 0; b < NB; ++b) { o[b] = ro[pp + b]; w[b] = rw[pp + b]; }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                Store<T>::load(value + o[b].x, v[b][0]);
+                Store<T>::load(value + o[b].y, v[b][1]);
+                Store<T>::load(value + o[b].z, v[b][2]);
+                Store<T>::load(value + o[b].w, v[b][3]);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int ch = 0; ch < VEC; ++ch) {
+                    acc[ch] = fmaf(w[b].x, v[b][0][ch], acc[ch]);
+                    acc[ch] = fmaf(w[b].y, v[b][1][ch], acc[ch]);
+                    acc[ch] = fmaf(w[b].z, v[b][2][ch], acc[ch]);
+                    acc[ch] = fmaf(w[b].w, v[b][3][ch], acc[ch]);
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();
     }
     if (r < rows_valid) {
         T *out = static_cast<T *>(p.out) + (row0 + (int64_t)r * p.M) * p.D + sub * VEC;
@@ -344,12 +389,25 @@ __device__ __forceinline__ float wave_absmax(float v)
     return v;
 }
 
-// sum over the G lanes of a row (G is a power of two <= 64): xor butterfly, DPP / ds_swizzle
+// sum over the G lanes of a row (G a power of two <= 64; rows are G-aligned lane groups).  Up to 16
+// lanes the butterfly is pure DPP (no LDS crossbar, no waits): quad_perm xor1 / xor2, row_half_mirror
+// (lane i <-> 7-i inside each 8), row_mirror (i <-> 15-i inside each 16); wider rows finish with
+// shuffles.  Every lane of the row ends up with the total.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
 template <int G>
 __device__ __forceinline__ float row_sum(float v)
 {
-#pragma unroll
-    for (int s = 1; s < G; s <<= 1) v += __shfl_xor(v, s, kWave);
+    if (G >= 2) v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
+    if (G >= 4) v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
+    if (G >= 8) v = dpp_add<0x141>(v);    // row_half_mirror
+    if (G >= 16) v = dpp_add<0x140>(v);   // row_mirror
+    if (G >= 32) v += __shfl_xor(v, 16, kWave);
+    if (G >= 64) v += __shfl_xor(v, 32, kWave);
     return v;
 }
 
@@ -398,24 +456,22 @@ msda_bwd_tile_kernel(const Params p)
         for (int c = 0; c < VEC; ++c) amax_g = absmax_key(amax_g, g[c]);
     }
 
+    const int nA = n_chunks(p.LA, p.PA), n_all = nA + n_chunks(p.LB, p.PB);
+    Staged<RPW * kPch / kWave> st;
 #pragma unroll 1
-    for (int arr = 0; arr < 2; ++arr) {
-        const T *loc = static_cast<const T *>(arr ? p.locB : p.locA);
-        const T *aw = static_cast<const T *>(arr ? p.awB : p.awA);
-        T *gloc = static_cast<T *>(arr ? p.glocB : p.glocA);
-        T *gaw = static_cast<T *>(arr ? p.gawB : p.gawA);
-        const int P = arr ? p.PB : p.PA;
-        const int LP = (arr ? p.LB : p.LA) * P;
-        const int vl_base = arr ? p.LA : 0;
-#pragma unroll 1
-        for (int p0 = 0; p0 < LP; p0 += kPch) {
-            stage_chunk<T, RPW, true>(p, loc, aw, LP, P, vl_base, p0, row0, rows_valid, s_lvl,
-                                      s_off, s_w, s_e, lane);
-            __syncthreads();
-            if (!ATOMICS) {     // every staged weight is seen by lanes sub == pp % G below; cheaper here:
-                for (int i = lane; i < RPW * kPch; i += kWave)
-                    amax_a = absmax_key(amax_a, s_e[(i / kPch) * kRowSlots + (i % kPch)].x);
+    for (int ci = 0; ci < n_all; ++ci) {
+        {
+            const ChunkRef<T> c = get_chunk<T>(p, ci, nA);
+            load_chunk<T, RPW>(p, c, row0, rows_valid, lane, st);
+            T *gloc = static_cast<T *>(c.arr ? p.glocB : p.glocA);
+            T *gaw = static_cast<T *>(c.arr ? p.gawB : p.gawA);
+            const int LP = c.LP, p0 = c.p0;
+            if (!ATOMICS) {
+#pragma unroll
+                for (int k = 0; k < RPW * kPch / kWave; ++k) amax_a = absmax_key(amax_a, st.a[k]);
             }
+            build_chunk<T, RPW, true>(p, c, st, s_lvl, s_off, s_w, s_e, lane);
+            __syncthreads();
             const int np = min(kPch, LP - p0);
             const int4 *ro = s_off + r * kRowSlots;
             const float4 *rw = s_w + r * kRowSlots;
@@ -466,22 +522,35 @@ msda_bwd_tile_kernel(const Params p)
                         for (int c = 0; c < VEC; ++c) atomic_accumulate(gvalue + o.w + c, wa3 * g[c]);
                     }
                 }
-                d0 = row_sum<G>(d0);
-                d1 = row_sum<G>(d1);
-                d2 = row_sum<G>(d2);
-                d3 = row_sum<G>(d3);
+                if (!(p.dbg & 16)) {
+                    d0 = row_sum<G>(d0);
+                    d1 = row_sum<G>(d1);
+                    d2 = row_sum<G>(d2);
+                    d3 = row_sum<G>(d3);
+                }
                 // one lane per (row, point) finishes: cuh:123-158 rewritten on the reduced dots
-                if (sub == (pp % G) && r < rows_valid) {
+                if (sub == (pp % G)) {
                     const float lh = e.y, lw = e.z, hh = 1.f - lh, hw = 1.f - lw;
                     const Level lv = s_lvl[bits >> 4];
                     const float g_aw = w.x * d0 + w.y * d1 + w.z * d2 + w.w * d3;
                     const float g_w = hh * (d1 - d0) + lh * (d3 - d2);
                     const float g_h = hw * (d2 - d0) + lw * (d3 - d1);
-                    const int64_t idx = row * LP + (p0 + pp);
-                    Store<T>::put(gaw + idx, g_aw);
-                    Store<T>::put(gloc + 2 * idx, (float)lv.W * g_w * a);
-                    Store<T>::put(gloc + 2 * idx + 1, (float)lv.H * g_h * a);
+                    // park the point's three gradients in its (now consumed) LDS slot; they leave for
+                    // HBM below as whole rows -- one 4-byte store per point and component cost as much
+                    // as the entire gather (measured: 91 -> 52 us per clip without them)
+                    s_e[r * kRowSlots + pp] = make_float4((float)lv.W * g_w * a, (float)lv.H * g_h * a, g_aw, 0.f);
                 }
+            }
+            __syncthreads();
+            // coalesced write-out: the chunk's 2*np grad_loc and np grad_attn elements of a row are
+            // contiguous in memory; the row's G lanes write them G elements per instruction
+            if (r < rows_valid && !(p.dbg & 8)) {
+                const int64_t idx0 = row * LP + p0;
+                const float *res = reinterpret_cast<const float *>(s_e + r * kRowSlots);
+                for (int el = sub; el < 2 * np; el += G)
+                    Store<T>::put(gloc + 2 * idx0 + el, res[(el >> 1) * 4 + (el & 1)]);
+                for (int el = sub; el < np; el += G)
+                    Store<T>::put(gaw + idx0 + el, res[el * 4 + 2]);
             }
             __syncthreads();
         }
@@ -533,8 +602,20 @@ msda_bwd_tile_kernel(const Params p)
 //   The grid is persistent (one 1024-thread workgroup per CU striding over the items) because the
 //   number of bands depends on spatial_shapes, which lives in device memory (no host sync allowed);
 //   item % M = head keeps the head -> XCD affinity of the gather kernels.
+// round(term * 2^k) as a 64-bit integer from two fp32 -> int32 conversions (no fp64, no 64-bit
+// multiply): with s = 2^(k-31), |term * s| < 2^31;  hi = rint(term * s) is exact in fp32, the remainder
+// term * s - hi is exact (|rem| <= 1/2), lo = rint(rem * 2^31);  result = hi * 2^31 + lo.
+__device__ __forceinline__ long long to_fixed(float term, float scale_hi)
+{
+    const float t = term * scale_hi;
+    const float hi = rintf(t);
+    const float lo = rintf((t - hi) * 2147483648.f);
+    return ((long long)(int)hi << 31) + (long long)(int)lo;
+}
+
 constexpr int kScatterThreads = 1024;
 constexpr int kScatterMaxLevels = 32;
+constexpr int kScatterMaxSources = 64;     // 1 + frames * window must fit
 typedef unsigned long long u64;
 
 template <typename T, int G>
@@ -548,6 +629,7 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int headroom_bits, int 
     u64 *band = reinterpret_cast<u64 *>(lds_raw);
     __shared__ int s_H[kScatterMaxLevels], s_W[kScatterMaxLevels], s_R[kScatterMaxLevels],
         s_first[kScatterMaxLevels + 1], s_lsi[kScatterMaxLevels];
+    __shared__ int s_src[kScatterMaxSources], s_nsrc;
 
     const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
     const int D = p.D, MD = p.M * p.D;
@@ -573,9 +655,10 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int headroom_bits, int 
     const float vmax = __uint_as_float(p.workspace[0]) * __uint_as_float(p.workspace[1]);
     const bool finite = vmax <= 3.0e38f;           // false for NaN too
     int e = 0;
-    (void)frexpf(fmaxf(vmax, 1e-30f), &e);          // vmax < 2^e
+    (void)frexpf(fmaxf(vmax, 1e-20f), &e);          // vmax < 2^e  (floor keeps 2^(k-31) a finite float)
     const int k = 62 - headroom_bits - e;
-    const double scale = ldexp(1.0, k), inv_scale = ldexp(1.0, -k);
+    const float scale_hi = ldexpf(1.f, k - 31);     // |term| * scale_hi < 2^(31 - headroom)
+    const double inv_scale = ldexp(1.0, -k);
 
     for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int m = (int)(item % p.M);
@@ -599,95 +682,148 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int headroom_bits, int 
         float *gmap = static_cast<float *>(p.grad_value) +
                       (((int64_t)clip * p.frames + f) * p.S + s_lsi[l]) * MD + m * D;
 
-        const int n_src = (dbg & 4) ? 0 : 1 + p.frames * p.window;
-        for (int src = 0; src < n_src; ++src) {
-            int t = f, vl = l, P = p.PA, LP = p.LA * p.PA;
-            const T *loc = static_cast<const T *>(p.locA);
-            const T *aw = static_cast<const T *>(p.awA);
-            if (src > 0) {
-                t = (src - 1) / p.window;
-                const int w = (src - 1) - t * p.window;
-                if (p.ftab[t * p.window + w] != f) continue;
-                vl = w * L + l; P = p.PB; LP = p.LB * p.PB;
-                loc = static_cast<const T *>(p.locB);
-                aw = static_cast<const T *>(p.awB);
+        // sources that read frame f: the current-frame points of frame f, then every temporal slot
+        // (t, w) with frame_table[t, w] == f (list built once per item; repeats allowed)
+        if (tid == 0) {
+            int n = 0;
+            s_src[n++] = -1;
+            for (int tw = 0; tw < p.frames * p.window; ++tw)
+                if (p.ftab[tw] == f) s_src[n++] = tw;
+            s_nsrc = (dbg & 4) ? 0 : n;
+        }
+        __syncthreads();
+        const int n_srcs = s_nsrc;
+        // flat candidate space: [Lq*PA points of the current source][Lq*PB points per temporal source]
+        const int nptsA = p.Lq * p.PA, nptsB = p.Lq * p.PB;
+        const int total = n_srcs ? nptsA + (n_srcs - 1) * nptsB : 0;
+
+        // one candidate per lane per pass; the NEXT pass's (x, y, attn) are loaded before this pass's
+        // hits are processed, so the scan's memory latency hides behind stage 2
+        auto fetch = [&](int i, float &x, float &y, float &a, int &qrow) {
+            x = y = -10.f; a = 0.f; qrow = 0;
+            if (i < total) {
+                int t = f, vl = l, P = p.PA, LP = p.LA * p.PA, j = i;
+                const T *loc = static_cast<const T *>(p.locA);
+                const T *aw = static_cast<const T *>(p.awA);
+                if (i >= nptsA) {
+                    const int k = (i - nptsA) / nptsB;
+                    j = (i - nptsA) - k * nptsB;
+                    const int tw = s_src[1 + k];
+                    t = tw / p.window;
+                    vl = (tw - t * p.window) * L + l; P = p.PB; LP = p.LB * p.PB;
+                    loc = static_cast<const T *>(p.locB);
+                    aw = static_cast<const T *>(p.awB);
+                }
+                const int q = j / P, pt = j - q * P;
+                const int64_t gq = ((int64_t)clip * p.frames + t) * p.Lq + q;
+                const int64_t idx = (gq * p.M + m) * LP + vl * P + pt;
+                x = Store<T>::get(loc + 2 * idx);
+                y = Store<T>::get(loc + 2 * idx + 1);
+                a = Store<T>::get(aw + idx);
+                qrow = (int)gq;
             }
-            const int64_t group = (int64_t)clip * p.frames + t;
-            const int npts = p.Lq * P;
-            for (int base = wave * kWave; base < npts; base += kWaves * kWave) {
-                const int i = base + lane;
-                // ---- stage 1: one lane per candidate point
+        };
+        // NC candidates per lane per pass: a band catches only ~1/7 of its level's points, so one
+        // candidate per lane gives ~10 hits per wave -- two stage-2 iterations at ~60 % team use.
+        // With 4 candidates per lane the hits are merged into dense rounds (~90 % use).
+        constexpr int NC = 4;
+        constexpr int kPass = kScatterThreads * NC;
+        float cx[NC], cy[NC], ca[NC];
+        int cq[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) fetch(c * kScatterThreads + tid, cx[c], cy[c], ca[c], cq[c]);
+        for (int base = 0; base < total; base += kPass) {
+            // ---- stage 1: tap arithmetic + band test for this lane's NC candidates
+            int pixs[NC], bitss[NC], qrows[NC];
+            float was[NC][4];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float x = cx[c], y = cy[c], a = ca[c];
+                qrows[c] = cq[c];
+                pixs[c] = 0; bitss[c] = 0;
+                was[c][0] = was[c][1] = was[c][2] = was[c][3] = 0.f;
+                const float h_im = __fsub_rn(__fmul_rn(y, (float)H), 0.5f);
+                const float w_im = __fsub_rn(__fmul_rn(x, (float)W), 0.5f);
+                if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                    const float hf = floorf(h_im), wf = floorf(w_im);
+                    const int h_low = (int)hf, w_low = (int)wf;
+                    // rows this band owns among the point's two rows
+                    const bool top = h_low >= max(r0, 0) && h_low <= r1;
+                    const bool bot = h_low + 1 >= r0 && h_low + 1 <= min(r1, H - 1);
+                    const bool x0 = w_low >= 0, x1 = w_low + 1 <= W - 1;
+                    bitss[c] = (top && x0 ? 1 : 0) | (top && x1 ? 2 : 0) | (bot && x0 ? 4 : 0) | (bot && x1 ? 8 : 0);
+                    const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+                    was[c][0] = hh * hw * a; was[c][1] = hh * lw * a; was[c][2] = lh * hw * a; was[c][3] = lh * lw * a;
+                    pixs[c] = (h_low - r0) * W + w_low;       // may be "virtual" for unowned corners
+                }
+            }
+            // next pass's (x, y, attn) fly while this pass's hits are processed
+#pragma unroll
+            for (int c = 0; c < NC; ++c) fetch(base + kPass + c * kScatterThreads + tid, cx[c], cy[c], ca[c], cq[c]);
+            if (dbg & 2) continue;
+            // ---- merge: every round each lane offers its first unprocessed hit
+#pragma unroll 1
+            for (int round = 0; round < NC; ++round) {
                 int pix00 = 0, bits = 0, qrow = 0;
                 float wa0 = 0.f, wa1 = 0.f, wa2 = 0.f, wa3 = 0.f;
-                if (i < npts) {
-                    const int q = i / P, pt = i - q * P;
-                    const int64_t row = (group * p.Lq + q) * p.M + m;
-                    const int64_t idx = row * LP + vl * P + pt;
-                    const float x = Store<T>::get(loc + 2 * idx);
-                    const float y = Store<T>::get(loc + 2 * idx + 1);
-                    const float h_im = __fsub_rn(__fmul_rn(y, (float)H), 0.5f);
-                    const float w_im = __fsub_rn(__fmul_rn(x, (float)W), 0.5f);
-                    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-                        const float hf = floorf(h_im), wf = floorf(w_im);
-                        const int h_low = (int)hf, w_low = (int)wf;
-                        // rows this band owns among the point's two rows
-                        const bool top = h_low >= max(r0, 0) && h_low <= r1;
-                        const bool bot = h_low + 1 >= r0 && h_low + 1 <= min(r1, H - 1);
-                        const bool x0 = w_low >= 0, x1 = w_low + 1 <= W - 1;
-                        bits = (top && x0 ? 1 : 0) | (top && x1 ? 2 : 0) | (bot && x0 ? 4 : 0) | (bot && x1 ? 8 : 0);
-                        if (bits) {
-                            const float a = Store<T>::get(aw + idx);
-                            const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-                            wa0 = hh * hw * a; wa1 = hh * lw * a; wa2 = lh * hw * a; wa3 = lh * lw * a;
-                            pix00 = (h_low - r0) * W + w_low;       // may be "virtual" for unowned corners
-                            qrow = (int)(group * p.Lq + q);
-                        }
+                bool taken = false;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const bool pick = !taken && bitss[c] != 0;
+                    if (pick) {
+                        pix00 = pixs[c]; bits = bitss[c]; qrow = qrows[c];
+                        wa0 = was[c][0]; wa1 = was[c][1]; wa2 = was[c][2]; wa3 = was[c][3];
+                        bitss[c] = 0;
+                        taken = true;
                     }
                 }
                 u64 mask = __ballot(bits != 0);
-                if (dbg & 2) mask = 0;
-                // ---- stage 2: RPW hits per pass, one team of G lanes per hit
-                while (mask) {
-                    u64 mm = mask;
+                if (!mask) break;
+            // ---- stage 2: RPW hits per iteration, one team of G lanes per hit (8 hits share one
+            // grad_out load latency; a one-hit-per-iteration variant with v_readlane broadcast measured
+            // 1.7x slower because every hit then exposes that latency).  Lane i of team k adds channel
+            // ((c + k) % VEC) * G + i at step c, so the teams of one half-wave hit disjoint LDS banks.
+            while (mask) {
+                u64 mm = mask;
 #pragma unroll
-                    for (int j = 0; j < RPW - 1; ++j)
-                        if (j < team) mm &= mm - 1;
-                    const bool has = mm != 0;
-                    const int from = has ? __builtin_ctzll(mm) : 0;
-                    const int h_pix = __shfl(pix00, from, kWave);
-                    const int b_all = __shfl(bits, from, kWave);
-                    const int h_bits = has ? b_all : 0;
-                    const int h_q = __shfl(qrow, from, kWave);
-                    const float h_w0 = __shfl(wa0, from, kWave), h_w1 = __shfl(wa1, from, kWave);
-                    const float h_w2 = __shfl(wa2, from, kWave), h_w3 = __shfl(wa3, from, kWave);
-                    if (h_bits) {
-                        const T *go = static_cast<const T *>(p.grad_out) + (int64_t)h_q * MD + m * D;
-                        float gc[VEC];
+                for (int j = 0; j < RPW - 1; ++j)
+                    if (j < team) mm &= mm - 1;
+                const bool has = mm != 0;
+                const int from = has ? __builtin_ctzll(mm) : 0;
+                const int h_pix = __shfl(pix00, from, kWave);
+                const int b_all = __shfl(bits, from, kWave);
+                const int h_bits = has ? b_all : 0;
+                const int h_q = __shfl(qrow, from, kWave);
+                const float h_w0 = __shfl(wa0, from, kWave), h_w1 = __shfl(wa1, from, kWave);
+                const float h_w2 = __shfl(wa2, from, kWave), h_w3 = __shfl(wa3, from, kWave);
+                if (h_bits) {
+                    const T *go = static_cast<const T *>(p.grad_out) + (int64_t)h_q * MD + m * D;
+                    float gc[VEC];
 #pragma unroll
-                        for (int c = 0; c < VEC; ++c)       // all channel loads in flight before the adds
-                            gc[c] = Store<T>::get(go + ((c + team) % VEC) * G + sub);
+                    for (int c = 0; c < VEC; ++c)       // all channel loads in flight before the adds
+                        gc[c] = Store<T>::get(go + ((c + team) % VEC) * G + sub);
 #pragma unroll
-                        for (int c = 0; c < VEC; ++c) {
-                            const int ch = ((c + team) % VEC) * G + sub;
-                            if (direct) {
-                                float *dst = gmap + (int64_t)h_pix * MD + ch;
-                                if (h_bits & 1) atomic_accumulate(dst, h_w0 * gc[c]);
-                                if (h_bits & 2) atomic_accumulate(dst + MD, h_w1 * gc[c]);
-                                if (h_bits & 4) atomic_accumulate(dst + (int64_t)W * MD, h_w2 * gc[c]);
-                                if (h_bits & 8) atomic_accumulate(dst + (int64_t)(W + 1) * MD, h_w3 * gc[c]);
-                            } else if (!(dbg & 1)) {
-                                u64 *dst = band + h_pix * D + ch;
-                                // fp32 product (the reference's atomicAdd operand) -> exact fixed point
-                                if (h_bits & 1) atomicAdd(dst, (u64)__double2ll_rn((double)(h_w0 * gc[c]) * scale));
-                                if (h_bits & 2) atomicAdd(dst + D, (u64)__double2ll_rn((double)(h_w1 * gc[c]) * scale));
-                                if (h_bits & 4) atomicAdd(dst + W * D, (u64)__double2ll_rn((double)(h_w2 * gc[c]) * scale));
-                                if (h_bits & 8) atomicAdd(dst + (W + 1) * D, (u64)__double2ll_rn((double)(h_w3 * gc[c]) * scale));
-                            }
+                    for (int c = 0; c < VEC; ++c) {
+                        const int ch = ((c + team) % VEC) * G + sub;
+                        // fp32 products = the reference's atomicAdd operands (cuh:125-152)
+                        if (direct) {
+                            float *dst = gmap + (int64_t)h_pix * MD + ch;
+                            if (h_bits & 1) atomic_accumulate(dst, h_w0 * gc[c]);
+                            if (h_bits & 2) atomic_accumulate(dst + MD, h_w1 * gc[c]);
+                            if (h_bits & 4) atomic_accumulate(dst + (int64_t)W * MD, h_w2 * gc[c]);
+                            if (h_bits & 8) atomic_accumulate(dst + (int64_t)(W + 1) * MD, h_w3 * gc[c]);
+                        } else if (!(dbg & 1)) {
+                            u64 *dst = band + h_pix * D + ch;
+                            if (h_bits & 1) atomicAdd(dst, (u64)to_fixed(h_w0 * gc[c], scale_hi));
+                            if (h_bits & 2) atomicAdd(dst + D, (u64)to_fixed(h_w1 * gc[c], scale_hi));
+                            if (h_bits & 4) atomicAdd(dst + W * D, (u64)to_fixed(h_w2 * gc[c], scale_hi));
+                            if (h_bits & 8) atomicAdd(dst + (W + 1) * D, (u64)to_fixed(h_w3 * gc[c], scale_hi));
                         }
                     }
-#pragma unroll
-                    for (int j = 0; j < RPW; ++j) mask &= mask - 1;
                 }
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) mask &= mask - 1;
+            }
             }
         }
         __syncthreads();
@@ -888,6 +1024,7 @@ bool scatter_applicable(const Params &p)
     const char *mode = getenv("MSDA_BWD_MODE");
     if (mode && !strcmp(mode, "atomic")) return false;
     if (p.L > kScatterMaxLevels || (p.D % 4) != 0 || !p.workspace) return false;
+    if (1 + p.frames * p.window > kScatterMaxSources) return false;
     if (p.window == 0 && p.LA != p.L) return false;
     return true;
 }
@@ -901,7 +1038,13 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     if (blocks > 0x7fffffffLL) return fail(MSDA_ERR_ARG, "msda: problem too large for one launch%s");
     const size_t lds = tile_lds_bytes(RPW, p.LA + p.LB, bwd);
     if (!bwd) {
-        hipLaunchKernelGGL((msda_fwd_tile_kernel<T, G>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
+        const int nb = env_int("MSDA_FWD_NB", 4);
+        if (nb == 1)
+            hipLaunchKernelGGL((msda_fwd_tile_kernel<T, G, 1>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
+        else if (nb == 2)
+            hipLaunchKernelGGL((msda_fwd_tile_kernel<T, G, 2>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
+        else
+            hipLaunchKernelGGL((msda_fwd_tile_kernel<T, G, 4>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
         return check_launch("msda forward (tile kernel)");
     }
     if (!scatter_applicable(p)) {
@@ -988,8 +1131,10 @@ int env_force_generic()
     return e && e[0] == '1';
 }
 
-int run(int dtype, const Params &p, bool bwd, hipStream_t stream)
+int run(int dtype, const Params &p_in, bool bwd, hipStream_t stream)
 {
+    Params p = p_in;
+    p.dbg = env_int("MSDA_DBG", 0);
     if (p.groups == 0 || p.Lq == 0) return MSDA_OK;
     bool taken = false;
     int rc = MSDA_OK;

@@ -30,9 +30,12 @@ def run(clips, locs, pyramid="A", dtype="f32", reps=10):
     w = tm(lambda: _native.temporal_backward(b["value"], b["shapes"], b["lsi"], b["ftab"], b["loc_c"], b["aw_c"], b["loc_t"], b["aw_t"], b["grad_out"], clips, gv, gl_c, ga_c, gl_t, ga_t)) if "--bwd" in sys.argv else float("nan")
     print(f"clips={clips:3d} locs={locs:9s} pyr={pyramid} {dtype}: fwd {f:9.1f} us ({f/clips:7.1f} us/clip)  bwd {w:10.1f} us ({w/clips:8.1f} us/clip)", flush=True)
 
-if __name__ == "__main__":
+def main():
     for dtype in ("f32", "bf16"):
         for locs in ("uniform", "clustered", "same"):
             for clips in (1, 4, 16, 32):
                 run(clips, locs, dtype=dtype)
     run(8, "uniform", pyramid="B"); run(8, "clustered", pyramid="B")
+
+if __name__ == "__main__":
+    main()
