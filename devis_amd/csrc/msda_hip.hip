@@ -136,7 +136,7 @@ struct Params {
     const void *grad_out;       // bwd
     void *grad_value;           // bwd: acc type, pre-zeroed
     void *glocA, *gawA, *glocB, *gawB;
-    unsigned *workspace;        // bwd: [0] = bits of max|grad_out|, [1] = bits of max|attn| (zeroed by caller)
+    unsigned *workspace;        // bwd: reserved scratch (unused since grad_value accumulates in fp64)
     int groups, frames, window;
     int S, M, D, L, Lq;
     int LA, PA, LB, PB;
@@ -375,20 +375,6 @@ msda_fwd_tile_kernel(const Params p)
     }
 }
 
-// running abs-max that treats NaN/Inf as +huge (so a non-finite input is never hidden)
-__device__ __forceinline__ float absmax_key(float cur, float v)
-{
-    const float a = fabsf(v);
-    return (a <= 3.0e38f) ? fmaxf(cur, a) : 3.4e38f;
-}
-
-__device__ __forceinline__ float wave_absmax(float v)
-{
-#pragma unroll
-    for (int s = 1; s < kWave; s <<= 1) v = fmaxf(v, __shfl_xor(v, s, kWave));
-    return v;
-}
-
 // sum over the G lanes of a row (G a power of two <= 64; rows are G-aligned lane groups).  Up to 16
 // lanes the butterfly is pure DPP (no LDS crossbar, no waits): quad_perm xor1 / xor2, row_half_mirror
 // (lane i <-> 7-i inside each 8), row_mirror (i <-> 15-i inside each 16); wider rows finish with
@@ -448,14 +434,6 @@ msda_bwd_tile_kernel(const Params p)
 #pragma unroll
     for (int c = 0; c < VEC; ++c) g[c] = 0.f;
     if (r < rows_valid) Store<T>::load(static_cast<const T *>(p.grad_out) + row * p.D + sub * VEC, g);
-    // abs-max of grad_out and of the attention weights seen by this wave: the LDS scatter kernel
-    // derives its fixed-point scale from them (NaN/Inf map to a huge key, which selects its float path)
-    float amax_g = 0.f, amax_a = 0.f;
-    if (!ATOMICS) {
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) amax_g = absmax_key(amax_g, g[c]);
-    }
-
     const int nA = n_chunks(p.LA, p.PA), n_all = nA + n_chunks(p.LB, p.PB);
     Staged<RPW * kPch / kWave> st;
 #pragma unroll 1
@@ -466,10 +444,6 @@ msda_bwd_tile_kernel(const Params p)
             T *gloc = static_cast<T *>(c.arr ? p.glocB : p.glocA);
             T *gaw = static_cast<T *>(c.arr ? p.gawB : p.gawA);
             const int LP = c.LP, p0 = c.p0;
-            if (!ATOMICS) {
-#pragma unroll
-                for (int k = 0; k < RPW * kPch / kWave; ++k) amax_a = absmax_key(amax_a, st.a[k]);
-            }
             build_chunk<T, RPW, true>(p, c, st, s_lvl, s_off, s_w, s_e, lane);
             __syncthreads();
             const int np = min(kPch, LP - p0);
@@ -555,44 +529,34 @@ msda_bwd_tile_kernel(const Params p)
             __syncthreads();
         }
     }
-    if (!ATOMICS) {
-        amax_g = wave_absmax(amax_g);
-        amax_a = wave_absmax(amax_a);
-        if (lane == 0) {
-            // non-negative floats order like their bit patterns; skip the atomic when not a new maximum
-            const unsigned kg = __float_as_uint(amax_g), ka = __float_as_uint(amax_a);
-            if (kg > __hip_atomic_load(p.workspace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.workspace, kg);
-            if (ka > __hip_atomic_load(p.workspace + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.workspace + 1, ka);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// grad_value by LDS-privatised scatter in 64-bit fixed point
+// grad_value by LDS-privatised scatter, accumulated in fp64
 // ------------------------------------------------------------------------------------------------
-// Measured on MI355X (scripts/ubench/lds_atomics.hip): global fp32 atomics ~80 G lane-op/s (34 ms for
-// 16 clips of the DeVIS decoder layer); LDS *float* atomics (ds_add_f32, ds_add_rtn_f32,
-// ds_pk_add_f16) 193 clk per wave instruction; LDS *integer* atomics ds_add_u32 / ds_add_u64 6.2 /
-// 7.5 clk per wave instruction.  So grad_value is accumulated with ds_add_u64 in fixed point:
+// Measured on MI355X (scripts/ubench/lds_atomics.hip), clk per wave instruction per CU:
+//   global fp32 atomics            ~80 G lane-op/s chip-wide (34 ms for 16 clips of the DeVIS decoder layer)
+//   LDS ds_add_f32 / ds_add_rtn_f32 / ds_pk_add_f16      193      (a slow path: 3 clk per LANE)
+//   LDS ds_add_u32 / ds_max_i32    5.0      ds_add_u64   7.5      ds_add_f64   9.1
+// So grad_value is accumulated with ds_add_f64 in LDS.  (A 64-bit fixed-point variant with ds_add_u64
+// was built first -- exact and order-independent -- but its float->fixed conversion costs ~13 VALU
+// instructions per term and made the kernel VALU-bound: 1.25 G VALU wave-instructions per launch.)
 //
 //   work item = (clip, source frame f, head m, band); a band is a run of pixel ROWS of one level map
 //   whose [rows, W, D] accumulator (8 bytes per channel) fits the workgroup's LDS budget.
 //   The workgroup zeroes the band, scans every sampling point that reads (f, m, level) -- the
 //   current-frame points of frame f and the temporal points of every (t, w) with
 //   frame_table[t, w] == f --, and adds each bilinear corner that falls on a row it OWNS:
-//       term  = fp32 product  w_corner * attn * grad_out[c]          (exactly the reference's
-//               atomicAdd operand, cuh:125-152)
-//       LDS  += llrint(term * 2^k)                                   (ds_add_u64, exact integer sum)
-//   then streams the band to grad_value as float(sum * 2^-k) with plain coalesced 16-byte stores.
-//   2^k is chosen so that the largest possible |term| (max|attn| * max|grad_out|, produced on the
-//   device by the gather pass -- no host sync) times the largest possible number of terms per
-//   accumulator stays below 2^62; the quantum is <= 2^-37 of the largest term.  The sum is therefore
-//   exact up to that quantum, independent of summation order (bit-reproducible, which the
-//   reference's float atomicAdd is not), and rounded to fp32 once.
+//       term  = fp32 product  w_corner * attn * grad_out[c]   (exactly the reference's atomicAdd
+//               operand, cuh:125-152), widened to fp64 and added with ds_add_f64;
+//   then streams the band to grad_value as float(sum) with plain coalesced 16-byte stores.  The fp64
+//   sum of fp32 terms carries 29 more bits than the reference's fp32 running sum, so the result is the
+//   correctly rounded sum for all practical purposes and independent of summation order up to 2^-53
+//   relative (the reference's float atomicAdd result depends on the order at the 2^-24 level).
 //   Every (pixel, head) of grad_value belongs to exactly one band, so the kernel OVERWRITES
-//   grad_value; a point whose two rows straddle two bands is visited by both owners, each adding only
-//   its own row.  Non-finite inputs (max key = huge) and levels whose single row does not fit the
-//   budget take the float global-atomic branch of the same loop ("direct"), so any input is handled.
+//   grad_value -- no global atomics; a point whose two rows straddle two bands is visited by both
+//   owners, each adding only its own row.  A level whose single row does not fit the budget takes the
+//   float global-atomic branch of the same loop ("direct"), so any shape is handled.
 //
 //   lane mapping: stage 1 -- one lane per candidate point (tap arithmetic once per point, band test,
 //   __ballot); stage 2 -- the hits are dealt to teams of G lanes (one team per point, RPW points per
@@ -602,17 +566,6 @@ msda_bwd_tile_kernel(const Params p)
 //   The grid is persistent (one 1024-thread workgroup per CU striding over the items) because the
 //   number of bands depends on spatial_shapes, which lives in device memory (no host sync allowed);
 //   item % M = head keeps the head -> XCD affinity of the gather kernels.
-// round(term * 2^k) as a 64-bit integer from two fp32 -> int32 conversions (no fp64, no 64-bit
-// multiply): with s = 2^(k-31), |term * s| < 2^31;  hi = rint(term * s) is exact in fp32, the remainder
-// term * s - hi is exact (|rem| <= 1/2), lo = rint(rem * 2^31);  result = hi * 2^31 + lo.
-__device__ __forceinline__ long long to_fixed(float term, float scale_hi)
-{
-    const float t = term * scale_hi;
-    const float hi = rintf(t);
-    const float lo = rintf((t - hi) * 2147483648.f);
-    return ((long long)(int)hi << 31) + (long long)(int)lo;
-}
-
 constexpr int kScatterThreads = 1024;
 constexpr int kScatterMaxLevels = 32;
 constexpr int kScatterMaxSources = 64;     // 1 + frames * window must fit
@@ -620,13 +573,13 @@ typedef unsigned long long u64;
 
 template <typename T, int G>
 __global__ void __launch_bounds__(kScatterThreads)
-msda_bwd_value_lds_kernel(const Params p, int cap_slots, int headroom_bits, int dbg)
+msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
 {
     constexpr int VEC = Store<T>::VEC;
     constexpr int RPW = kWave / G;
     constexpr int kWaves = kScatterThreads / kWave;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    u64 *band = reinterpret_cast<u64 *>(lds_raw);
+    double *band = reinterpret_cast<double *>(lds_raw);
     __shared__ int s_H[kScatterMaxLevels], s_W[kScatterMaxLevels], s_R[kScatterMaxLevels],
         s_first[kScatterMaxLevels + 1], s_lsi[kScatterMaxLevels];
     __shared__ int s_src[kScatterMaxSources], s_nsrc;
@@ -651,15 +604,6 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int headroom_bits, int 
     const int64_t n_items = (int64_t)clips * p.frames * p.M * NB;
     const int team = lane / G, sub = lane % G;
 
-    // fixed-point scale 2^k from the device-side abs-max keys (see header comment)
-    const float vmax = __uint_as_float(p.workspace[0]) * __uint_as_float(p.workspace[1]);
-    const bool finite = vmax <= 3.0e38f;           // false for NaN too
-    int e = 0;
-    (void)frexpf(fmaxf(vmax, 1e-20f), &e);          // vmax < 2^e  (floor keeps 2^(k-31) a finite float)
-    const int k = 62 - headroom_bits - e;
-    const float scale_hi = ldexpf(1.f, k - 31);     // |term| * scale_hi < 2^(31 - headroom)
-    const double inv_scale = ldexp(1.0, -k);
-
     for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int m = (int)(item % p.M);
         int64_t rest = item / p.M;
@@ -670,7 +614,7 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int headroom_bits, int 
         while (l + 1 < L && s_first[l + 1] <= part) ++l;
         const int H = s_H[l], W = s_W[l], R = s_R[l];
         const bool whole_level = (R == 0);
-        const bool direct = whole_level || !finite;
+        const bool direct = whole_level;
         const int r0 = whole_level ? 0 : (part - s_first[l]) * R;
         const int r1 = whole_level ? H - 1 : min(H, r0 + R) - 1;
         const int band_slots = direct ? 0 : (r1 - r0 + 1) * W * D;
@@ -723,15 +667,80 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int headroom_bits, int 
                 qrow = (int)gq;
             }
         };
-        // NC candidates per lane per pass: a band catches only ~1/7 of its level's points, so one
-        // candidate per lane gives ~10 hits per wave -- two stage-2 iterations at ~60 % team use.
-        // With 4 candidates per lane the hits are merged into dense rounds (~90 % use).
-        constexpr int NC = 4;
+        // NC candidates per lane per pass: a band catches only ~1/7 of its level's points, so the hits
+        // of NC candidates per lane are merged into dense rounds before they are dealt to teams.
+        constexpr int NC = 2;
         constexpr int kPass = kScatterThreads * NC;
         float cx[NC], cy[NC], ca[NC];
         int cq[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) fetch(c * kScatterThreads + tid, cx[c], cy[c], ca[c], cq[c]);
+
+        // Stage 2 is software-pipelined over "hit groups" (RPW hits, one team of G lanes each): prep()
+        // finds the team's hit, fetches its tap record from the finder lane (ds_bpermute) and ISSUES the
+        // grad_out loads; the conversions + LDS adds of a group run only after the NEXT group's prep, so
+        // the load latency (one 1024-thread workgroup per CU = only 4 waves per SIMD to hide it) overlaps
+        // useful work.  Measured per clip: LDS adds 12 us, conversion VALU 44 us, exposed latency 58 us.
+        struct Hit { int pix, bits; float w0, w1, w2, w3; float g[VEC]; };
+        Hit pend;
+        pend.bits = 0;
+        auto prep = [&](u64 mk, int pix00, int bits, int qrow, float wa0, float wa1, float wa2, float wa3) {
+            Hit h;
+            u64 mm = mk;
+#pragma unroll
+            for (int j = 0; j < RPW - 1; ++j)
+                if (j < team) mm &= mm - 1;
+            const bool has = mm != 0;
+            const int from = has ? __builtin_ctzll(mm) : 0;
+            h.pix = __shfl(pix00, from, kWave);
+            const int b_all = __shfl(bits, from, kWave);
+            h.bits = has ? b_all : 0;
+            const int h_q = __shfl(qrow, from, kWave);
+            h.w0 = __shfl(wa0, from, kWave); h.w1 = __shfl(wa1, from, kWave);
+            h.w2 = __shfl(wa2, from, kWave); h.w3 = __shfl(wa3, from, kWave);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) h.g[c] = 0.f;
+            if (h.bits) {
+                const T *go = static_cast<const T *>(p.grad_out) + (int64_t)h_q * MD + m * D;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) h.g[c] = Store<T>::get(go + ((c + team) % VEC) * G + sub);
+            }
+            return h;
+        };
+        auto consume = [&](const Hit &h) {
+            if (!h.bits) return;
+            if (direct) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    float *dst = gmap + (int64_t)h.pix * MD + ((c + team) % VEC) * G + sub;
+                    if (h.bits & 1) atomic_accumulate(dst, h.w0 * h.g[c]);
+                    if (h.bits & 2) atomic_accumulate(dst + MD, h.w1 * h.g[c]);
+                    if (h.bits & 4) atomic_accumulate(dst + (int64_t)W * MD, h.w2 * h.g[c]);
+                    if (h.bits & 8) atomic_accumulate(dst + (int64_t)(W + 1) * MD, h.w3 * h.g[c]);
+                }
+                return;
+            }
+            // Branch-free: a corner this band does not own (or outside the map) adds 0 at the address
+            // of a corner it does own -- 4*VEC independent ds_add_f64 per lane, no exec-mask juggling.
+            // Terms are the fp32 products the reference hands to atomicAdd (cuh:125-152), widened to
+            // fp64 (one v_cvt_f64_f32) and summed in fp64.
+            const int o1 = D, o2 = W * D, o3 = (W + 1) * D;
+            const int safe = (h.bits & 1) ? 0 : (h.bits & 2) ? o1 : (h.bits & 4) ? o2 : o3;
+            const int a0 = (h.bits & 1) ? 0 : safe, a1 = (h.bits & 2) ? o1 : safe;
+            const int a2 = (h.bits & 4) ? o2 : safe, a3 = (h.bits & 8) ? o3 : safe;
+            const float m0 = (h.bits & 1) ? h.w0 : 0.f, m1 = (h.bits & 2) ? h.w1 : 0.f;
+            const float m2 = (h.bits & 4) ? h.w2 : 0.f, m3 = (h.bits & 8) ? h.w3 : 0.f;
+            double *pixel = band + h.pix * D;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                double *dst = pixel + ((c + team) % VEC) * G + sub;
+                unsafeAtomicAdd(dst + a0, (double)(m0 * h.g[c]));
+                unsafeAtomicAdd(dst + a1, (double)(m1 * h.g[c]));
+                unsafeAtomicAdd(dst + a2, (double)(m2 * h.g[c]));
+                unsafeAtomicAdd(dst + a3, (double)(m3 * h.g[c]));
+            }
+        };
+
         for (int base = 0; base < total; base += kPass) {
             // ---- stage 1: tap arithmetic + band test for this lane's NC candidates
             int pixs[NC], bitss[NC], qrows[NC];
@@ -779,53 +788,16 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int headroom_bits, int 
                 }
                 u64 mask = __ballot(bits != 0);
                 if (!mask) break;
-            // ---- stage 2: RPW hits per iteration, one team of G lanes per hit (8 hits share one
-            // grad_out load latency; a one-hit-per-iteration variant with v_readlane broadcast measured
-            // 1.7x slower because every hit then exposes that latency).  Lane i of team k adds channel
-            // ((c + k) % VEC) * G + i at step c, so the teams of one half-wave hit disjoint LDS banks.
-            while (mask) {
-                u64 mm = mask;
+                while (mask) {
+                    const Hit h = prep(mask, pix00, bits, qrow, wa0, wa1, wa2, wa3);
 #pragma unroll
-                for (int j = 0; j < RPW - 1; ++j)
-                    if (j < team) mm &= mm - 1;
-                const bool has = mm != 0;
-                const int from = has ? __builtin_ctzll(mm) : 0;
-                const int h_pix = __shfl(pix00, from, kWave);
-                const int b_all = __shfl(bits, from, kWave);
-                const int h_bits = has ? b_all : 0;
-                const int h_q = __shfl(qrow, from, kWave);
-                const float h_w0 = __shfl(wa0, from, kWave), h_w1 = __shfl(wa1, from, kWave);
-                const float h_w2 = __shfl(wa2, from, kWave), h_w3 = __shfl(wa3, from, kWave);
-                if (h_bits) {
-                    const T *go = static_cast<const T *>(p.grad_out) + (int64_t)h_q * MD + m * D;
-                    float gc[VEC];
-#pragma unroll
-                    for (int c = 0; c < VEC; ++c)       // all channel loads in flight before the adds
-                        gc[c] = Store<T>::get(go + ((c + team) % VEC) * G + sub);
-#pragma unroll
-                    for (int c = 0; c < VEC; ++c) {
-                        const int ch = ((c + team) % VEC) * G + sub;
-                        // fp32 products = the reference's atomicAdd operands (cuh:125-152)
-                        if (direct) {
-                            float *dst = gmap + (int64_t)h_pix * MD + ch;
-                            if (h_bits & 1) atomic_accumulate(dst, h_w0 * gc[c]);
-                            if (h_bits & 2) atomic_accumulate(dst + MD, h_w1 * gc[c]);
-                            if (h_bits & 4) atomic_accumulate(dst + (int64_t)W * MD, h_w2 * gc[c]);
-                            if (h_bits & 8) atomic_accumulate(dst + (int64_t)(W + 1) * MD, h_w3 * gc[c]);
-                        } else if (!(dbg & 1)) {
-                            u64 *dst = band + h_pix * D + ch;
-                            if (h_bits & 1) atomicAdd(dst, (u64)to_fixed(h_w0 * gc[c], scale_hi));
-                            if (h_bits & 2) atomicAdd(dst + D, (u64)to_fixed(h_w1 * gc[c], scale_hi));
-                            if (h_bits & 4) atomicAdd(dst + W * D, (u64)to_fixed(h_w2 * gc[c], scale_hi));
-                            if (h_bits & 8) atomicAdd(dst + (W + 1) * D, (u64)to_fixed(h_w3 * gc[c], scale_hi));
-                        }
-                    }
+                    for (int j = 0; j < RPW; ++j) mask &= mask - 1;
+                    consume(pend);
+                    pend = h;
                 }
-#pragma unroll
-                for (int j = 0; j < RPW; ++j) mask &= mask - 1;
-            }
             }
         }
+        consume(pend);
         __syncthreads();
         // ---- flush the band: fixed point -> fp32, plain coalesced stores (D floats per pixel at stride M*D)
         const int vec_per_pix = D / 4;
@@ -833,12 +805,12 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int headroom_bits, int 
         float *gband = gmap + (int64_t)r0 * W * MD;
         for (int i = tid; i < n_vec; i += kScatterThreads) {
             const int pix = i / vec_per_pix, c4 = i - pix * vec_per_pix;
-            const long long *src = reinterpret_cast<const long long *>(band) + i * 4;
+            const double *src = band + i * 4;
             float4 v;
-            v.x = (float)((double)src[0] * inv_scale);
-            v.y = (float)((double)src[1] * inv_scale);
-            v.z = (float)((double)src[2] * inv_scale);
-            v.w = (float)((double)src[3] * inv_scale);
+            v.x = (float)src[0];
+            v.y = (float)src[1];
+            v.z = (float)src[2];
+            v.w = (float)src[3];
             *reinterpret_cast<float4 *>(gband + (int64_t)pix * MD + c4 * 4) = v;
         }
         __syncthreads();
@@ -1023,7 +995,7 @@ bool scatter_applicable(const Params &p)
 {
     const char *mode = getenv("MSDA_BWD_MODE");
     if (mode && !strcmp(mode, "atomic")) return false;
-    if (p.L > kScatterMaxLevels || (p.D % 4) != 0 || !p.workspace) return false;
+    if (p.L > kScatterMaxLevels || (p.D % 4) != 0) return false;
     if (1 + p.frames * p.window > kScatterMaxSources) return false;
     if (p.window == 0 && p.LA != p.L) return false;
     return true;
@@ -1066,10 +1038,6 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     const int per_cu = env_int("MSDA_SCATTER_WG_PER_CU", 1);
     unsigned grid = (unsigned)(device_cus() * per_cu);
     grid -= grid % 8;                                   // multiple of the XCD count: item % M stays put
-    // headroom: an accumulator can receive at most one term per sampling point that reads its map
-    const int64_t max_terms = (int64_t)(1 + (int64_t)p.frames * p.window) * p.Lq * (p.PA > p.PB ? p.PA : p.PB);
-    int headroom_bits = 1;
-    while (((int64_t)1 << headroom_bits) < max_terms && headroom_bits < 40) ++headroom_bits;
     static int lds_limit_set = 0;      // per instantiation; dynamic LDS above 64 KiB must be opted into
     if (cap_bytes > lds_limit_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_value_lds_kernel<T, G>),
@@ -1078,7 +1046,7 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
         lds_limit_set = cap_bytes;
     }
     hipLaunchKernelGGL((msda_bwd_value_lds_kernel<T, G>), dim3(grid), dim3(kScatterThreads),
-                       (size_t)cap_bytes, stream, p, cap_bytes / 8, headroom_bits, env_int("MSDA_SCATTER_DBG", 0));
+                       (size_t)cap_bytes, stream, p, cap_bytes / 8, env_int("MSDA_SCATTER_DBG", 0));
     return check_launch("msda backward (LDS scatter kernel)");
 }
 

@@ -49,6 +49,13 @@ __global__ void __launch_bounds__(kThreads) k(float *out, int iters)
         } else if (MODE == 7) {     // ds_add_f32 all lanes same bank-row linear (lane -> consecutive floats)
 #pragma unroll
             for (int c = 0; c < 4; ++c) atomicAdd(band + ((pix * 4 + c) * 64 + lane) % (kPix * 32), v);
+        } else if (MODE == 9) {     // ds_add_f64 (double atomics)
+            double *b = reinterpret_cast<double *>(band);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) unsafeAtomicAdd(b + (pix >> 1) * 32 + ((c + team) & 3) * 8 + sub, (double)v);
+        } else if (MODE == 10) {    // ds_max_f32 / ds_min style float op for reference
+#pragma unroll
+            for (int c = 0; c < 4; ++c) atomicMax(reinterpret_cast<int *>(band) + pix * 32 + ((c + team) & 3) * 8 + sub, (int)(s & 255));
         } else if (MODE == 8) {     // half2 packed atomics (ds_pk_add_f16)
             __half2 *b = reinterpret_cast<__half2 *>(band);
 #pragma unroll
@@ -90,6 +97,8 @@ int main()
     run<1>("ds_add_u32 rotated octets", 4);
     run<2>("ds_add_u64 rotated octets", 4);
     run<8>("ds_pk_add_f16", 2);
+    run<9>("ds_add_f64", 4);
+    run<10>("ds_max_i32", 4);
     run<3>("RMW float4 (non-atomic)", 1);
     run<4>("RMW 4 x b32 (non-atomic)", 4);
     run<5>("read float4", 1);
