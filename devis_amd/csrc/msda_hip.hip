@@ -686,12 +686,17 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
         pend.bits = 0;
         auto prep = [&](u64 mk, int pix00, int bits, int qrow, float wa0, float wa1, float wa2, float wa3) {
             Hit h;
+            // the j-th set bit of the (wave-uniform) mask goes to team j: found with scalar
+            // s_ff1/s_bitset0, one v_cndmask per team instead of a per-lane 64-bit loop
+            int from = 0;
+            bool has = false;
             u64 mm = mk;
 #pragma unroll
-            for (int j = 0; j < RPW - 1; ++j)
-                if (j < team) mm &= mm - 1;
-            const bool has = mm != 0;
-            const int from = has ? __builtin_ctzll(mm) : 0;
+            for (int j = 0; j < RPW; ++j) {
+                const int sj = mm ? (int)__builtin_ctzll(mm) : -1;
+                if (team == j) { from = sj < 0 ? 0 : sj; has = sj >= 0; }
+                mm &= mm - 1;
+            }
             h.pix = __shfl(pix00, from, kWave);
             const int b_all = __shfl(bits, from, kWave);
             h.bits = has ? b_all : 0;
@@ -728,8 +733,7 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
             const int safe = (h.bits & 1) ? 0 : (h.bits & 2) ? o1 : (h.bits & 4) ? o2 : o3;
             const int a0 = (h.bits & 1) ? 0 : safe, a1 = (h.bits & 2) ? o1 : safe;
             const int a2 = (h.bits & 4) ? o2 : safe, a3 = (h.bits & 8) ? o3 : safe;
-            const float m0 = (h.bits & 1) ? h.w0 : 0.f, m1 = (h.bits & 2) ? h.w1 : 0.f;
-            const float m2 = (h.bits & 4) ? h.w2 : 0.f, m3 = (h.bits & 8) ? h.w3 : 0.f;
+            const float m0 = h.w0, m1 = h.w1, m2 = h.w2, m3 = h.w3;      // already 0 for unowned corners
             double *pixel = band + h.pix * D;
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
@@ -762,7 +766,9 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
                     const bool x0 = w_low >= 0, x1 = w_low + 1 <= W - 1;
                     bitss[c] = (top && x0 ? 1 : 0) | (top && x1 ? 2 : 0) | (bot && x0 ? 4 : 0) | (bot && x1 ? 8 : 0);
                     const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-                    was[c][0] = hh * hw * a; was[c][1] = hh * lw * a; was[c][2] = lh * hw * a; was[c][3] = lh * lw * a;
+                    // weights of corners this band does not own are zeroed here, once per point
+                    was[c][0] = (top && x0) ? hh * hw * a : 0.f; was[c][1] = (top && x1) ? hh * lw * a : 0.f;
+                    was[c][2] = (bot && x0) ? lh * hw * a : 0.f; was[c][3] = (bot && x1) ? lh * lw * a : 0.f;
                     pixs[c] = (h_low - r0) * W + w_low;       // may be "virtual" for unowned corners
                 }
             }
