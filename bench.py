@@ -201,9 +201,11 @@ def main():
             dv[0], b["shapes"], b["lsi"], b["ftab"], dv[1], dv[2], dv[3], dv[4], args.clips, out), 20)
         # the backward entry point launches two kernels; MSDA_BWD_PHASES lets each be timed alone
         ws = _native.bwd_workspace(device)
-        bwd = lambda: _native.temporal_backward(
-            dv[0], b["shapes"], b["lsi"], b["ftab"], dv[1], dv[2], dv[3], dv[4], b["grad_out"], args.clips,
-            gv, gl_c, ga_c, gl_t, ga_t, workspace=ws)
+        def bwd():
+            ws.zero_()      # the scatter pass takes its work tickets from the zeroed workspace
+            _native.temporal_backward(
+                dv[0], b["shapes"], b["lsi"], b["ftab"], dv[1], dv[2], dv[3], dv[4], b["grad_out"], args.clips,
+                gv, gl_c, ga_c, gl_t, ga_t, workspace=ws)
         os.environ["MSDA_BWD_PHASES"] = "1"
         gat_ms, gat_med = time_kernel(bwd, 20)
         os.environ["MSDA_BWD_PHASES"] = "2"

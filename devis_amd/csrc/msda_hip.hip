@@ -136,7 +136,7 @@ struct Params {
     const void *grad_out;       // bwd
     void *grad_value;           // bwd: acc type, pre-zeroed
     void *glocA, *gawA, *glocB, *gawB;
-    unsigned *workspace;        // bwd: reserved scratch (unused since grad_value accumulates in fp64)
+    unsigned *workspace;        // bwd: 8 work-ticket counters of the scatter pass (zeroed by the caller) or null
     int groups, frames, window;
     int S, M, D, L, Lq;
     int LA, PA, LB, PB;
@@ -604,14 +604,51 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
     const int64_t n_items = (int64_t)clips * p.frames * p.M * NB;
     const int team = lane / G, sub = lane % G;
 
-    for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int m = (int)(item % p.M);
-        int64_t rest = item / p.M;
-        const int part = (int)(rest % NB); rest /= NB;
-        const int f = (int)(rest % p.frames);
-        const int clip = (int)(rest / p.frames);
-        int l = 0;
-        while (l + 1 < L && s_first[l + 1] <= part) ++l;
+    // Item order: heaviest first.  A band of a small level catches a larger share of its level's points
+    // (a 1-band level catches all of them), so parts are walked from the last level down; with few
+    // clips the items are also handed out DYNAMICALLY -- one atomic ticket counter per XCD residue
+    // (blockIdx % 8) in the caller-zeroed workspace -- because their costs differ by ~7x and a static
+    // stride leaves most CUs idle behind the unlucky ones (encoder shape, 1 clip: 2.85 -> see DESIGN).
+    __shared__ long long s_item;
+    // plenty of items per workgroup: a static stride balances well enough and skips the ticket traffic
+    const bool dynamic = p.workspace != nullptr && (dbg & 16) == 0 && n_items < (int64_t)16 * gridDim.x;
+    const int lane8 = blockIdx.x % 8;
+    for (int64_t it = blockIdx.x;; it += gridDim.x) {
+        int64_t item = it;
+        if (dynamic) {
+            if (tid == 0) s_item = (long long)atomicAdd(p.workspace + lane8, 1u) * 8 + lane8;
+            __syncthreads();
+            item = s_item;
+        }
+        if (item >= n_items) break;
+        int l, part, m, f, clip;
+        if (dynamic) {
+            // heaviest first: levels from the last to the first; inside a level the bands of one
+            // (clip, frame) stay adjacent
+            const int64_t ctm = (int64_t)clips * p.frames * p.M;
+            l = L - 1;
+            int64_t local = item;
+            while (l > 0 && local >= ctm * (s_first[l + 1] - s_first[l])) {
+                local -= ctm * (s_first[l + 1] - s_first[l]);
+                --l;
+            }
+            const int nb_l = s_first[l + 1] - s_first[l];
+            m = (int)(local % p.M);
+            int64_t rest = local / p.M;
+            part = s_first[l] + (int)(rest % nb_l); rest /= nb_l;
+            f = (int)(rest % p.frames);
+            clip = (int)(rest / p.frames);
+        } else {
+            // static stride: all parts of one (clip, frame) adjacent -- one 128-byte loc line holds the
+            // points of all levels, so concurrently running workgroups share their scan traffic in L2
+            m = (int)(item % p.M);
+            int64_t rest = item / p.M;
+            part = (int)(rest % NB); rest /= NB;
+            f = (int)(rest % p.frames);
+            clip = (int)(rest / p.frames);
+            l = 0;
+            while (l + 1 < L && s_first[l + 1] <= part) ++l;
+        }
         const int H = s_H[l], W = s_W[l], R = s_R[l];
         const bool whole_level = (R == 0);
         const bool direct = whole_level;

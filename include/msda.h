@@ -86,8 +86,8 @@ int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,
  *   grad_sampling_loc [N, Lq, M, L, P, 2]  dtype, fully overwritten (skipped points get 0)
  *   grad_attn_weight  [N, Lq, M, L, P]     dtype, fully overwritten
  *   workspace         MSDA_BWD_WORKSPACE_BYTES of device scratch, zero-filled by the caller, private to
- *                     this call until it completes.  Reserved for the backward's two-kernel pipeline
- *                     (currently unused: grad_value is accumulated in fp64 in LDS); NULL is allowed.
+ *                     this call until it completes: the scatter pass keeps its work-ticket counters there
+ *                     (dynamic scheduling).  NULL is allowed (static scheduling, slower for few clips).
  */
 int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
                   const int64_t *level_start_index, const void *sampling_loc,
