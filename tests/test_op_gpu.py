@@ -243,3 +243,91 @@ def test_full_size_properties_cfg3():
     lhs = (out.double() * t["grad_out"].double()).sum().item()
     rhs = (v.double() * gv.double()).sum().item()
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+
+# ---------------------------------------------------------------------------------------------
+# alternate backward routes (not the default dispatch) and larger BASELINE shapes
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("env", [{"MSDA_BWD_MODE": "atomic"},            # one-kernel backward, global float atomics
+                                 {"MSDA_SCATTER_LDS_KB": "1"},           # no level row fits LDS -> "direct" branch
+                                 {"MSDA_SCATTER_LDS_KB": "8"},           # many thin bands, straddling points
+                                 {"MSDA_SCATTER_WG_PER_CU": "3"}])
+def test_backward_alternate_routes(env, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g, d = _golden_dict("op_devis_small")
+    out, gv, gl, ga = _run_op(d, torch.float32)
+    assert _maxabs(gv, g["grad_value"]) <= 2e-5 * max(1.0, np.abs(g["grad_value"]).max())
+    assert _maxabs(gl, g["grad_sampling_loc"]) <= 2e-5 * max(1.0, np.abs(g["grad_sampling_loc"]).max())
+    assert _maxabs(ga, g["grad_attn_weight"]) <= 2e-5 * max(1.0, np.abs(g["grad_attn_weight"]).max())
+    dt = make_temporal_inputs(41, T=4, W=3, M=8, D=32, Lq=23, shapes=[(9, 7), (5, 4)], Pc=4, Pt=2)
+    ref = temporal_reference(*(np.asarray(dt[k], dtype=np.float64) if dt[k].dtype.kind == "f" else dt[k]
+                               for k in ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")))
+    got = _run_temporal(dt, torch.float32)
+    for a, b in zip(got, ref):
+        assert _maxabs(a, b) <= 2e-5 * max(1.0, np.abs(b).max())
+
+
+def test_backward_without_workspace_static_schedule():
+    """The C ABI allows workspace = NULL (static item stride)."""
+    from devis_amd import _native
+    g, d = _golden_dict("op_devis_small")
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in d.items()}
+    gv = torch.zeros(t["value"].shape, device=DEV)
+    gl, ga = torch.empty_like(t["loc"]), torch.empty_like(t["aw"])
+    N, S, M, D = t["value"].shape
+    _, Lq, _, L, P, _ = t["loc"].shape
+    lib = _native.load()
+    rc = lib.msda_backward(0, t["value"].data_ptr(), t["shapes"].data_ptr(), t["lsi"].data_ptr(), t["loc"].data_ptr(),
+                           t["aw"].data_ptr(), t["grad_out"].float().contiguous().data_ptr(), N, S, M, D, L, Lq, P,
+                           gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), None,
+                           torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert _maxabs(gv.double().cpu().numpy(), g["grad_value"]) <= 2e-5 * max(1.0, np.abs(g["grad_value"]).max())
+
+
+def test_many_levels_falls_back_to_atomic_kernel():
+    """L > 32 levels: the LDS scatter declines, the one-kernel backward takes over."""
+    shapes = [(3, 2), (2, 2)] * 20          # 40 levels
+    d = make_inputs(55, 1, 4, 16, 9, shapes, 2, "wide", np.float32)
+    ref = oracle_fwd_bwd(d, np.float32)
+    got = _run_op(d, torch.float32)
+    assert _maxabs(got[0], ref[0]) <= 1e-6
+    for a, b in zip(got[1:], ref[1:]):
+        assert _maxabs(a, b) <= 2e-5 * max(1.0, np.abs(b).max())
+
+
+def test_full_size_cfg2_encoder_bf16_properties():
+    """BASELINE configs[1]: single-frame Deformable-DETR encoder attention on the 800x1333 pyramid,
+    Lq = S = 22223, M=8, K=4, C=256, bf16 -- checked through size-independent properties plus an
+    oracle comparison on a random subset of query rows."""
+    from devis_amd.functions import MSDeformAttnFunction
+    from helpers import PYR_B
+    from oracle import msda_oracle as O
+    shapes_np = np.asarray(PYR_B, dtype=np.int64)
+    S = int((shapes_np[:, 0] * shapes_np[:, 1]).sum())
+    g = torch.Generator().manual_seed(9)
+    value = (torch.rand(1, S, 8, 32, generator=g) * 2 - 1).to(torch.bfloat16)
+    loc = (torch.rand(1, S, 8, 4, 4, 2, generator=g) * 1.2 - 0.1).to(torch.bfloat16)
+    aw = torch.softmax(torch.randn(1, S, 8, 16, generator=g), -1).view(1, S, 8, 4, 4).to(torch.bfloat16)
+    go = torch.randn(1, S, 256, generator=g).to(torch.bfloat16)
+    shapes = torch.from_numpy(shapes_np).to(DEV)
+    lsi = torch.from_numpy(O.level_start_index(shapes_np)).to(DEV)
+    v, l, a = (x.to(DEV).requires_grad_(True) for x in (value, loc, aw))
+    out = MSDeformAttnFunction.apply(v, shapes, lsi, l, a, 64)
+    gv, gl, ga = torch.autograd.grad(out, (v, l, a), go.to(DEV))
+    torch.cuda.synchronize()
+    # oracle on 64 random query rows (forward + grad_loc/grad_attn are row-local)
+    rows = torch.randperm(S, generator=g)[:64]
+    sub = lambda x: x[:, rows].double().numpy()
+    o_ref = O.forward(value.double().numpy(), shapes_np, O.level_start_index(shapes_np), sub(loc), sub(aw))
+    assert _maxabs(out[:, rows].detach().double().cpu().numpy(), o_ref) <= 1e-2
+    _, gl_ref, ga_ref = O.backward(value.double().numpy(), shapes_np, O.level_start_index(shapes_np), sub(loc), sub(aw),
+                                   go[:, rows].double().numpy())
+    assert _maxabs(ga[:, rows].double().cpu().numpy(), ga_ref) <= 2e-2 * max(1.0, np.abs(ga_ref).max())
+    assert _maxabs(gl[:, rows].double().cpu().numpy(), gl_ref) <= 2e-2 * max(1.0, np.abs(gl_ref).max())
+    # adjointness ties grad_value to the forward:  <out(value), g> == <value, grad_value(g)>
+    lhs = (out.detach().double() * go.to(DEV).double()).sum().item()
+    rhs = (v.detach().double() * gv.double()).sum().item()
+    assert abs(lhs - rhs) <= 2e-2 * max(1.0, abs(lhs))
