@@ -55,6 +55,10 @@ def parse_args():
     ap.add_argument("--locs", choices=["uniform", "clustered"], default="uniform",
                     help="uniform: rand in [0,1) as the reference test.py; clustered: reference point + "
                          "N(0, (3 px)^2) offsets per level, as a trained decoder produces")
+    ap.add_argument("--mode", choices=["clip-parallel", "sharded"], default="clip-parallel",
+                    help="clip-parallel: independent clips per GPU, no collective (default, weak scaling); "
+                         "sharded: every clip is split over ALL ranks (devis_amd/clip_parallel.py: RCCL all-gather "
+                         "of value forward, reduce-scatter of grad_value backward; strong scaling)")
     ap.add_argument("--pattern", choices=["fused", "reference"], default="fused",
                     help="fused: one launch per direction; reference: the 2*T calls per layer of the reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,6 +124,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)   # RCCL on ROCm
+    elif args.mode == "sharded":                            # single process: degenerate collectives
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
 
     from devis_amd.functions import MSDeformAttnFunction, MSDeformAttnTemporalFunction
     dtype = DTYPES[args.dtype]
@@ -150,6 +159,30 @@ def main():
         out = forward()
         torch.autograd.grad(out, leaves, b["grad_out"])
 
+    if args.mode == "sharded":
+        # Mode 2: the SAME `clips` clips on every rank (seed without rank), each split over the ranks:
+        # value rows chunked over the flattened T*S axis, queries chunked per frame.
+        from devis_amd import clip_parallel as cp
+        b = make_clip_batch(args, device, dtype, seed=1234)
+        rows = T * S
+        chunk = cp.padded_chunk(rows, world)
+        q0, q1 = cp.shard_range(q, world, rank)
+        shard = []
+        for c in range(args.clips):
+            flat = b["value"][c * T:(c + 1) * T].reshape(rows, M, D)
+            pad = torch.zeros((chunk * world, M, D), dtype=dtype, device=device)
+            pad[:rows] = flat
+            cut = lambda k: b[k][c * T:(c + 1) * T, q0:q1].contiguous().requires_grad_(True)
+            shard.append(dict(v=pad[rank * chunk:(rank + 1) * chunk].clone().requires_grad_(True),
+                              lc=cut("loc_c"), ac=cut("aw_c"), lt=cut("loc_t"), at=cut("aw_t"),
+                              go=b["grad_out"][c * T:(c + 1) * T, q0:q1].contiguous()))
+
+        def step():  # noqa: F811
+            for sh in shard:
+                out = cp.sharded_temporal_attention(sh["v"], T, S, b["shapes"], b["lsi"], b["ftab"], sh["lc"],
+                                                    sh["ac"], sh["lt"], sh["at"])
+                torch.autograd.grad(out, (sh["v"], sh["lc"], sh["ac"], sh["lt"], sh["at"]), sh["go"])
+
     def barrier():
         if world > 1:
             import torch.distributed as dist
@@ -170,12 +203,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     ms_per_step = elapsed / args.steps * 1e3
-    rows_per_step = world * args.clips * T * q
+    rows_per_step = (1 if args.mode == "sharded" else world) * args.clips * T * q
     value = rows_per_step / (ms_per_step * 1e-3) / 1e6
 
     # ---- per-kernel durations with HIP events on the launch stream (fused pattern only) ----------
     roofline, extra = None, {}
-    if rank == 0 and args.pattern == "fused":
+    if rank == 0 and args.pattern == "fused" and args.mode == "clip-parallel":
         from devis_amd import _native
         stream = torch.cuda.current_stream()
         out = torch.empty((args.clips * T, q, M * D), dtype=dtype, device=device)
@@ -266,19 +299,21 @@ def main():
         line = {
             "metric": "MSDeformAttn fwd+bwd M-queries/s at T=6,L=4,K=4,C=256", "value": round(value, 3),
             "unit": "M-queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong" if args.mode == "sharded" else "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "cfg3 DeVIS decoder temporal MSDeformAttn, one layer fwd+bwd: T=%d frames, "
                                    "%d queries/frame, L=4, K=4, C=256 (M=8xD=32), pyramid %s (S=%d), %d clips/GPU/step, "
                                    "%s call pattern, %s sampling locations"
                                    % (T, q, args.pyramid, S, args.clips, args.pattern, args.locs),
                        "clips_per_gpu": args.clips, "query_rows_per_step": rows_per_step,
-                       "parallelism": "clip-parallel x%d (no data-path collective)" % world},
+                       "parallelism": ("clip-parallel x%d (no data-path collective)" % world) if args.mode == "clip-parallel"
+                       else "one clip sharded x%d (all-gather value / reduce-scatter grad_value over RCCL)" % world},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extra)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.mode == "sharded":
         import torch.distributed as dist
         dist.destroy_process_group()
 
