@@ -219,6 +219,7 @@ __device__ __forceinline__ void tile_coords(const Params &p, int &m, int &group,
     // head = blockIdx % M -> XCD affinity (see file header); tiles of one group are consecutive
     m = blockIdx.x % p.M;
     const int tile = blockIdx.x / p.M;
+    if (p.dbg & 32) m = (m + tile) % p.M;      // measurement: break the head <-> XCD affinity
     const int tiles_per_group = (p.Lq + RPW - 1) / RPW;
     group = tile / tiles_per_group;
     q0 = (tile - group * tiles_per_group) * RPW;
