@@ -251,13 +251,15 @@ __device__ __forceinline__ int n_chunks(int levels, int points) { return (levels
 // (x, y, weight) of the points this lane stages for one chunk: RPW*kPch/64 points per lane, all loads
 // issued before any tap arithmetic.
 template <int NPL> struct Staged { float x[NPL], y[NPL], a[NPL]; };
+// points a lane stages per chunk (wide rows, G >= 32, leave some lanes without a point)
+template <int RPW> constexpr int staged_per_lane() { return (RPW * kPch + kWave - 1) / kWave; }
 
 template <typename T, int RPW>
 __device__ __forceinline__ void load_chunk(const Params &p, const ChunkRef<T> &c, int64_t row0,
-                                           int rows_valid, int lane, Staged<RPW * kPch / kWave> &st)
+                                           int rows_valid, int lane, Staged<staged_per_lane<RPW>()> &st)
 {
 #pragma unroll
-    for (int k = 0; k < RPW * kPch / kWave; ++k) {
+    for (int k = 0; k < staged_per_lane<RPW>(); ++k) {
         const int i = lane + k * kWave;
         const int rr = i / kPch, pt = c.p0 + i % kPch;
         st.x[k] = st.y[k] = -10.f;      // far outside every map: yields an all-zero tap record
@@ -274,13 +276,14 @@ __device__ __forceinline__ void load_chunk(const Params &p, const ChunkRef<T> &c
 // Builds the tap records of one chunk (<= kPch points of every row of the wave) in LDS.
 template <typename T, int RPW, bool BWD>
 __device__ __forceinline__ void build_chunk(const Params &p, const ChunkRef<T> &c,
-                                            const Staged<RPW * kPch / kWave> &st, const Level *s_lvl,
+                                            const Staged<staged_per_lane<RPW>()> &st, const Level *s_lvl,
                                             int4 *s_off, float4 *s_w, float4 *s_e, int lane)
 {
     const int MD = p.M * p.D;
 #pragma unroll
-    for (int k = 0; k < RPW * kPch / kWave; ++k) {
+    for (int k = 0; k < staged_per_lane<RPW>(); ++k) {
         const int i = lane + k * kWave;
+        if (i >= RPW * kPch) break;
         const int rr = i / kPch, pp = i % kPch;
         const int vl = c.vl_base + min(c.p0 + pp, c.LP - 1) / c.P;
         const float a = st.a[k];
@@ -332,7 +335,7 @@ msda_fwd_tile_kernel(const Params p)
     // No cross-chunk prefetch on purpose: vector-memory loads return in order, so an HBM-latency load of
     // the next chunk's (x, y, weight) issued ahead of the gathers only makes every gather wait for it
     // (measured: 0.73 -> 0.82 ms); the other waves of the SIMD cover the stage phase instead.
-    Staged<RPW * kPch / kWave> st;
+    Staged<staged_per_lane<RPW>()> st;
 #pragma unroll 1
     for (int ci = 0; ci < n_all; ++ci) {
         const ChunkRef<T> c = get_chunk<T>(p, ci, nA);
@@ -436,7 +439,7 @@ msda_bwd_tile_kernel(const Params p)
     for (int c = 0; c < VEC; ++c) g[c] = 0.f;
     if (r < rows_valid) Store<T>::load(static_cast<const T *>(p.grad_out) + row * p.D + sub * VEC, g);
     const int nA = n_chunks(p.LA, p.PA), n_all = nA + n_chunks(p.LB, p.PB);
-    Staged<RPW * kPch / kWave> st;
+    Staged<staged_per_lane<RPW>()> st;
 #pragma unroll 1
     for (int ci = 0; ci < n_all; ++ci) {
         {

@@ -1,0 +1,57 @@
+"""Randomised GPU parity sweep: op and fused temporal op against the CPU oracle over shapes that hit every
+template variant (lanes per row G = 1..64 for fp32, 16-bit storage, heads not a multiple of 8, 1..8 points,
+1..6 levels, odd query counts, windows with repeated frames)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_inputs, make_temporal_inputs, oracle_fwd_bwd, round_to, temporal_reference
+from test_op_gpu import _maxabs, _run_op, _run_temporal
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_shapes(rng, L):
+    return [(int(rng.integers(1, 14)), int(rng.integers(1, 17))) for _ in range(L)]
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_op_random_config_fp32(seed):
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.choice([4, 8, 12, 16, 20, 32, 64, 128, 256, 6]))
+    M = int(rng.choice([1, 2, 3, 5, 8, 16]))
+    L, P = int(rng.integers(1, 7)), int(rng.integers(1, 9))
+    N, Lq = int(rng.integers(1, 4)), int(rng.integers(1, 70))
+    d = make_inputs(seed, N, M, D, Lq, _rand_shapes(rng, L), P, "wide", np.float32, value_scale=1.0)
+    ref = oracle_fwd_bwd(d, np.float32)        # same fp32 cell decisions as the kernel
+    ref64 = oracle_fwd_bwd(d, np.float64)
+    got = _run_op(d, torch.float32)
+    cfg = dict(D=D, M=M, L=L, P=P, N=N, Lq=Lq)
+    assert _maxabs(got[0], ref64[0]) <= 1e-5 * max(1.0, np.abs(ref64[0]).max()), cfg
+    for a, b in zip(got[1:], ref[1:]):
+        assert _maxabs(a, b) <= 1e-4 * max(1.0, np.abs(b).max()), cfg
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_temporal_random_config(seed):
+    rng = np.random.default_rng(2000 + seed)
+    D = int(rng.choice([8, 16, 32, 64]))
+    M = int(rng.choice([2, 4, 8]))
+    L, Pc, Pt = int(rng.integers(1, 5)), int(rng.integers(1, 6)), int(rng.integers(1, 6))
+    T = int(rng.integers(2, 6))
+    W = int(rng.integers(1, T))                                   # window < T: frames may repeat
+    ftab = rng.integers(0, T, size=(T, W)).astype(np.int32)
+    Lq = int(rng.integers(1, 50))
+    dtype = [torch.float32, torch.float32, torch.bfloat16, torch.float16][seed % 4]
+    d = make_temporal_inputs(seed, T, W, M, D, Lq, _rand_shapes(rng, L), Pc, Pt, ftab=ftab, dtype=np.float64)
+    if dtype != torch.float32:
+        d = round_to(d, dtype)
+    keys = ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")
+    ref = temporal_reference(*(np.asarray(d[k], dtype=np.float64) if d[k].dtype.kind == "f" else d[k] for k in keys))
+    got = _run_temporal(d, dtype)
+    tol = {torch.float32: 1e-4, torch.bfloat16: 3e-2, torch.float16: 6e-3}[dtype]
+    cfg = dict(D=D, M=M, L=L, Pc=Pc, Pt=Pt, T=T, W=W, Lq=Lq, dtype=str(dtype))
+    for i, (a, b) in enumerate(zip(got, ref)):
+        if dtype == torch.float32 and i in (2, 4):
+            continue    # grad_loc in fp32 vs an fp64 oracle: cell flips at pixel borders (checked in fp32 above)
+        assert _maxabs(a, b) <= tol * max(1.0, np.abs(b).max()), (cfg, i)
