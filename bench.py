@@ -233,9 +233,9 @@ def main():
         fwd_ms, fwd_med = time_kernel(lambda: _native.temporal_forward(
             dv[0], b["shapes"], b["lsi"], b["ftab"], dv[1], dv[2], dv[3], dv[4], args.clips, out), 20)
         # the backward entry point launches two kernels; MSDA_BWD_PHASES lets each be timed alone
-        ws = _native.bwd_workspace(device)
+        ws = _native.bwd_workspace(device, args.clips * T, q, M, L * (1 + W))
         def bwd():
-            ws.zero_()      # the scatter pass takes its work tickets from the zeroed workspace
+            ws[:16].zero_()     # the scatter pass takes its work tickets from the zeroed head of the workspace
             _native.temporal_backward(
                 dv[0], b["shapes"], b["lsi"], b["ftab"], dv[1], dv[2], dv[3], dv[4], b["grad_out"], args.clips,
                 gv, gl_c, ga_c, gl_t, ga_t, workspace=ws)

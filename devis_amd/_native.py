@@ -11,14 +11,14 @@ import torch
 
 from . import build as _build
 
-MSDA_ABI_VERSION = 2
+MSDA_ABI_VERSION = 3
 BWD_WORKSPACE_BYTES = 64
 _DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.float16: 3}
 
 # every symbol include/msda.h declares (tests check the library exports each of them)
 EXPORTED_SYMBOLS = (
     "msda_version", "msda_last_error", "msda_forward", "msda_backward",
-    "msda_temporal_forward", "msda_temporal_backward",
+    "msda_temporal_forward", "msda_temporal_backward", "msda_backward_workspace_bytes",
 )
 
 _lib = None
@@ -54,11 +54,13 @@ def load():
         lib.msda_forward.restype = _ci
         lib.msda_forward.argtypes = [_ci] + [_vp] * 5 + [_ci] * 7 + [_vp, _vp]
         lib.msda_backward.restype = _ci
-        lib.msda_backward.argtypes = [_ci] + [_vp] * 6 + [_ci] * 7 + [_vp] * 5
+        lib.msda_backward.argtypes = [_ci] + [_vp] * 6 + [_ci] * 7 + [_vp] * 4 + [ctypes.c_longlong, _vp]
+        lib.msda_backward_workspace_bytes.restype = ctypes.c_longlong
+        lib.msda_backward_workspace_bytes.argtypes = [_ci] * 4
         lib.msda_temporal_forward.restype = _ci
         lib.msda_temporal_forward.argtypes = [_ci] + [_vp] * 8 + [_ci] * 10 + [_vp, _vp]
         lib.msda_temporal_backward.restype = _ci
-        lib.msda_temporal_backward.argtypes = [_ci] + [_vp] * 9 + [_ci] * 10 + [_vp] * 7
+        lib.msda_temporal_backward.argtypes = [_ci] + [_vp] * 9 + [_ci] * 10 + [_vp] * 6 + [ctypes.c_longlong, _vp]
         _lib = lib
     return _lib
 
@@ -98,19 +100,23 @@ def forward(value, shapes, lsi, loc, aw, out):
     _check(rc, "msda_forward")
 
 
-def bwd_workspace(device):
-    """Zero-filled device scratch for one backward call (MSDA_BWD_WORKSPACE_BYTES in include/msda.h)."""
-    return torch.zeros(BWD_WORKSPACE_BYTES // 4, dtype=torch.int32, device=device)
+def bwd_workspace(device, batch, num_query, num_heads, virtual_levels):
+    """Device scratch for one backward call (include/msda.h): full size, first 64 bytes (the scatter
+    pass's ticket counters) zeroed; the rest is written by the gather pass before it is read."""
+    n = load().msda_backward_workspace_bytes(batch, num_query, num_heads, virtual_levels)
+    ws = torch.empty((n + 3) // 4, dtype=torch.int32, device=device)
+    ws[:BWD_WORKSPACE_BYTES // 4].zero_()
+    return ws
 
 
 def backward(value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_aw):
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = loc.shape
     with torch.cuda.device(value.device):
-        ws = bwd_workspace(value.device)
+        ws = bwd_workspace(value.device, N, Lq, M, L)
         rc = load().msda_backward(dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(aw),
                                   _p(grad_out), N, S, M, D, L, Lq, P,
-                                  _p(grad_value), _p(grad_loc), _p(grad_aw), _p(ws), _stream(value))
+                                  _p(grad_value), _p(grad_loc), _p(grad_aw), _p(ws), ws.numel() * 4, _stream(value))
     _check(rc, "msda_backward")
 
 
@@ -135,9 +141,9 @@ def temporal_backward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, grad_o
     window = ftab.shape[1] if ftab is not None else 0
     Pt = loc_t.shape[4] if window else 1
     with torch.cuda.device(value.device):
-        ws = workspace if workspace is not None else bwd_workspace(value.device)
+        ws = workspace if workspace is not None else bwd_workspace(value.device, G, Lq, M, L * (1 + window))
         rc = load().msda_temporal_backward(
             dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(ftab), _p(loc_c), _p(aw_c),
             _p(loc_t), _p(aw_t), _p(grad_out), clips, frames, window, S, M, D, L, Lq, Pc, Pt,
-            _p(grad_value), _p(gloc_c), _p(gaw_c), _p(gloc_t), _p(gaw_t), _p(ws), _stream(value))
+            _p(grad_value), _p(gloc_c), _p(gaw_c), _p(gloc_t), _p(gaw_t), _p(ws), ws.numel() * 4, _stream(value))
     _check(rc, "msda_temporal_backward")

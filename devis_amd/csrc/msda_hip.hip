@@ -137,6 +137,8 @@ struct Params {
     void *grad_value;           // bwd: acc type, pre-zeroed
     void *glocA, *gawA, *glocB, *gawB;
     unsigned *workspace;        // bwd: 8 work-ticket counters of the scatter pass (zeroed by the caller) or null
+    int *bbox;                  // bwd: [groups, M, LA+LB, Lq, 2] (min, max) top tap row per (row, virtual level), written by
+                                // the gather pass, read by the scatter pass to cull rows; or null
     int groups, frames, window;
     int S, M, D, L, Lq;
     int LA, PA, LB, PB;
@@ -171,6 +173,7 @@ struct Taps {
     float w[4];        // hh*hw, hh*lw, lh*hw, lh*lw  -- zero for corners outside the map
     float lh, lw;
     int valid;         // bit k set = corner k inside the map; 0 = point skipped
+    int hl;            // floor(h_im): top tap row (-1 .. H-1), meaningful when valid != 0
 };
 
 __device__ __forceinline__ Taps make_taps(float x, float y, const Level lv, int MD)
@@ -180,6 +183,7 @@ __device__ __forceinline__ Taps make_taps(float x, float y, const Level lv, int 
     t.w[0] = t.w[1] = t.w[2] = t.w[3] = 0.f;
     t.lh = t.lw = 0.f;
     t.valid = 0;
+    t.hl = 0;
     // rounded multiply THEN subtract (no FMA contraction): the reference evaluates
     // `loc * spatial - 0.5` with a float product (cuh:285-286), and which pixel cell a point falls
     // in must not depend on the compiler's contraction choices.
@@ -195,7 +199,7 @@ __device__ __forceinline__ Taps make_taps(float x, float y, const Level lv, int 
         const bool x0 = w_low >= 0, x1 = w_high <= lv.W - 1;
         const int r0 = (lv.start + h_low * lv.W) * MD, r1 = r0 + lv.W * MD;
         const int c0 = w_low * MD, c1 = c0 + MD;
-        t.lh = lh; t.lw = lw;
+        t.lh = lh; t.lw = lw; t.hl = h_low;
         if (y0 && x0) { t.off[0] = r0 + c0; t.w[0] = hh * hw; t.valid |= 1; }
         if (y0 && x1) { t.off[1] = r0 + c1; t.w[1] = hh * lw; t.valid |= 2; }
         if (y1 && x0) { t.off[2] = r1 + c0; t.w[2] = lh * hw; t.valid |= 4; }
@@ -277,7 +281,8 @@ __device__ __forceinline__ void load_chunk(const Params &p, const ChunkRef<T> &c
 template <typename T, int RPW, bool BWD>
 __device__ __forceinline__ void build_chunk(const Params &p, const ChunkRef<T> &c,
                                             const Staged<staged_per_lane<RPW>()> &st, const Level *s_lvl,
-                                            int4 *s_off, float4 *s_w, float4 *s_e, int lane)
+                                            int4 *s_off, float4 *s_w, float4 *s_e, int lane,
+                                            int *s_bb = nullptr, int nvl = 0)
 {
     const int MD = p.M * p.D;
 #pragma unroll
@@ -293,6 +298,10 @@ __device__ __forceinline__ void build_chunk(const Params &p, const ChunkRef<T> &
             s_w[rr * kRowSlots + pp] = make_float4(t.w[0], t.w[1], t.w[2], t.w[3]);
             // a, fractions, and (valid bits | level index << 4) for the final gradient lane
             s_e[rr * kRowSlots + pp] = make_float4(a, t.lh, t.lw, __int_as_float(t.valid | (vl << 4)));
+            if (s_bb && t.valid) {      // interval of top tap rows of this (row, level): ds_min/ds_max_i32
+                atomicMin(s_bb + (rr * nvl + vl) * 2, t.hl);
+                atomicMax(s_bb + (rr * nvl + vl) * 2 + 1, t.hl);
+            }
         } else {
             s_w[rr * kRowSlots + pp] = make_float4(t.w[0] * a, t.w[1] * a, t.w[2] * a, t.w[3] * a);
         }
@@ -422,7 +431,10 @@ msda_bwd_tile_kernel(const Params p)
     tile_coords<RPW>(p, m, group, q0);
     const int clip = group / p.frames, t = group - clip * p.frames;
     const int nvl = p.LA + p.LB;
+    int *s_bb = p.bbox ? reinterpret_cast<int *>(s_lvl + nvl) : nullptr;      // [RPW, nvl, 2]
     for (int j = lane; j < nvl; j += kWave) s_lvl[j] = make_level(p, t, j);
+    if (s_bb)
+        for (int j = lane; j < RPW * nvl; j += kWave) { s_bb[2 * j] = 0x7fffffff; s_bb[2 * j + 1] = -0x7fffffff - 1; }
     __syncthreads();
 
     const int r = lane / G, sub = lane % G;
@@ -448,7 +460,7 @@ msda_bwd_tile_kernel(const Params p)
             T *gloc = static_cast<T *>(c.arr ? p.glocB : p.glocA);
             T *gaw = static_cast<T *>(c.arr ? p.gawB : p.gawA);
             const int LP = c.LP, p0 = c.p0;
-            build_chunk<T, RPW, true>(p, c, st, s_lvl, s_off, s_w, s_e, lane);
+            build_chunk<T, RPW, true>(p, c, st, s_lvl, s_off, s_w, s_e, lane, s_bb, nvl);
             __syncthreads();
             const int np = min(kPch, LP - p0);
             const int4 *ro = s_off + r * kRowSlots;
@@ -533,6 +545,15 @@ msda_bwd_tile_kernel(const Params p)
             __syncthreads();
         }
     }
+    if (s_bb) {     // the rows' tap-row intervals; layout [group, head, level, query] (query fastest, so
+                    // that the scatter pass reads them coalesced while it walks the queries)
+        const int64_t gm = ((int64_t)group * p.M + m) * nvl;
+        for (int i = lane; i < rows_valid * nvl; i += kWave) {
+            const int vl = i / rows_valid, rr = i - vl * rows_valid;
+            *reinterpret_cast<int2 *>(p.bbox + ((gm + vl) * p.Lq + q0 + rr) * 2) =
+                make_int2(s_bb[(rr * nvl + vl) * 2], s_bb[(rr * nvl + vl) * 2 + 1]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -573,6 +594,7 @@ msda_bwd_tile_kernel(const Params p)
 constexpr int kScatterThreads = 1024;
 constexpr int kScatterMaxLevels = 32;
 constexpr int kScatterMaxSources = 64;     // 1 + frames * window must fit
+constexpr int kScatterSeg = 2048;          // (source, query) groups culled + compacted per segment
 typedef unsigned long long u64;
 
 template <typename T, int G>
@@ -586,7 +608,8 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
     double *band = reinterpret_cast<double *>(lds_raw);
     __shared__ int s_H[kScatterMaxLevels], s_W[kScatterMaxLevels], s_R[kScatterMaxLevels],
         s_first[kScatterMaxLevels + 1], s_lsi[kScatterMaxLevels];
-    __shared__ int s_src[kScatterMaxSources], s_nsrc;
+    __shared__ int s_src_t[kScatterMaxSources], s_src_vl[kScatterMaxSources], s_nsrc;    // sources of frame f
+    __shared__ int s_list[kScatterSeg], s_count;       // surviving (source, query) groups of a segment
 
     const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
     const int D = p.D, MD = p.M * p.D;
@@ -671,41 +694,54 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
         // (t, w) with frame_table[t, w] == f (list built once per item; repeats allowed)
         if (tid == 0) {
             int n = 0;
-            s_src[n++] = -1;
+            s_src_t[n] = f; s_src_vl[n] = l; ++n;                       // k = 0: current-frame points
             for (int tw = 0; tw < p.frames * p.window; ++tw)
-                if (p.ftab[tw] == f) s_src[n++] = tw;
+                if (p.ftab[tw] == f) {
+                    const int t = tw / p.window;
+                    s_src_t[n] = t; s_src_vl[n] = (tw - t * p.window) * L + l; ++n;
+                }
             s_nsrc = (dbg & 4) ? 0 : n;
         }
         __syncthreads();
         const int n_srcs = s_nsrc;
-        // flat candidate space: [Lq*PA points of the current source][Lq*PB points per temporal source]
-        const int nptsA = p.Lq * p.PA, nptsB = p.Lq * p.PB;
-        const int total = n_srcs ? nptsA + (n_srcs - 1) * nptsB : 0;
-
+        // Candidate GROUPS are (source k, query q) pairs, each with P points at this level.  They are
+        // walked in segments of kScatterSeg groups: a segment is first CULLED against the band -- the
+        // gather pass left, per (row, level), the interval of top tap rows in p.bbox; a group whose
+        // interval misses rows [r0-1, r1] cannot touch the band -- and the survivors are compacted
+        // into s_list; only they are scanned.  With local (encoder) or clustered (decoder) sampling
+        // most groups die here; without p.bbox every group survives.
+        const int n_groups = n_srcs * p.Lq;
+        const int Pmax = max(p.PA, p.window > 0 ? p.PB : p.PA);
+        const int VL = p.LA + p.LB;
+        int n_cand = 0;
+        const int pshift = (Pmax & (Pmax - 1)) == 0 ? __builtin_ctz(Pmax) : -1;     // i / Pmax as a shift
+        auto source_of = [&](int k, int &t, int &vl, int &vlg, int &P, int &LP, const T *&loc, const T *&aw) {
+            t = s_src_t[k]; vl = s_src_vl[k];
+            const bool cur = (k == 0);
+            vlg = cur ? vl : p.LA + vl;
+            P = cur ? p.PA : p.PB;
+            LP = cur ? p.LA * p.PA : p.LB * p.PB;
+            loc = static_cast<const T *>(cur ? p.locA : p.locB);
+            aw = static_cast<const T *>(cur ? p.awA : p.awB);
+        };
         // one candidate per lane per pass; the NEXT pass's (x, y, attn) are loaded before this pass's
         // hits are processed, so the scan's memory latency hides behind stage 2
         auto fetch = [&](int i, float &x, float &y, float &a, int &qrow) {
             x = y = -10.f; a = 0.f; qrow = 0;
-            if (i < total) {
-                int t = f, vl = l, P = p.PA, LP = p.LA * p.PA, j = i;
-                const T *loc = static_cast<const T *>(p.locA);
-                const T *aw = static_cast<const T *>(p.awA);
-                if (i >= nptsA) {
-                    const int k = (i - nptsA) / nptsB;
-                    j = (i - nptsA) - k * nptsB;
-                    const int tw = s_src[1 + k];
-                    t = tw / p.window;
-                    vl = (tw - t * p.window) * L + l; P = p.PB; LP = p.LB * p.PB;
-                    loc = static_cast<const T *>(p.locB);
-                    aw = static_cast<const T *>(p.awB);
+            if (i < n_cand) {
+                const int ei = pshift >= 0 ? (i >> pshift) : i / Pmax, pt = i - ei * Pmax;
+                const int e = s_list[ei];
+                int t, vl, vlg, P, LP;
+                const T *loc, *aw;
+                source_of(e >> 24, t, vl, vlg, P, LP, loc, aw);
+                if (pt < P) {
+                    const int64_t gq = ((int64_t)clip * p.frames + t) * p.Lq + (e & 0xffffff);
+                    const int64_t idx = (gq * p.M + m) * LP + vl * P + pt;
+                    x = Store<T>::get(loc + 2 * idx);
+                    y = Store<T>::get(loc + 2 * idx + 1);
+                    a = Store<T>::get(aw + idx);
+                    qrow = (int)gq;
                 }
-                const int q = j / P, pt = j - q * P;
-                const int64_t gq = ((int64_t)clip * p.frames + t) * p.Lq + q;
-                const int64_t idx = (gq * p.M + m) * LP + vl * P + pt;
-                x = Store<T>::get(loc + 2 * idx);
-                y = Store<T>::get(loc + 2 * idx + 1);
-                a = Store<T>::get(aw + idx);
-                qrow = (int)gq;
             }
         };
         // NC candidates per lane per pass: a band catches only ~1/7 of its level's points, so the hits
@@ -714,8 +750,6 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
         constexpr int kPass = kScatterThreads * NC;
         float cx[NC], cy[NC], ca[NC];
         int cq[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) fetch(c * kScatterThreads + tid, cx[c], cy[c], ca[c], cq[c]);
 
         // Stage 2 is software-pipelined over "hit groups" (RPW hits, one team of G lanes each): prep()
         // finds the team's hit, fetches its tap record from the finder lane (ds_bpermute) and ISSUES the
@@ -786,7 +820,37 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
             }
         };
 
-        for (int base = 0; base < total; base += kPass) {
+        for (int seg = 0; seg < n_groups; seg += kScatterSeg) {
+        __syncthreads();                                    // s_list of the previous segment is done
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kScatterSeg / kScatterThreads; ++j) {
+            const int gi = seg + j * kScatterThreads + tid;
+            bool keep = gi < n_groups;
+            int k = 0, q = 0;
+            if (keep) {
+                k = gi / p.Lq; q = gi - k * p.Lq;
+                if (p.bbox) {
+                    int t, vl, vlg, P, LP;
+                    const T *loc, *aw;
+                    source_of(k, t, vl, vlg, P, LP, loc, aw);
+                    const int64_t gm = (((int64_t)clip * p.frames + t) * p.M + m) * VL + vlg;
+                    const int2 iv = *reinterpret_cast<const int2 *>(p.bbox + (gm * p.Lq + q) * 2);
+                    keep = iv.y >= r0 - 1 && iv.x <= r1;      // empty interval (no valid point): false
+                }
+            }
+            const u64 bal = __ballot(keep);
+            int wbase = 0;
+            if (lane == 0 && bal) wbase = atomicAdd(&s_count, (int)__popcll(bal));
+            wbase = __shfl(wbase, 0, kWave);
+            if (keep) s_list[wbase + (int)__popcll(bal & ((1ull << lane) - 1ull))] = (k << 24) | q;
+        }
+        __syncthreads();
+        n_cand = s_count * Pmax;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) fetch(c * kScatterThreads + tid, cx[c], cy[c], ca[c], cq[c]);
+        for (int base = 0; base < n_cand; base += kPass) {
             // ---- stage 1: tap arithmetic + band test for this lane's NC candidates
             int pixs[NC], bitss[NC], qrows[NC];
             float was[NC][4];
@@ -844,6 +908,7 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
                 }
             }
         }
+        }   // segments
         consume(pend);
         __syncthreads();
         // ---- flush the band: fixed point -> fp32, plain coalesced stores (D floats per pixel at stride M*D)
@@ -1012,9 +1077,10 @@ int check_launch(const char *what)
 
 bool aligned16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
 
-size_t tile_lds_bytes(int rpw, int nvl, bool bwd)
+size_t tile_lds_bytes(int rpw, int nvl, bool bwd, bool intervals = false)
 {
-    return (size_t)rpw * kRowSlots * 16 * (bwd ? 3 : 2) + (size_t)nvl * sizeof(Level);
+    return (size_t)rpw * kRowSlots * 16 * (bwd ? 3 : 2) + (size_t)nvl * sizeof(Level) +
+           (intervals ? (size_t)rpw * nvl * 8 : 0);     // + the per-(row, level) tap-row intervals
 }
 
 int env_int(const char *name, int dflt)
@@ -1043,7 +1109,7 @@ bool scatter_applicable(const Params &p)
     const char *mode = getenv("MSDA_BWD_MODE");
     if (mode && !strcmp(mode, "atomic")) return false;
     if (p.L > kScatterMaxLevels || (p.D % 4) != 0) return false;
-    if (1 + p.frames * p.window > kScatterMaxSources) return false;
+    if (1 + p.frames * p.window > kScatterMaxSources || p.Lq >= (1 << 24)) return false;
     if (p.window == 0 && p.LA != p.L) return false;
     return true;
 }
@@ -1055,7 +1121,7 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     const int64_t tiles = (int64_t)p.groups * ((p.Lq + RPW - 1) / RPW);
     const int64_t blocks = tiles * p.M;
     if (blocks > 0x7fffffffLL) return fail(MSDA_ERR_ARG, "msda: problem too large for one launch%s");
-    const size_t lds = tile_lds_bytes(RPW, p.LA + p.LB, bwd);
+    const size_t lds = tile_lds_bytes(RPW, p.LA + p.LB, bwd, bwd && p.bbox != nullptr);
     if (!bwd) {
         const int nb = env_int("MSDA_FWD_NB", 4);
         if (nb == 1)
@@ -1183,11 +1249,30 @@ int check_common(const void *value, const int64_t *shapes, const int64_t *lsi, i
     return MSDA_OK;
 }
 
+long long workspace_need(int batch, int num_query, int num_heads, int virtual_levels)
+{
+    return MSDA_BWD_WORKSPACE_BYTES + (long long)batch * num_query * num_heads * virtual_levels * 8;
+}
+
+void attach_workspace(Params &p, void *workspace, long long bytes, int batch, int num_query, int num_heads, int vl)
+{
+    p.workspace = (workspace && bytes >= MSDA_BWD_WORKSPACE_BYTES) ? static_cast<unsigned *>(workspace) : nullptr;
+    p.bbox = nullptr;
+    const char *e = getenv("MSDA_BWD_CULL");        // measurement hook: 0 disables the culling structure
+    if (p.workspace && bytes >= workspace_need(batch, num_query, num_heads, vl) && !(e && e[0] == '0'))
+        p.bbox = reinterpret_cast<int *>(p.workspace) + MSDA_BWD_WORKSPACE_BYTES / 4;
+}
+
 }  // namespace
 
 extern "C" {
 
 int msda_version(void) { return MSDA_ABI_VERSION; }
+
+long long msda_backward_workspace_bytes(int batch, int num_query, int num_heads, int virtual_levels)
+{
+    return workspace_need(batch, num_query, num_heads, virtual_levels);
+}
 
 const char *msda_last_error(void) { return g_err; }
 
@@ -1219,7 +1304,7 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
                   int batch, int spatial_size, int num_heads, int channels, int num_levels,
                   int num_query, int num_point,
                   void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
-                  void *workspace, void *stream)
+                  void *workspace, long long workspace_bytes, void *stream)
 {
     g_err[0] = 0;
     int rc = check_common(value, spatial_shapes, level_start_index, batch, spatial_size, num_heads,
@@ -1234,7 +1319,7 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
     p.value = value; p.shapes = spatial_shapes; p.lsi = level_start_index;
     p.locA = sampling_loc; p.awA = attn_weight; p.grad_out = grad_out;
     p.grad_value = grad_value; p.glocA = grad_sampling_loc; p.gawA = grad_attn_weight;
-    p.workspace = static_cast<unsigned *>(workspace);
+    attach_workspace(p, workspace, workspace_bytes, batch, num_query, num_heads, num_levels);
     p.groups = batch; p.frames = 1; p.window = 0;
     p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
     p.LA = num_levels; p.PA = num_point; p.LB = 0; p.PB = 1;
@@ -1277,7 +1362,8 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
                            int channels, int num_levels, int num_query,
                            int num_curr_point, int num_temp_point,
                            void *grad_value, void *grad_loc_curr, void *grad_aw_curr,
-                           void *grad_loc_temp, void *grad_aw_temp, void *workspace, void *stream)
+                           void *grad_loc_temp, void *grad_aw_temp, void *workspace, long long workspace_bytes,
+                           void *stream)
 {
     g_err[0] = 0;
     int rc = check_common(value, spatial_shapes, level_start_index, clips, spatial_size, num_heads,
@@ -1295,7 +1381,7 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
     p.locA = loc_curr; p.awA = aw_curr; p.locB = loc_temp; p.awB = aw_temp; p.grad_out = grad_out;
     p.grad_value = grad_value; p.glocA = grad_loc_curr; p.gawA = grad_aw_curr;
     p.glocB = grad_loc_temp; p.gawB = grad_aw_temp;
-    p.workspace = static_cast<unsigned *>(workspace);
+    attach_workspace(p, workspace, workspace_bytes, clips * frames, num_query, num_heads, num_levels * (1 + window));
     p.groups = clips * frames; p.frames = frames; p.window = window;
     p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
     p.LA = num_levels; p.PA = num_curr_point;

@@ -37,8 +37,8 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 2
-#define MSDA_BWD_WORKSPACE_BYTES 64   /* device scratch the backward entry points need */
+#define MSDA_ABI_VERSION 3
+#define MSDA_BWD_WORKSPACE_BYTES 64   /* minimum device scratch of the backward entry points (ticket counters) */
 
 enum msda_dtype { MSDA_F32 = 0, MSDA_F64 = 1, MSDA_BF16 = 2, MSDA_F16 = 3 };
 
@@ -85,9 +85,13 @@ int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,
  *   grad_value        [N, S, M, D]         float (double for MSDA_F64); caller zero-fills; accumulated
  *   grad_sampling_loc [N, Lq, M, L, P, 2]  dtype, fully overwritten (skipped points get 0)
  *   grad_attn_weight  [N, Lq, M, L, P]     dtype, fully overwritten
- *   workspace         MSDA_BWD_WORKSPACE_BYTES of device scratch, zero-filled by the caller, private to
- *                     this call until it completes: the scatter pass keeps its work-ticket counters there
- *                     (dynamic scheduling).  NULL is allowed (static scheduling, slower for few clips).
+ *   workspace         device scratch private to this call until it completes, `workspace_bytes` long, whose
+ *                     FIRST MSDA_BWD_WORKSPACE_BYTES are zero-filled by the caller (work-ticket counters of
+ *                     the scatter pass: dynamic scheduling).  With at least msda_backward_workspace_bytes()
+ *                     bytes the gather pass also leaves, per (row, level), the interval of pixel rows its
+ *                     taps touch, and the scatter pass culls the rows that cannot reach its band -- a large
+ *                     win whenever sampling is local (encoder) or clustered (decoder).  NULL / 0 is allowed
+ *                     (static scheduling, no culling).
  */
 int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
                   const int64_t *level_start_index, const void *sampling_loc,
@@ -95,7 +99,12 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
                   int batch, int spatial_size, int num_heads, int channels, int num_levels,
                   int num_query, int num_point,
                   void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
-                  void *workspace, void *stream);
+                  void *workspace, long long workspace_bytes, void *stream);
+
+/* Bytes of `workspace` that enable every feature of msda_backward / msda_temporal_backward:
+ * 64 + rows * virtual_levels * 8 with rows = batch * num_query * num_heads and virtual_levels = num_levels
+ * (msda_backward) or num_levels * (1 + window) (msda_temporal_backward; batch = clips * frames). */
+long long msda_backward_workspace_bytes(int batch, int num_query, int num_heads, int virtual_levels);
 
 /*
  * Fused temporal forward: for every frame t of every clip, current-frame attention on value[t] PLUS
@@ -140,7 +149,8 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
                            int channels, int num_levels, int num_query,
                            int num_curr_point, int num_temp_point,
                            void *grad_value, void *grad_loc_curr, void *grad_aw_curr,
-                           void *grad_loc_temp, void *grad_aw_temp, void *workspace, void *stream);
+                           void *grad_loc_temp, void *grad_aw_temp, void *workspace, long long workspace_bytes,
+                           void *stream);
 
 #ifdef __cplusplus
 }
