@@ -52,9 +52,11 @@ def parse_args():
     ap.add_argument("--queries", type=int, default=300, help="queries per frame")
     ap.add_argument("--pyramid", choices=sorted(PYRAMIDS), default="A")
     ap.add_argument("--dtype", choices=sorted(DTYPES), default="f32")
-    ap.add_argument("--locs", choices=["uniform", "clustered"], default="uniform",
+    ap.add_argument("--locs", choices=["uniform", "clustered", "local"], default="uniform",
                     help="uniform: rand in [0,1) as the reference test.py; clustered: reference point + "
-                         "N(0, (3 px)^2) offsets per level, as a trained decoder produces")
+                         "N(0, (3 px)^2) offsets per level, as a trained decoder produces; local: query i sits on "
+                         "pixel i of the pyramid (needs --queries S) and samples N(0, (2 px)^2) around it in every "
+                         "frame, as the temporal ENCODER does")
     ap.add_argument("--mode", choices=["clip-parallel", "sharded"], default="clip-parallel",
                     help="clip-parallel: independent clips per GPU, no collective (default, weak scaling); "
                          "sharded: every clip is split over ALL ranks (devis_amd/clip_parallel.py: RCCL all-gather "
@@ -79,10 +81,19 @@ def make_clip_batch(args, device, dtype, seed):
         loc_c = torch.rand(G, q, M, L, P, 2, generator=g)
         loc_t = torch.rand(G, q, M, W * L, P, 2, generator=g)
     else:
+        sigma = 3.0
         ref = torch.rand(G, q, 1, 1, 1, 2, generator=g)
+        if args.locs == "local":
+            if q != S:
+                sys.exit("--locs local needs --queries %d (= S of pyramid %s)" % (S, args.pyramid))
+            sigma = 2.0
+            centres = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w,
+                                                             indexing="ij"), -1).reshape(-1, 2).flip(-1)
+                                 for h, w in shapes.tolist()], 0)                       # [S, 2] as (x, y)
+            ref = centres[None, :, None, None, None, :].expand(G, q, 1, 1, 1, 2)
         wh = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()
-        loc_c = ref + torch.randn(G, q, M, L, P, 2, generator=g) * 3.0 / wh[None, None, None, :, None, :]
-        loc_t = ref + torch.randn(G, q, M, W * L, P, 2, generator=g) * 3.0 / wh.repeat(W, 1)[None, None, None, :, None, :]
+        loc_c = ref + torch.randn(G, q, M, L, P, 2, generator=g) * sigma / wh[None, None, None, :, None, :]
+        loc_t = ref + torch.randn(G, q, M, W * L, P, 2, generator=g) * sigma / wh.repeat(W, 1)[None, None, None, :, None, :]
     aw = torch.softmax(torch.randn(G, q, M, L * P + W * L * P, generator=g), -1)
     aw_c = aw[..., :L * P].reshape(G, q, M, L, P)
     aw_t = aw[..., L * P:].reshape(G, q, M, W * L, P)

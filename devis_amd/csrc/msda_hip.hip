@@ -594,7 +594,7 @@ msda_bwd_tile_kernel(const Params p)
 constexpr int kScatterThreads = 1024;
 constexpr int kScatterMaxLevels = 32;
 constexpr int kScatterMaxSources = 64;     // 1 + frames * window must fit
-constexpr int kScatterSeg = 2048;          // (source, query) groups culled + compacted per segment
+constexpr int kScatterList = 3072;         // capacity of the survivor list (12 KiB of the 16 KiB LDS left by the band)
 typedef unsigned long long u64;
 
 template <typename T, int G>
@@ -609,7 +609,7 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
     __shared__ int s_H[kScatterMaxLevels], s_W[kScatterMaxLevels], s_R[kScatterMaxLevels],
         s_first[kScatterMaxLevels + 1], s_lsi[kScatterMaxLevels];
     __shared__ int s_src_t[kScatterMaxSources], s_src_vl[kScatterMaxSources], s_nsrc;    // sources of frame f
-    __shared__ int s_list[kScatterSeg], s_count;       // surviving (source, query) groups of a segment
+    __shared__ int s_list[kScatterList], s_count;      // surviving (source, query) groups awaiting their scan
 
     const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
     const int D = p.D, MD = p.M * p.D;
@@ -705,7 +705,7 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
         __syncthreads();
         const int n_srcs = s_nsrc;
         // Candidate GROUPS are (source k, query q) pairs, each with P points at this level.  They are
-        // walked in segments of kScatterSeg groups: a segment is first CULLED against the band -- the
+        // culled in batches of 1024 against the band before they are scanned -- the
         // gather pass left, per (row, level), the interval of top tap rows in p.bbox; a group whose
         // interval misses rows [r0-1, r1] cannot touch the band -- and the survivors are compacted
         // into s_list; only they are scanned.  With local (encoder) or clustered (decoder) sampling
@@ -820,13 +820,15 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
             }
         };
 
-        for (int seg = 0; seg < n_groups; seg += kScatterSeg) {
-        __syncthreads();                                    // s_list of the previous segment is done
+        // Cull in batches of one group per thread, appending survivors to s_list; the list is scanned
+        // when another batch might not fit (or the groups are exhausted), so that sparse survivors
+        // (local / clustered sampling) still fill whole scan passes.
+        __syncthreads();
         if (tid == 0) s_count = 0;
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < kScatterSeg / kScatterThreads; ++j) {
-            const int gi = seg + j * kScatterThreads + tid;
+        for (int gi0 = 0; gi0 < n_groups || gi0 == 0; gi0 += kScatterThreads) {
+        {
+            const int gi = gi0 + tid;
             bool keep = gi < n_groups;
             int k = 0, q = 0;
             if (keep) {
@@ -847,7 +849,10 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
             if (keep) s_list[wbase + (int)__popcll(bal & ((1ull << lane) - 1ull))] = (k << 24) | q;
         }
         __syncthreads();
-        n_cand = s_count * Pmax;
+        const int listed = s_count;
+        const bool last = gi0 + kScatterThreads >= n_groups;
+        if (!last && listed <= kScatterList - kScatterThreads) continue;     // room for another batch
+        n_cand = listed * Pmax;
 #pragma unroll
         for (int c = 0; c < NC; ++c) fetch(c * kScatterThreads + tid, cx[c], cy[c], ca[c], cq[c]);
         for (int base = 0; base < n_cand; base += kPass) {
@@ -908,7 +913,10 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
                 }
             }
         }
-        }   // segments
+        __syncthreads();                                    // everyone is done with s_list
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+        }   // cull batches
         consume(pend);
         __syncthreads();
         // ---- flush the band: fixed point -> fp32, plain coalesced stores (D floats per pixel at stride M*D)
