@@ -258,7 +258,7 @@ def main():
         e = b["value"].element_size()
         ab = algorithmic_bytes(args, e)
         kernels = {
-            "msda_fwd_tile_kernel": (fwd_ms, fwd_med, ab["fwd"]),
+            "msda_fwd_slab_kernel": (fwd_ms, fwd_med, ab["fwd"]),
             "msda_bwd_tile_kernel (grad_loc/grad_attn gather pass)": (gat_ms, gat_med, ab["bwd_gather"]),
             "msda_bwd_value_lds_kernel (grad_value scatter)": (sca_ms, sca_med, ab["bwd_scatter"]),
         }

@@ -388,6 +388,214 @@ msda_fwd_tile_kernel(const Params p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// forward with the small pyramid levels served from a workgroup-shared LDS slab
+// ------------------------------------------------------------------------------------------------
+// The tile forward is bound by the rate at which a CU's L1 serves distinct 64-byte granules (DESIGN.md
+// section 5): ~25-29 B/clk/CU for scattered 128-byte rows, whatever the locality.  Random 16-byte-per-lane
+// LDS reads run at ~94 B/clk/CU.  So 16 waves share one workgroup: each wave still owns a tile of RPW rows
+// and builds its tap records once per point in its own LDS region exactly as the tile kernel does, but
+// the workgroup walks the clip's SOURCE FRAMES together and, for each, stages the slab
+// value[frame, levels >= l0, head, :] (as many of the last levels as fit; levels 2-3 of the DeVIS pyramid =
+// 50 % of all taps, 38 KiB) into LDS with LDS-DMA.  A tap whose level is in the slab reads LDS, the
+// others go through L1 as before; the level of chunk position pp is the same for every row, so the choice
+// is wave-uniform.  Accumulators stay in registers across the frames.
+constexpr int kSlabWaves = 16;
+constexpr int kSlabThreads = kSlabWaves * kWave;
+constexpr int kSlabMaxLevels = 32;
+
+// single-wave producer/consumer hand-off through LDS: DS operations of one wave execute in order, only the
+// compiler must be kept from moving them across
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// levels [result, L) form the slab: the last levels whose pixels are one contiguous tail of the map and
+// whose [pixels, D] slab fits `cap` elements
+__device__ __forceinline__ int first_slab_level(const Params &p, int cap)
+{
+    int l0 = p.L;
+    long long acc = 0;
+    for (int l = p.L - 1; l >= 0; --l) {
+        const long long hw = (long long)p.shapes[2 * l] * p.shapes[2 * l + 1];
+        if (l + 1 < p.L && p.lsi[l] + hw != p.lsi[l + 1]) break;
+        acc += hw * p.D;
+        if (acc > cap) break;
+        l0 = l;
+    }
+    return l0;
+}
+
+template <typename T, int G, int NB>
+__global__ void __launch_bounds__(kSlabThreads)
+msda_fwd_slab_kernel(const Params p, int slab_elems)
+{
+    constexpr int VEC = Store<T>::VEC;
+    constexpr int RPW = kWave / G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ int s_sH[kSlabMaxLevels], s_sW[kSlabMaxLevels], s_sStart[kSlabMaxLevels];
+    __shared__ int s_l0, s_px0, s_npx;
+
+    const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
+    const int nvl = p.LA + p.LB, L = p.L;
+    T *slab = reinterpret_cast<T *>(lds_raw);
+    unsigned char *mine = lds_raw + (size_t)slab_elems * sizeof(T) +
+                          (size_t)wave * (RPW * kRowSlots * 32 + nvl * sizeof(Level));
+    int4 *s_off = reinterpret_cast<int4 *>(mine);
+    float4 *s_w = reinterpret_cast<float4 *>(s_off + RPW * kRowSlots);
+    Level *s_lvl = reinterpret_cast<Level *>(s_w + RPW * kRowSlots);
+
+    if (tid == 0) {
+        const int l0 = first_slab_level(p, slab_elems - 2048 / (int)sizeof(T));    // slack: last LDS-DMA piece
+        const int px0 = l0 < L ? (int)p.lsi[l0] : 0;
+        int npx = 0;
+        for (int l = l0; l < L; ++l) {
+            s_sH[l] = (int)p.shapes[2 * l]; s_sW[l] = (int)p.shapes[2 * l + 1];
+            s_sStart[l] = (int)p.lsi[l] - px0;
+            npx += s_sH[l] * s_sW[l];
+        }
+        s_l0 = l0; s_px0 = px0; s_npx = npx;
+    }
+
+    // workgroup -> (clip, head, 16 consecutive tiles of the clip); wave -> tile
+    const int m = blockIdx.x % p.M;
+    const int tiles_per_group = (p.Lq + RPW - 1) / RPW;
+    const int tiles_per_clip = p.frames * tiles_per_group;
+    const int blocks_per_clip = (tiles_per_clip + kSlabWaves - 1) / kSlabWaves;
+    const int rest = blockIdx.x / p.M;
+    const int clip = rest / blocks_per_clip;
+    const int ct = (rest - clip * blocks_per_clip) * kSlabWaves + wave;
+    const bool have_tile = ct < tiles_per_clip;
+    const int t = have_tile ? ct / tiles_per_group : 0;
+    const int q0 = have_tile ? (ct - t * tiles_per_group) * RPW : 0;
+    const int group = clip * p.frames + t;
+    if (have_tile)
+        for (int j = lane; j < nvl; j += kWave) s_lvl[j] = make_level(p, t, j);
+    __syncthreads();
+    const int l0 = s_l0, px0 = s_px0, npx = s_npx;
+
+    const int r = lane / G, sub = lane % G;
+    const int rows_valid = have_tile ? min(RPW, p.Lq - q0) : 0;
+    const int D = p.D, MD = p.M * p.D;
+    const T *__restrict__ value =
+        static_cast<const T *>(p.value) + (int64_t)clip * p.frames * p.S * MD + (m * D + sub * VEC);
+    const T *slab_lane = slab + sub * VEC;
+    const int64_t row0 = ((int64_t)group * p.Lq + q0) * p.M + m;
+
+    float acc[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[c] = 0.f;
+
+    for (int f = 0; f < p.frames; ++f) {
+        __syncthreads();                                   // every wave is done with the previous slab
+        if (l0 < L) {
+            constexpr int PXW = kWave / G;                 // pixels per LDS-DMA wave instruction
+            const T *src = static_cast<const T *>(p.value) +
+                           (((int64_t)clip * p.frames + f) * p.S + px0) * MD + m * D;
+            for (int pb = wave * PXW; pb < npx; pb += kSlabWaves * PXW) {
+                const int px = min(pb + lane / G, npx - 1);
+                const T *gp = src + (int64_t)px * MD + (lane % G) * VEC;
+#if defined(__HIP_DEVICE_COMPILE__)      // device-only builtin: keep the host pass (kernel stub) clean
+                __builtin_amdgcn_global_load_lds(
+                    gp, (__attribute__((address_space(3))) void *)(slab + (size_t)pb * D), 16, 0, 0);
+#else
+                (void)gp;
+#endif
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (!have_tile) continue;
+        for (int sl = -1; sl < p.window; ++sl) {           // sl = -1: the tile's current-frame points
+            if (sl < 0) { if (t != f) continue; }
+            else if (p.ftab[t * p.window + sl] != f) continue;
+            const T *loc = static_cast<const T *>(sl < 0 ? p.locA : p.locB);
+            const T *aw = static_cast<const T *>(sl < 0 ? p.awA : p.awB);
+            const int P = sl < 0 ? p.PA : p.PB;
+            const int LP = (sl < 0 ? p.LA : p.LB) * P;
+            const int nlev = sl < 0 ? p.LA : L;
+            const int pt0 = sl < 0 ? 0 : sl * L * P;
+            const int vl0 = sl < 0 ? 0 : p.LA + sl * L;    // virtual level of the slot's level 0
+            const int npts = nlev * P;
+#pragma unroll 1
+            for (int c0 = 0; c0 < npts; c0 += kPch) {
+                // ---- stage: tap records of this chunk (one point per lane and step), LDS or global flavour
+#pragma unroll
+                for (int k = 0; k < staged_per_lane<RPW>(); ++k) {
+                    const int i = lane + k * kWave;
+                    if (i >= RPW * kPch) break;
+                    const int rr = i / kPch, pp = i % kPch, kk = c0 + pp;
+                    float x = -10.f, y = -10.f, a = 0.f;
+                    if (rr < rows_valid && kk < npts) {
+                        const int64_t idx = (row0 + (int64_t)rr * p.M) * LP + pt0 + kk;
+                        x = Store<T>::get(loc + 2 * idx);
+                        y = Store<T>::get(loc + 2 * idx + 1);
+                        a = Store<T>::get(aw + idx);
+                    }
+                    const int l = min(kk, npts - 1) / P;
+                    Taps tp;
+                    if (l >= l0) {
+                        Level lv; lv.H = s_sH[l]; lv.W = s_sW[l]; lv.start = s_sStart[l]; lv.pad = 0;
+                        tp = make_taps(x, y, lv, D);               // offsets inside the slab (stride D)
+                    } else {
+                        tp = make_taps(x, y, s_lvl[vl0 + l], MD);
+                    }
+                    s_off[rr * kRowSlots + pp] = make_int4(tp.off[0], tp.off[1], tp.off[2], tp.off[3]);
+                    s_w[rr * kRowSlots + pp] = make_float4(tp.w[0] * a, tp.w[1] * a, tp.w[2] * a, tp.w[3] * a);
+                }
+                wave_sync();
+                // ---- gather
+                const int np = min(kPch, npts - c0);
+                const int4 *ro = s_off + r * kRowSlots;
+                const float4 *rw = s_w + r * kRowSlots;
+#pragma unroll 1
+                for (int pp = 0; pp < np; pp += NB) {
+                    int4 o[NB];
+                    float4 w[NB];
+                    float v[NB][4][VEC];
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) { o[b] = ro[pp + b]; w[b] = rw[pp + b]; }
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const bool in_slab = min(c0 + pp + b, npts - 1) / P >= l0;     // wave-uniform
+                        const T *base = in_slab ? slab_lane : value;
+                        if (in_slab) {
+                            Store<T>::load(slab_lane + o[b].x, v[b][0]);
+                            Store<T>::load(slab_lane + o[b].y, v[b][1]);
+                            Store<T>::load(slab_lane + o[b].z, v[b][2]);
+                            Store<T>::load(slab_lane + o[b].w, v[b][3]);
+                        } else {
+                            Store<T>::load(value + o[b].x, v[b][0]);
+                            Store<T>::load(value + o[b].y, v[b][1]);
+                            Store<T>::load(value + o[b].z, v[b][2]);
+                            Store<T>::load(value + o[b].w, v[b][3]);
+                        }
+                        (void)base;
+                    }
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                        for (int ch = 0; ch < VEC; ++ch) {
+                            acc[ch] = fmaf(w[b].x, v[b][0][ch], acc[ch]);
+                            acc[ch] = fmaf(w[b].y, v[b][1][ch], acc[ch]);
+                            acc[ch] = fmaf(w[b].z, v[b][2][ch], acc[ch]);
+                            acc[ch] = fmaf(w[b].w, v[b][3][ch], acc[ch]);
+                        }
+                    }
+                }
+                wave_sync();
+            }
+        }
+    }
+    if (r < rows_valid) {
+        T *out = static_cast<T *>(p.out) + (row0 + (int64_t)r * p.M) * D + sub * VEC;
+        Store<T>::store(out, acc);
+    }
+}
+
 // sum over the G lanes of a row (G a power of two <= 64; rows are G-aligned lane groups).  Up to 16
 // lanes the butterfly is pure DPP (no LDS crossbar, no waits): quad_perm xor1 / xor2, row_half_mirror
 // (lane i <-> 7-i inside each 8), row_mirror (i <-> 15-i inside each 16); wider rows finish with
@@ -1130,6 +1338,29 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     const int64_t blocks = tiles * p.M;
     if (blocks > 0x7fffffffLL) return fail(MSDA_ERR_ARG, "msda: problem too large for one launch%s");
     const size_t lds = tile_lds_bytes(RPW, p.LA + p.LB, bwd, bwd && p.bbox != nullptr);
+    if (!bwd && sizeof(T) == 4 && p.LA == p.L && p.L <= kSlabMaxLevels) {
+        // slab forward: 16 waves per workgroup share the small levels in LDS; needs enough workgroups
+        const int tiles_per_clip = p.frames * ((p.Lq + RPW - 1) / RPW);
+        const int blocks_per_clip = (tiles_per_clip + kSlabWaves - 1) / kSlabWaves;
+        const int64_t slab_blocks = (int64_t)(p.groups / p.frames) * blocks_per_clip * p.M;
+        const int mode = env_int("MSDA_FWD_SLAB", -1);                 // -1 auto, 0 off, 1 force
+        const size_t per_wave = (size_t)RPW * kRowSlots * 32 + (size_t)(p.LA + p.LB) * sizeof(Level);
+        const long long slab_bytes = ((160 * 1024 - 1024 - (long long)kSlabWaves * (long long)per_wave) / 1024) * 1024;
+        if (mode != 0 && slab_bytes >= 16 * 1024 && (mode == 1 || slab_blocks >= 2 * device_cus()) &&
+            slab_blocks <= 0x7fffffffLL) {
+            const size_t total = (size_t)slab_bytes + kSlabWaves * per_wave;
+            static size_t limit_set = 0;
+            if (total > limit_set) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_slab_kernel<T, G, 4>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)total) != hipSuccess)
+                    return fail(MSDA_ERR_HIP, "msda forward: cannot reserve the LDS budget of the slab kernel%s");
+                limit_set = total;
+            }
+            hipLaunchKernelGGL((msda_fwd_slab_kernel<T, G, 4>), dim3((unsigned)slab_blocks), dim3(kSlabThreads),
+                               total, stream, p, (int)(slab_bytes / (long long)sizeof(T)));
+            return check_launch("msda forward (slab kernel)");
+        }
+    }
     if (!bwd) {
         const int nb = env_int("MSDA_FWD_NB", 4);
         if (nb == 1)
@@ -1149,6 +1380,9 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     const int phases = env_int("MSDA_BWD_PHASES", 3);
     int rc = MSDA_OK;
     if (phases & 1) {
+        // (a slab variant of this pass, as for the forward, was built and measured: +4 % on the decoder
+        //  workload, -8 % on the encoder shape -- its point loop is VALU-heavier and its per-wave LDS only
+        //  leaves room for 12 waves per CU -- so the gather pass stays on the tile kernel)
         hipLaunchKernelGGL((msda_bwd_tile_kernel<T, G, false>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
         rc = check_launch("msda backward (tile kernel, grad_loc/grad_attn)");
         if (rc) return rc;

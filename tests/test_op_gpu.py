@@ -380,3 +380,21 @@ def test_full_size_temporal_encoder_800x1333():
     lhs = (out.detach().double() * go.to(DEV).double()).sum().item()
     rhs = (v.detach().double() * gv.double()).sum().item()
     assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+
+
+def test_forward_slab_kernel_forced(monkeypatch):
+    """MSDA_FWD_SLAB=1 forces the 16-wave slab forward (small levels served from a workgroup-shared LDS
+    slab) on shapes the host heuristic would leave to the tile kernel."""
+    monkeypatch.setenv("MSDA_FWD_SLAB", "1")
+    for name in ("op_devis_small", "op_batched_im2col", "op_out_of_range", "op_many_levels", "op_cfg1", "op_generic_D64"):
+        g, d = _golden_dict(name)
+        out, gv, gl, ga = _run_op(d, torch.float32)
+        assert _maxabs(out, g["out"]) <= 1e-6, name
+    ftab = np.array([[1, 1], [0, 2], [1, 3], [2, 4], [3, 3]], dtype=np.int32)     # repeated frames
+    for kw in (dict(T=4, W=3, ftab=None, Lq=37), dict(T=5, W=2, ftab=ftab, Lq=150)):
+        dt = make_temporal_inputs(47, kw["T"], kw["W"], 8, 32, kw["Lq"], [(9, 7), (5, 4), (3, 2)], 4, 2, ftab=kw["ftab"])
+        ref = temporal_reference(*(np.asarray(dt[k], dtype=np.float64) if dt[k].dtype.kind == "f" else dt[k]
+                                   for k in ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t")))
+        got = _run_temporal(dt, torch.float32)
+        assert _maxabs(got[0], ref) <= 2e-5 * max(1.0, np.abs(ref).max())
+
