@@ -260,10 +260,12 @@ def main():
         # the library runs the slab forward when there are >= 2 workgroups of 16 tiles per CU, else the tile forward
         n_cu = torch.cuda.get_device_properties(device).multi_processor_count
         slab_blocks = args.clips * ((T * ((q + 7) // 8) + 15) // 16) * M
-        fwd_name = "msda_fwd_slab_kernel" if (dtype == torch.float32 and slab_blocks >= 2 * n_cu) else "msda_fwd_tile_kernel"
+        use_slab = dtype == torch.float32 and slab_blocks >= 2 * n_cu
+        fwd_name = "msda_fwd_slab_kernel" if use_slab else "msda_fwd_tile_kernel"
+        gat_name = "msda_bwd_slab_kernel" if use_slab else "msda_bwd_tile_kernel"
         kernels = {
             fwd_name: (fwd_ms, fwd_med, ab["fwd"]),
-            "msda_bwd_tile_kernel (grad_loc/grad_attn gather pass)": (gat_ms, gat_med, ab["bwd_gather"]),
+            gat_name + " (grad_loc/grad_attn gather pass)": (gat_ms, gat_med, ab["bwd_gather"]),
             "msda_bwd_value_lds_kernel (grad_value scatter)": (sca_ms, sca_med, ab["bwd_scatter"]),
         }
         dom = max(kernels, key=lambda k: kernels[k][0])

@@ -618,6 +618,208 @@ __device__ __forceinline__ float row_sum(float v)
     return v;
 }
 
+// Backward gather pass (grad_loc / grad_attn) with the same workgroup-shared slab of the small levels.
+// To keep 16 waves per workgroup its tap-row interval table is per SLOT ([RPW, L], flushed after each
+// slot) instead of per virtual level as in the tile kernel.
+template <typename T, int G>
+__global__ void __launch_bounds__(kSlabThreads)
+msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
+{
+    constexpr int VEC = Store<T>::VEC;
+    constexpr int RPW = kWave / G;
+    constexpr int NW = kSlabWaves;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ int s_sH[kSlabMaxLevels], s_sW[kSlabMaxLevels], s_sStart[kSlabMaxLevels];
+    __shared__ int s_l0, s_px0, s_npx;
+
+    const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
+    const int nvl = p.LA + p.LB, L = p.L;
+    T *slab = reinterpret_cast<T *>(lds_raw);
+    unsigned char *mine = lds_raw + (size_t)slab_elems * sizeof(T) + (size_t)wave * per_wave_bytes;
+    int4 *s_off = reinterpret_cast<int4 *>(mine);
+    float4 *s_w = reinterpret_cast<float4 *>(s_off + RPW * kRowSlots);
+    float4 *s_e = s_w + RPW * kRowSlots;
+    Level *s_lvl = reinterpret_cast<Level *>(s_e + RPW * kRowSlots);
+    int *s_bb = p.bbox ? reinterpret_cast<int *>(s_lvl + nvl) : nullptr;      // [RPW, L, 2] of the current slot
+
+    if (tid == 0) {
+        const int l0 = first_slab_level(p, slab_elems - 2048 / (int)sizeof(T));
+        const int px0 = l0 < L ? (int)p.lsi[l0] : 0;
+        int npx = 0;
+        for (int l = l0; l < L; ++l) {
+            s_sH[l] = (int)p.shapes[2 * l]; s_sW[l] = (int)p.shapes[2 * l + 1];
+            s_sStart[l] = (int)p.lsi[l] - px0;
+            npx += s_sH[l] * s_sW[l];
+        }
+        s_l0 = l0; s_px0 = px0; s_npx = npx;
+    }
+    const int m = blockIdx.x % p.M;
+    const int tiles_per_group = (p.Lq + RPW - 1) / RPW;
+    const int tiles_per_clip = p.frames * tiles_per_group;
+    const int blocks_per_clip = (tiles_per_clip + NW - 1) / NW;
+    const int rest = blockIdx.x / p.M;
+    const int clip = rest / blocks_per_clip;
+    const int ct = (rest - clip * blocks_per_clip) * NW + wave;
+    const bool have_tile = ct < tiles_per_clip;
+    const int t = have_tile ? ct / tiles_per_group : 0;
+    const int q0 = have_tile ? (ct - t * tiles_per_group) * RPW : 0;
+    const int group = clip * p.frames + t;
+    if (have_tile)
+        for (int j = lane; j < nvl; j += kWave) s_lvl[j] = make_level(p, t, j);
+    __syncthreads();
+    const int l0 = s_l0, px0 = s_px0, npx = s_npx;
+
+    const int r = lane / G, sub = lane % G;
+    const int rows_valid = have_tile ? min(RPW, p.Lq - q0) : 0;
+    const int D = p.D, MD = p.M * p.D;
+    const T *__restrict__ value =
+        static_cast<const T *>(p.value) + (int64_t)clip * p.frames * p.S * MD + (m * D + sub * VEC);
+    const T *slab_lane = slab + sub * VEC;
+    const int64_t row0 = ((int64_t)group * p.Lq + q0) * p.M + m;
+    const int64_t row = row0 + (int64_t)r * p.M;
+
+    float g[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) g[c] = 0.f;
+    if (r < rows_valid) Store<T>::load(static_cast<const T *>(p.grad_out) + row * D + sub * VEC, g);
+
+    for (int f = 0; f < p.frames; ++f) {
+        __syncthreads();
+        if (l0 < L) {
+            constexpr int PXW = kWave / G;
+            const T *src = static_cast<const T *>(p.value) +
+                           (((int64_t)clip * p.frames + f) * p.S + px0) * MD + m * D;
+            for (int pb = wave * PXW; pb < npx; pb += NW * PXW) {
+                const int px = min(pb + lane / G, npx - 1);
+                const T *gp = src + (int64_t)px * MD + (lane % G) * VEC;
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_global_load_lds(
+                    gp, (__attribute__((address_space(3))) void *)(slab + (size_t)pb * D), 16, 0, 0);
+#else
+                (void)gp;
+#endif
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (!have_tile) continue;
+        for (int sl = -1; sl < p.window; ++sl) {
+            if (sl < 0) { if (t != f) continue; }
+            else if (p.ftab[t * p.window + sl] != f) continue;
+            const T *loc = static_cast<const T *>(sl < 0 ? p.locA : p.locB);
+            const T *aw = static_cast<const T *>(sl < 0 ? p.awA : p.awB);
+            T *gloc = static_cast<T *>(sl < 0 ? p.glocA : p.glocB);
+            T *gaw = static_cast<T *>(sl < 0 ? p.gawA : p.gawB);
+            const int P = sl < 0 ? p.PA : p.PB;
+            const int LP = (sl < 0 ? p.LA : p.LB) * P;
+            const int nlev = sl < 0 ? p.LA : L;
+            const int pt0 = sl < 0 ? 0 : sl * L * P;
+            const int vl0 = sl < 0 ? 0 : p.LA + sl * L;
+            const int npts = nlev * P;
+            if (s_bb) {
+                for (int j = lane; j < RPW * nlev; j += kWave) { s_bb[2 * j] = 0x7fffffff; s_bb[2 * j + 1] = -0x7fffffff - 1; }
+                wave_sync();
+            }
+#pragma unroll 1
+            for (int c0 = 0; c0 < npts; c0 += kPch) {
+#pragma unroll
+                for (int k = 0; k < staged_per_lane<RPW>(); ++k) {
+                    const int i = lane + k * kWave;
+                    if (i >= RPW * kPch) break;
+                    const int rr = i / kPch, pp = i % kPch, kk = c0 + pp;
+                    float x = -10.f, y = -10.f, a = 0.f;
+                    if (rr < rows_valid && kk < npts) {
+                        const int64_t idx = (row0 + (int64_t)rr * p.M) * LP + pt0 + kk;
+                        x = Store<T>::get(loc + 2 * idx);
+                        y = Store<T>::get(loc + 2 * idx + 1);
+                        a = Store<T>::get(aw + idx);
+                    }
+                    const int l = min(kk, npts - 1) / P, vl = vl0 + l;
+                    Taps tp;
+                    if (l >= l0) {
+                        Level lv; lv.H = s_sH[l]; lv.W = s_sW[l]; lv.start = s_sStart[l]; lv.pad = 0;
+                        tp = make_taps(x, y, lv, D);
+                    } else {
+                        tp = make_taps(x, y, s_lvl[vl], MD);
+                    }
+                    s_off[rr * kRowSlots + pp] = make_int4(tp.off[0], tp.off[1], tp.off[2], tp.off[3]);
+                    s_w[rr * kRowSlots + pp] = make_float4(tp.w[0], tp.w[1], tp.w[2], tp.w[3]);
+                    s_e[rr * kRowSlots + pp] = make_float4(a, tp.lh, tp.lw, __int_as_float(tp.valid | (vl << 4)));
+                    if (s_bb && tp.valid) {
+                        atomicMin(s_bb + (rr * nlev + l) * 2, tp.hl);
+                        atomicMax(s_bb + (rr * nlev + l) * 2 + 1, tp.hl);
+                    }
+                }
+                wave_sync();
+                const int np = min(kPch, npts - c0);
+                const int4 *ro = s_off + r * kRowSlots;
+                const float4 *rw = s_w + r * kRowSlots;
+                const float4 *re = s_e + r * kRowSlots;
+#pragma unroll 2
+                for (int pp = 0; pp < np; ++pp) {
+                    const int4 o = ro[pp];
+                    const float4 w = rw[pp];
+                    const float4 e = re[pp];
+                    const int bits = __float_as_int(e.w);
+                    const bool in_slab = (c0 + pp) / P >= l0;          // wave-uniform
+                    float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+                    if (in_slab) {
+                        Store<T>::load(slab_lane + o.x, v0);
+                        Store<T>::load(slab_lane + o.y, v1);
+                        Store<T>::load(slab_lane + o.z, v2);
+                        Store<T>::load(slab_lane + o.w, v3);
+                    } else {
+                        Store<T>::load(value + o.x, v0);
+                        Store<T>::load(value + o.y, v1);
+                        Store<T>::load(value + o.z, v2);
+                        Store<T>::load(value + o.w, v3);
+                    }
+                    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) {
+                        d0 = fmaf(g[c], v0[c], d0);
+                        d1 = fmaf(g[c], v1[c], d1);
+                        d2 = fmaf(g[c], v2[c], d2);
+                        d3 = fmaf(g[c], v3[c], d3);
+                    }
+                    d0 = (bits & 1) ? d0 : 0.f;
+                    d1 = (bits & 2) ? d1 : 0.f;
+                    d2 = (bits & 4) ? d2 : 0.f;
+                    d3 = (bits & 8) ? d3 : 0.f;
+                    d0 = row_sum<G>(d0); d1 = row_sum<G>(d1); d2 = row_sum<G>(d2); d3 = row_sum<G>(d3);
+                    if (sub == (pp % G)) {
+                        const float a = e.x, lh = e.y, lw = e.z, hh = 1.f - lh, hw = 1.f - lw;
+                        const Level lv = s_lvl[bits >> 4];
+                        const float g_aw = w.x * d0 + w.y * d1 + w.z * d2 + w.w * d3;
+                        const float g_w = hh * (d1 - d0) + lh * (d3 - d2);
+                        const float g_h = hw * (d2 - d0) + lw * (d3 - d1);
+                        s_e[r * kRowSlots + pp] = make_float4((float)lv.W * g_w * a, (float)lv.H * g_h * a, g_aw, 0.f);
+                    }
+                }
+                wave_sync();
+                if (r < rows_valid) {        // coalesced write-out, as in the tile kernel
+                    const int64_t idx0 = row * LP + pt0 + c0;
+                    const float *res = reinterpret_cast<const float *>(s_e + r * kRowSlots);
+                    for (int el = sub; el < 2 * np; el += G)
+                        Store<T>::put(gloc + 2 * idx0 + el, res[(el >> 1) * 4 + (el & 1)]);
+                    for (int el = sub; el < np; el += G)
+                        Store<T>::put(gaw + idx0 + el, res[el * 4 + 2]);
+                }
+                wave_sync();
+            }
+            if (s_bb) {      // this slot's tap-row intervals -> [group, head, virtual level, query]
+                const int64_t gm = ((int64_t)group * p.M + m) * nvl + vl0;
+                for (int i = lane; i < rows_valid * nlev; i += kWave) {
+                    const int l = i / rows_valid, rr = i - l * rows_valid;
+                    *reinterpret_cast<int2 *>(p.bbox + ((gm + l) * p.Lq + q0 + rr) * 2) =
+                        make_int2(s_bb[(rr * nlev + l) * 2], s_bb[(rr * nlev + l) * 2 + 1]);
+                }
+                wave_sync();
+            }
+        }
+    }
+}
+
 // ATOMICS = true : also scatters grad_value with global float atomics (one-kernel backward; used when
 //                  the LDS scatter kernel below cannot take the shape).
 // ATOMICS = false: computes grad_sampling_loc / grad_attn_weight only; grad_value comes from
@@ -1380,12 +1582,38 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     const int phases = env_int("MSDA_BWD_PHASES", 3);
     int rc = MSDA_OK;
     if (phases & 1) {
-        // (a slab variant of this pass, as for the forward, was built and measured: +4 % on the decoder
-        //  workload, -8 % on the encoder shape -- its point loop is VALU-heavier and its per-wave LDS only
-        //  leaves room for 12 waves per CU -- so the gather pass stays on the tile kernel)
-        hipLaunchKernelGGL((msda_bwd_tile_kernel<T, G, false>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
-        rc = check_launch("msda backward (tile kernel, grad_loc/grad_attn)");
-        if (rc) return rc;
+        bool done = false;
+        if (sizeof(T) == 4 && p.LA == p.L && p.L <= kSlabMaxLevels) {      // slab variant of the gather pass
+            const int tiles_per_clip = p.frames * ((p.Lq + RPW - 1) / RPW);
+            const int blocks_per_clip = (tiles_per_clip + kSlabWaves - 1) / kSlabWaves;
+            const int64_t slab_blocks = (int64_t)(p.groups / p.frames) * blocks_per_clip * p.M;
+            const int mode = env_int("MSDA_BWD_SLAB", -1);              // -1 auto, 0 off, 1 force
+            const size_t per_wave = (size_t)RPW * kRowSlots * 48 + (size_t)(p.LA + p.LB) * sizeof(Level) +
+                                    (p.bbox ? (size_t)RPW * p.L * 8 : 0);
+            const long long slab_bytes =
+                ((160 * 1024 - 1024 - (long long)kSlabWaves * (long long)per_wave) / 1024) * 1024;
+            if (mode != 0 && slab_bytes >= 16 * 1024 && (mode == 1 || slab_blocks >= 2 * device_cus()) &&
+                slab_blocks <= 0x7fffffffLL) {
+                const size_t total = (size_t)slab_bytes + kSlabWaves * per_wave;
+                static size_t limit_set = 0;
+                if (total > limit_set) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_slab_kernel<T, G>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)total) != hipSuccess)
+                        return fail(MSDA_ERR_HIP, "msda backward: cannot reserve the LDS budget of the slab kernel%s");
+                    limit_set = total;
+                }
+                hipLaunchKernelGGL((msda_bwd_slab_kernel<T, G>), dim3((unsigned)slab_blocks), dim3(kSlabThreads),
+                                   total, stream, p, (int)(slab_bytes / (long long)sizeof(T)), (int)per_wave);
+                rc = check_launch("msda backward (slab kernel, grad_loc/grad_attn)");
+                if (rc) return rc;
+                done = true;
+            }
+        }
+        if (!done) {
+            hipLaunchKernelGGL((msda_bwd_tile_kernel<T, G, false>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
+            rc = check_launch("msda backward (tile kernel, grad_loc/grad_attn)");
+            if (rc) return rc;
+        }
     }
     if (!(phases & 2)) return rc;
     // LDS budget: one 1024-thread workgroup per CU with 144 KiB of 8-byte accumulators

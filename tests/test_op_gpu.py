@@ -398,3 +398,22 @@ def test_forward_slab_kernel_forced(monkeypatch):
         got = _run_temporal(dt, torch.float32)
         assert _maxabs(got[0], ref) <= 2e-5 * max(1.0, np.abs(ref).max())
 
+
+
+def test_backward_slab_kernel_forced(monkeypatch):
+    """MSDA_BWD_SLAB=1 forces the slab variant of the backward gather pass on small shapes."""
+    monkeypatch.setenv("MSDA_BWD_SLAB", "1")
+    for name in ("op_devis_small", "op_batched_im2col", "op_out_of_range", "op_many_levels", "op_cfg1"):
+        g, d = _golden_dict(name)
+        out, gv, gl, ga = _run_op(d, torch.float32)
+        assert _maxabs(gv, g["grad_value"]) <= 2e-5 * max(1.0, np.abs(g["grad_value"]).max()), name
+        assert _maxabs(gl, g["grad_sampling_loc"]) <= 2e-5 * max(1.0, np.abs(g["grad_sampling_loc"]).max()), name
+        assert _maxabs(ga, g["grad_attn_weight"]) <= 2e-5 * max(1.0, np.abs(g["grad_attn_weight"]).max()), name
+    ftab = np.array([[1, 1], [0, 2], [1, 3], [2, 4], [3, 3]], dtype=np.int32)
+    for kw in (dict(T=4, W=3, ftab=None, Lq=37), dict(T=5, W=2, ftab=ftab, Lq=150)):
+        dt = make_temporal_inputs(49, kw["T"], kw["W"], 8, 32, kw["Lq"], [(9, 7), (5, 4), (3, 2)], 4, 2, ftab=kw["ftab"])
+        ref = temporal_reference(*(np.asarray(dt[k], dtype=np.float64) if dt[k].dtype.kind == "f" else dt[k]
+                                   for k in ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")))
+        got = _run_temporal(dt, torch.float32)
+        for a, b in zip(got, ref):
+            assert _maxabs(a, b) <= 2e-5 * max(1.0, np.abs(b).max())
