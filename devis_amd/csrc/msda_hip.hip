@@ -137,11 +137,13 @@ struct Params {
     void *grad_value;           // bwd: acc type, pre-zeroed
     void *glocA, *gawA, *glocB, *gawB;
     unsigned *workspace;        // bwd: 8 work-ticket counters of the scatter pass (zeroed by the caller) or null
-    int *bbox;                  // bwd: [groups, M, LA+LB, Lq, 2] (min, max) top tap row per (row, virtual level), written by
-                                // the gather pass, read by the scatter pass to cull rows; or null
+    int *bbox;                  // bwd: [groups, M, LA+LB, Lq, 2] (min, max) top tap row per (row, virtual level) -- or, with
+                                // cull_points, the top tap row of each of its <= 4 points as int16 (same 8 bytes) --
+                                // written by the gather pass, read by the scatter pass to cull rows; or null
     int groups, frames, window;
     int S, M, D, L, Lq;
     int LA, PA, LB, PB;
+    int cull_points;            // bbox entries are 4 x int16 top tap rows, one per POINT (PA, PB <= 4), not (min, max)
     int dbg;                    // measurement hooks (MSDA_DBG env), 0 in production
 };
 
@@ -277,6 +279,21 @@ __device__ __forceinline__ void load_chunk(const Params &p, const ChunkRef<T> &c
     }
 }
 
+// Culling record of one sampling point inside its (row, level) entry of the interval table: either widens
+// the (min, max) interval (ds_min/ds_max_i32) or, in point mode, stores the point's own top tap row as
+// int16 (rows beyond 32767 saturate: the scatter's test saturates the same way, so it stays conservative).
+constexpr int kNoRow16 = -32768;
+__device__ __forceinline__ void note_tap_row(int *entry, bool points, int pt, int valid, int hl)
+{
+    if (points) reinterpret_cast<short *>(entry)[pt] = valid ? (short)min(hl, 32767) : (short)kNoRow16;
+    else if (valid) { atomicMin(entry, hl); atomicMax(entry + 1, hl); }
+}
+__device__ __forceinline__ void init_tap_rows(int *entry, bool points)
+{
+    entry[0] = points ? (int)0x80008000u : 0x7fffffff;
+    entry[1] = points ? (int)0x80008000u : -0x7fffffff - 1;
+}
+
 // Builds the tap records of one chunk (<= kPch points of every row of the wave) in LDS.
 template <typename T, int RPW, bool BWD>
 __device__ __forceinline__ void build_chunk(const Params &p, const ChunkRef<T> &c,
@@ -298,9 +315,10 @@ __device__ __forceinline__ void build_chunk(const Params &p, const ChunkRef<T> &
             s_w[rr * kRowSlots + pp] = make_float4(t.w[0], t.w[1], t.w[2], t.w[3]);
             // a, fractions, and (valid bits | level index << 4) for the final gradient lane
             s_e[rr * kRowSlots + pp] = make_float4(a, t.lh, t.lw, __int_as_float(t.valid | (vl << 4)));
-            if (s_bb && t.valid) {      // interval of top tap rows of this (row, level): ds_min/ds_max_i32
-                atomicMin(s_bb + (rr * nvl + vl) * 2, t.hl);
-                atomicMax(s_bb + (rr * nvl + vl) * 2 + 1, t.hl);
+            if (s_bb) {
+                const int kk = min(c.p0 + pp, c.LP - 1);
+                if (c.p0 + pp < c.LP)
+                    note_tap_row(s_bb + (rr * nvl + vl) * 2, p.cull_points != 0, kk - (kk / c.P) * c.P, t.valid, t.hl);
             }
         } else {
             s_w[rr * kRowSlots + pp] = make_float4(t.w[0] * a, t.w[1] * a, t.w[2] * a, t.w[3] * a);
@@ -717,7 +735,7 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
             const int vl0 = sl < 0 ? 0 : p.LA + sl * L;
             const int npts = nlev * P;
             if (s_bb) {
-                for (int j = lane; j < RPW * nlev; j += kWave) { s_bb[2 * j] = 0x7fffffff; s_bb[2 * j + 1] = -0x7fffffff - 1; }
+                for (int j = lane; j < RPW * nlev; j += kWave) init_tap_rows(s_bb + 2 * j, p.cull_points != 0);
                 wave_sync();
             }
 #pragma unroll 1
@@ -745,10 +763,8 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
                     s_off[rr * kRowSlots + pp] = make_int4(tp.off[0], tp.off[1], tp.off[2], tp.off[3]);
                     s_w[rr * kRowSlots + pp] = make_float4(tp.w[0], tp.w[1], tp.w[2], tp.w[3]);
                     s_e[rr * kRowSlots + pp] = make_float4(a, tp.lh, tp.lw, __int_as_float(tp.valid | (vl << 4)));
-                    if (s_bb && tp.valid) {
-                        atomicMin(s_bb + (rr * nlev + l) * 2, tp.hl);
-                        atomicMax(s_bb + (rr * nlev + l) * 2 + 1, tp.hl);
-                    }
+                    if (s_bb && kk < npts)
+                        note_tap_row(s_bb + (rr * nlev + l) * 2, p.cull_points != 0, kk - l * P, tp.valid, tp.hl);
                 }
                 wave_sync();
                 const int np = min(kPch, npts - c0);
@@ -844,7 +860,7 @@ msda_bwd_tile_kernel(const Params p)
     int *s_bb = p.bbox ? reinterpret_cast<int *>(s_lvl + nvl) : nullptr;      // [RPW, nvl, 2]
     for (int j = lane; j < nvl; j += kWave) s_lvl[j] = make_level(p, t, j);
     if (s_bb)
-        for (int j = lane; j < RPW * nvl; j += kWave) { s_bb[2 * j] = 0x7fffffff; s_bb[2 * j + 1] = -0x7fffffff - 1; }
+        for (int j = lane; j < RPW * nvl; j += kWave) init_tap_rows(s_bb + 2 * j, p.cull_points != 0);
     __syncthreads();
 
     const int r = lane / G, sub = lane % G;
@@ -1102,15 +1118,15 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
 
         // sources that read frame f: the current-frame points of frame f, then every temporal slot
         // (t, w) with frame_table[t, w] == f (list built once per item; repeats allowed)
-        if (tid == 0) {
-            int n = 0;
-            s_src_t[n] = f; s_src_vl[n] = l; ++n;                       // k = 0: current-frame points
-            for (int tw = 0; tw < p.frames * p.window; ++tw)
-                if (p.ftab[tw] == f) {
-                    const int t = tw / p.window;
-                    s_src_t[n] = t; s_src_vl[n] = (tw - t * p.window) * L + l; ++n;
-                }
-            s_nsrc = (dbg & 4) ? 0 : n;
+        if (wave == 0) {        // frames * window <= 63: one wave tests every (t, w) at once and compacts
+            const int tw = lane, n_tw = p.frames * p.window;
+            const bool hit = tw < n_tw && p.ftab[tw] == f;
+            const u64 bal = __ballot(hit);
+            if (lane == 0) { s_src_t[0] = f; s_src_vl[0] = l; s_nsrc = (dbg & 4) ? 0 : 1 + (int)__popcll(bal); }
+            if (hit) {
+                const int n = 1 + (int)__popcll(bal & ((1ull << lane) - 1ull)), t = tw / p.window;
+                s_src_t[n] = t; s_src_vl[n] = (tw - t * p.window) * L + l;
+            }
         }
         __syncthreads();
         const int n_srcs = s_nsrc;
@@ -1214,6 +1230,13 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
             // of a corner it does own -- 4*VEC independent ds_add_f64 per lane, no exec-mask juggling.
             // Terms are the fp32 products the reference hands to atomicAdd (cuh:125-152), widened to
             // fp64 (one v_cvt_f64_f32) and summed in fp64.
+            if (dbg & 8) {          // measurement: everything but the LDS adds
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) acc += h.g[c];
+                if (acc * h.w0 == 123.456f) band[0] = 1.0;
+                return;
+            }
             const int o1 = D, o2 = W * D, o3 = (W + 1) * D;
             const int safe = (h.bits & 1) ? 0 : (h.bits & 2) ? o1 : (h.bits & 4) ? o2 : o3;
             const int a0 = (h.bits & 1) ? 0 : safe, a1 = (h.bits & 2) ? o1 : safe;
@@ -1230,12 +1253,12 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
             }
         };
 
-        // Cull in batches of one group per thread, appending survivors to s_list; the list is scanned
-        // when another batch might not fit (or the groups are exhausted), so that sparse survivors
-        // (local / clustered sampling) still fill whole scan passes.
         __syncthreads();
         if (tid == 0) s_count = 0;
         __syncthreads();
+        // Cull in batches of one group per thread, appending survivors to s_list; the list is scanned
+        // when another batch might not fit (or the groups are exhausted), so that sparse survivors
+        // (local / clustered sampling) still fill whole scan passes.
         for (int gi0 = 0; gi0 < n_groups || gi0 == 0; gi0 += kScatterThreads) {
         {
             const int gi = gi0 + tid;
@@ -1346,6 +1369,445 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
         __syncthreads();
     }
 }
+
+// msda_bwd_value_points_kernel -- the scatter for the common case PA, PB <= 4, where the gather pass
+// leaves the top tap row of every POINT (4 x int16 per (row, level)) in the workspace.  Same work items,
+// same band accumulators, same arithmetic and flush as msda_bwd_value_lds_kernel; what differs is
+//   * the cull keeps exactly the POINTS that have a row in the band and compacts them into the list as
+//     (source k : 6 | point : 2 | query : 24), so in the scan (nearly) every lane is a hit and stage 2
+//     deals lanes [R*RPW, R*RPW + RPW) to the teams in G fixed sub-rounds: no merge rounds, no scalar
+//     bit-select chain;
+//   * the items are SOFTWARE-PIPELINED: an item is ~800 hits, i.e. only ~6 hit groups per wave, so its
+//     fixed latencies (ticket, frame table, the cull's table reads, the scan's loc/attn reads) used to
+//     be exposed one after the other with all 16 waves waiting in lock-step.  Now wave 0 stages item
+//     i+2 (ticket, decode, source list) and every thread issues the cull loads of item i+1 BEFORE the
+//     scan of item i, compacts them after it, and issues the first scan pass of item i+1 before
+//     flushing the band of item i; the flush re-zeroes the band as it reads it.
+template <typename T, int G>
+__global__ void __launch_bounds__(kScatterThreads)
+msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
+{
+    constexpr int VEC = Store<T>::VEC;
+    constexpr int RPW = kWave / G;
+    constexpr int U = 2;                  // groups per thread per cull batch
+    constexpr int kBatch = U * kScatterThreads;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double *band = reinterpret_cast<double *>(lds_raw);
+    __shared__ int s_H[kScatterMaxLevels], s_W[kScatterMaxLevels], s_R[kScatterMaxLevels],
+        s_first[kScatterMaxLevels + 1], s_lsi[kScatterMaxLevels];
+    __shared__ int s_src_t[3][kScatterMaxSources], s_src_vl[3][kScatterMaxSources], s_nsrc[3];
+    __shared__ int s_dec[3][8];           // staged item: valid, l, m, f, clip, r0, r1, direct
+    __shared__ int s_list[kScatterList], s_cnt[3], s_valid;
+    __shared__ int s_ftab[kScatterMaxSources];      // the frame table, read once
+
+    const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+    const int D = p.D, MD = p.M * p.D, L = p.L, VL = p.LA + p.LB;
+    if (tid == 0) {
+        int first = 0;
+        for (int l = 0; l < L; ++l) {
+            const int H = (int)p.shapes[2 * l], W = (int)p.shapes[2 * l + 1];
+            const int R = min(H, cap_slots / max(1, W * D));     // rows per band; 0 = "direct" level
+            s_H[l] = H; s_W[l] = W; s_R[l] = R; s_lsi[l] = (int)p.lsi[l];
+            s_first[l] = first;
+            first += (R > 0) ? (H + R - 1) / R : 1;
+        }
+        s_first[L] = first;
+        s_cnt[0] = s_cnt[1] = s_cnt[2] = 0;
+        s_valid = 0;
+    }
+    if (tid < p.frames * p.window) s_ftab[tid] = p.ftab[tid];
+    __syncthreads();
+    const int NB = s_first[L];
+    const int clips = p.groups / p.frames;
+    const int64_t n_items = (int64_t)clips * p.frames * p.M * NB;
+    const int team = lane / G, sub = lane % G;
+    const bool dynamic = p.workspace != nullptr && (dbg & 16) == 0 && n_items < (int64_t)16 * gridDim.x;
+    const int lane8 = blockIdx.x % 8;
+
+    struct Item { int valid, l, m, f, clip, r0, r1, direct, H, W; };
+
+    // wave 0: draw the seq-th item of this workgroup, decode it, list the sources that read its frame
+    auto stage_item = [&](int64_t seq, int buf) {
+        unsigned lo32 = 0, hi32 = 0;
+        if (lane == 0) {
+            const int64_t id = dynamic ? (int64_t)atomicAdd(p.workspace + lane8, 1u) * 8 + lane8
+                                       : (int64_t)blockIdx.x + seq * gridDim.x;
+            lo32 = (unsigned)id; hi32 = (unsigned)((u64)id >> 32);
+        }
+        lo32 = __builtin_amdgcn_readfirstlane(lo32); hi32 = __builtin_amdgcn_readfirstlane(hi32);
+        const int64_t item = (int64_t)(((u64)hi32 << 32) | lo32);
+        if (item >= n_items) { if (lane == 0) s_dec[buf][0] = 0; return; }
+        int l, part, m, f, clip;
+        if (dynamic) {      // heaviest first: levels from the last to the first (see msda_bwd_value_lds_kernel)
+            const int64_t ctm = (int64_t)clips * p.frames * p.M;
+            l = L - 1;
+            int64_t local = item;
+            while (l > 0 && local >= ctm * (s_first[l + 1] - s_first[l])) {
+                local -= ctm * (s_first[l + 1] - s_first[l]);
+                --l;
+            }
+            const unsigned nb_l = (unsigned)(s_first[l + 1] - s_first[l]);
+            unsigned rest = (unsigned)local;                 // dynamic => n_items < 16 * grid: fits 32 bits
+            m = (int)(rest % (unsigned)p.M); rest /= (unsigned)p.M;
+            part = s_first[l] + (int)(rest % nb_l); rest /= nb_l;
+            f = (int)(rest % (unsigned)p.frames);
+            clip = (int)(rest / (unsigned)p.frames);
+        } else if (n_items < 0x7fffffffLL) {
+            unsigned rest = (unsigned)item;
+            m = (int)(rest % (unsigned)p.M); rest /= (unsigned)p.M;
+            part = (int)(rest % (unsigned)NB); rest /= (unsigned)NB;
+            f = (int)(rest % (unsigned)p.frames);
+            clip = (int)(rest / (unsigned)p.frames);
+            l = 0;
+            while (l + 1 < L && s_first[l + 1] <= part) ++l;
+        } else {
+            m = (int)(item % p.M);
+            int64_t rest = item / p.M;
+            part = (int)(rest % NB); rest /= NB;
+            f = (int)(rest % p.frames);
+            clip = (int)(rest / p.frames);
+            l = 0;
+            while (l + 1 < L && s_first[l + 1] <= part) ++l;
+        }
+        const int H = s_H[l], R = s_R[l];
+        const bool direct = (R == 0);
+        const int r0 = direct ? 0 : (part - s_first[l]) * R;
+        const int r1 = direct ? H - 1 : min(H, r0 + R) - 1;
+        const int n_tw = p.frames * p.window;
+        const bool hit = lane < n_tw && s_ftab[lane] == f;
+        const u64 bal = __ballot(hit);
+        if (lane == 0) {
+            s_dec[buf][0] = 1; s_dec[buf][1] = l; s_dec[buf][2] = m; s_dec[buf][3] = f; s_dec[buf][4] = clip;
+            s_dec[buf][5] = r0; s_dec[buf][6] = r1; s_dec[buf][7] = direct ? 1 : 0;
+            s_src_t[buf][0] = f; s_src_vl[buf][0] = l;
+            s_nsrc[buf] = (dbg & 4) ? 0 : 1 + (int)__popcll(bal);
+        }
+        if (hit) {
+            const int n = 1 + (int)__popcll(bal & ((1ull << lane) - 1ull)), t = lane / p.window;
+            s_src_t[buf][n] = t; s_src_vl[buf][n] = (lane - t * p.window) * L + l;
+        }
+    };
+    auto load_item = [&](int buf) {
+        Item it;
+        it.valid = s_dec[buf][0];
+        it.l = s_dec[buf][1]; it.m = s_dec[buf][2]; it.f = s_dec[buf][3]; it.clip = s_dec[buf][4];
+        it.r0 = s_dec[buf][5]; it.r1 = s_dec[buf][6]; it.direct = s_dec[buf][7];
+        it.H = it.valid ? s_H[it.l] : 1; it.W = it.valid ? s_W[it.l] : 1;
+        return it;
+    };
+    auto source_of = [&](int buf, int k, int &t, int &vl, int &vlg, int &P, int &LP, const T *&loc, const T *&aw) {
+        t = s_src_t[buf][k]; vl = s_src_vl[buf][k];
+        const bool cur = (k == 0);
+        vlg = cur ? vl : p.LA + vl;
+        P = cur ? p.PA : p.PB;
+        LP = cur ? p.LA * p.PA : p.LB * p.PB;
+        loc = static_cast<const T *>(cur ? p.locA : p.locB);
+        aw = static_cast<const T *>(cur ? p.awA : p.awB);
+    };
+    // the per-point rows of U groups per thread, all loads in flight together
+    auto cull_load = [&](const Item &it, int buf, int gi0, int2 (&iv)[U], unsigned (&ent)[U]) {
+        const int ng = s_nsrc[buf] * p.Lq;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int gi = gi0 + u * kScatterThreads + tid;
+            iv[u] = make_int2((int)0x80008000u, (int)0x80008000u);
+            ent[u] = 0u;
+            if (gi < ng) {
+                const int k = gi / p.Lq, q = gi - k * p.Lq;
+                int t, vl, vlg, P, LP;
+                const T *loc, *aw;
+                source_of(buf, k, t, vl, vlg, P, LP, loc, aw);
+                const int64_t gm = (((int64_t)it.clip * p.frames + t) * p.M + it.m) * VL + vlg;
+                iv[u] = *reinterpret_cast<const int2 *>(p.bbox + (gm * p.Lq + q) * 2);
+                ent[u] = ((unsigned)k << 26) | (unsigned)q;
+            }
+        }
+    };
+    struct Marks { u64 bal[4 * U]; int total; };
+    auto mark = [&](const Item &it, const int2 (&iv)[U]) {
+        Marks mk;
+        mk.total = 0;
+        const int lo = min(it.r0 - 1, 32767), hi = min(it.r1, 32767);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int hr[4] = {(int)(short)(iv[u].x & 0xffff), iv[u].x >> 16, (int)(short)(iv[u].y & 0xffff), iv[u].y >> 16};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mk.bal[4 * u + j] = __ballot(hr[j] >= lo && hr[j] <= hi);
+                mk.total += (int)__popcll(mk.bal[4 * u + j]);
+            }
+        }
+        return mk;
+    };
+    // One attempt at appending a batch's surviving points behind the `listed` entries of s_list, with ONE
+    // workgroup barrier: every wave that still has entries (`pendw`) reserves a range with one atomic on
+    // the batch's relative counter and writes it if it ends inside the list.  Ranges are handed out in
+    // order, so when the batch does not fit the written entries are a prefix that ends where the first
+    // failing wave starts (s_valid).  Counters rotate over three slots: slot j is reset two barriers
+    // before it is used again, so no wave can still be reading it.  Returns the batch's entry count.
+    int ci = 0;
+    auto try_add = [&](const Marks &mk, const unsigned (&ent)[U], bool pendw, int listed, bool &fit) {
+        int wbase = 0;
+        if (lane == 0 && pendw) wbase = atomicAdd(&s_cnt[ci], mk.total);
+        wbase = __shfl(wbase, 0, kWave);
+        fit = pendw && listed + wbase + mk.total <= kScatterList;
+        if (fit) {
+            int off = listed + wbase;
+#pragma unroll
+            for (int b = 0; b < 4 * U; ++b) {
+                if ((mk.bal[b] >> lane) & 1ull)
+                    s_list[off + (int)__popcll(mk.bal[b] & ((1ull << lane) - 1ull))] = (int)(ent[b / 4] | ((unsigned)(b & 3) << 24));
+                off += (int)__popcll(mk.bal[b]);
+            }
+        } else if (pendw && listed + wbase <= kScatterList && lane == 0) {
+            s_valid = listed + wbase;
+        }
+        __syncthreads();
+        const int rel = s_cnt[ci];
+        if (tid == 0) s_cnt[(ci + 2) % 3] = 0;
+        ci = (ci + 1) % 3;
+        return rel;
+    };
+
+    struct Hit { int pix, bits; float w0, w1, w2, w3; float g[VEC]; };
+    Hit pend;
+    pend.bits = 0;
+    auto consume = [&](const Item &it, const Hit &h) {
+        if (!h.bits) return;
+        const int W = it.W;
+        if (it.direct) {
+            float *gmap = static_cast<float *>(p.grad_value) +
+                          (((int64_t)it.clip * p.frames + it.f) * p.S + s_lsi[it.l]) * MD + it.m * D;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                float *dst = gmap + (int64_t)h.pix * MD + ((c + team) % VEC) * G + sub;
+                if (h.bits & 1) atomic_accumulate(dst, h.w0 * h.g[c]);
+                if (h.bits & 2) atomic_accumulate(dst + MD, h.w1 * h.g[c]);
+                if (h.bits & 4) atomic_accumulate(dst + (int64_t)W * MD, h.w2 * h.g[c]);
+                if (h.bits & 8) atomic_accumulate(dst + (int64_t)(W + 1) * MD, h.w3 * h.g[c]);
+            }
+            return;
+        }
+        // branch-free ds_add_f64, exactly as in msda_bwd_value_lds_kernel
+        const int o1 = D, o2 = W * D, o3 = (W + 1) * D;
+        const int safe = (h.bits & 1) ? 0 : (h.bits & 2) ? o1 : (h.bits & 4) ? o2 : o3;
+        const int a0 = (h.bits & 1) ? 0 : safe, a1 = (h.bits & 2) ? o1 : safe;
+        const int a2 = (h.bits & 4) ? o2 : safe, a3 = (h.bits & 8) ? o3 : safe;
+        double *pixel = band + h.pix * D;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            double *dst = pixel + ((c + team) % VEC) * G + sub;
+            unsafeAtomicAdd(dst + a0, (double)(h.w0 * h.g[c]));
+            unsafeAtomicAdd(dst + a1, (double)(h.w1 * h.g[c]));
+            unsafeAtomicAdd(dst + a2, (double)(h.w2 * h.g[c]));
+            unsafeAtomicAdd(dst + a3, (double)(h.w3 * h.g[c]));
+        }
+    };
+    auto fetchp = [&](const Item &it, int buf, int i, int listed, float &x, float &y, float &a, int &qrow) {
+        x = y = -10.f; a = 0.f; qrow = 0;
+        if (i < listed) {
+            const unsigned e = (unsigned)s_list[i];
+            int t, vl, vlg, P, LP;
+            const T *loc, *aw;
+            source_of(buf, (int)(e >> 26), t, vl, vlg, P, LP, loc, aw);
+            const int64_t gq = ((int64_t)it.clip * p.frames + t) * p.Lq + (int)(e & 0xffffffu);
+            const int64_t idx = (gq * p.M + it.m) * LP + vl * P + (int)((e >> 24) & 3u);
+            x = Store<T>::get(loc + 2 * idx);
+            y = Store<T>::get(loc + 2 * idx + 1);
+            a = Store<T>::get(aw + idx);
+            qrow = (int)gq;
+        }
+    };
+    // Scans the `listed` points of s_list (one per lane per pass); `primed`: the first pass's (x, y, attn)
+    // are already in (x, y, a, qrow).  No barrier: the caller separates it from the next list write.
+    auto scan_points = [&](const Item &it, int buf, int listed, bool primed, float &x, float &y, float &a, int &qrow) {
+        const int H = it.H, W = it.W, r0 = it.r0, r1 = it.r1;
+        if (!primed) fetchp(it, buf, tid, listed, x, y, a, qrow);
+        for (int base = 0; base < listed; base += kScatterThreads) {
+            int pix = 0, bits = 0;
+            const int qr = qrow;
+            float wa0 = 0.f, wa1 = 0.f, wa2 = 0.f, wa3 = 0.f;
+            const float h_im = __fsub_rn(__fmul_rn(y, (float)H), 0.5f);
+            const float w_im = __fsub_rn(__fmul_rn(x, (float)W), 0.5f);
+            if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                const float hf = floorf(h_im), wf = floorf(w_im);
+                const int h_low = (int)hf, w_low = (int)wf;
+                const bool top = h_low >= max(r0, 0) && h_low <= r1;          // rows this band owns
+                const bool bot = h_low + 1 >= r0 && h_low + 1 <= min(r1, H - 1);
+                const bool x0 = w_low >= 0, x1 = w_low + 1 <= W - 1;
+                bits = (top && x0 ? 1 : 0) | (top && x1 ? 2 : 0) | (bot && x0 ? 4 : 0) | (bot && x1 ? 8 : 0);
+                const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+                wa0 = (top && x0) ? hh * hw * a : 0.f; wa1 = (top && x1) ? hh * lw * a : 0.f;
+                wa2 = (bot && x0) ? lh * hw * a : 0.f; wa3 = (bot && x1) ? lh * lw * a : 0.f;
+                pix = (h_low - r0) * W + w_low;
+            }
+            fetchp(it, buf, base + kScatterThreads + tid, listed, x, y, a, qrow);      // next pass's loads fly
+            if (dbg & 2) continue;
+            const u64 mask = __ballot(bits != 0);
+#pragma unroll 1
+            for (int R = 0; R < G; ++R) {
+                const u64 part = RPW == kWave ? mask : (mask >> (R * RPW)) & ((1ull << (RPW % kWave)) - 1ull);
+                if (!part) continue;
+                const int from = R * RPW + team;
+                Hit h;
+                h.pix = __shfl(pix, from, kWave);
+                h.bits = __shfl(bits, from, kWave);
+                const int h_q = __shfl(qr, from, kWave);
+                h.w0 = __shfl(wa0, from, kWave); h.w1 = __shfl(wa1, from, kWave);
+                h.w2 = __shfl(wa2, from, kWave); h.w3 = __shfl(wa3, from, kWave);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) h.g[c] = 0.f;
+                if (h.bits) {
+                    const T *go = static_cast<const T *>(p.grad_out) + (int64_t)h_q * MD + it.m * D;
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) h.g[c] = Store<T>::get(go + ((c + team) % VEC) * G + sub);
+                }
+                consume(it, pend);
+                pend = h;
+            }
+        }
+    };
+    // Lists one batch; when it does not fit, scans the written prefix and retries the waves that failed.
+    auto add_batch = [&](const Item &it, int buf, const Marks &mk, const unsigned (&ent)[U], int listed,
+                         float &x, float &y, float &a, int &qrow) {
+        bool pendw = mk.total > 0;
+        for (;;) {
+            bool fit;
+            const int rel = try_add(mk, ent, pendw, listed, fit);
+            if (listed + rel <= kScatterList) return listed + rel;
+            scan_points(it, buf, s_valid, false, x, y, a, qrow);
+            __syncthreads();
+            listed = 0;
+            pendw = pendw && !fit;
+        }
+    };
+
+    // Flushes 16-byte vectors [v0, v1) of the item's band as float(sum) with plain coalesced stores
+    // (D floats per pixel at stride M*D), re-zeroing the band on the way.
+    auto flush = [&](const Item &it, int v0, int v1) {
+        const int vec_per_pix = D / 4;
+        float *gband = static_cast<float *>(p.grad_value) +
+                       (((int64_t)it.clip * p.frames + it.f) * p.S + s_lsi[it.l] + (int64_t)it.r0 * it.W) * MD + it.m * D;
+        for (int i = v0 + tid; i < v1; i += kScatterThreads) {
+            const int pix = i / vec_per_pix, c4 = i - pix * vec_per_pix;
+            double *src = band + i * 4;
+            const double2 lo2 = *reinterpret_cast<const double2 *>(src), hi2 = *reinterpret_cast<const double2 *>(src + 2);
+            *reinterpret_cast<uint4 *>(src) = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4 *>(src + 2) = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<float4 *>(gband + (int64_t)pix * MD + c4 * 4) =
+                make_float4((float)lo2.x, (float)lo2.y, (float)hi2.x, (float)hi2.y);
+        }
+    };
+
+    // ---- prologue: stage item 0 (and 1), zero the band, cull + prime item 0.
+    // With a STATIC item order the pipeline runs two items ahead (item i+1's table reads fly during the
+    // scan of item i).  With dynamic tickets an item is claimed only when the previous one has been
+    // scanned -- a workgroup sitting on a heavy item must not hoard work the others could take -- and
+    // its table reads overlap the first half of the flush instead.
+    int bc = 0, bn = 1, bnn = 2;
+    if (wave == 0) { stage_item(0, bc); if (!dynamic) stage_item(1, bn); else if (lane == 0) s_dec[bn][0] = 0; }
+    for (int i = tid * 2; i < cap_slots; i += kScatterThreads * 2)
+        *reinterpret_cast<uint4 *>(band + i) = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    Item cur = load_item(bc), nxt = load_item(bn);
+    int64_t seq = dynamic ? 1 : 2;
+    int2 iv[U];
+    unsigned ent[U];
+    float x = -10.f, y = -10.f, a = 0.f;
+    int qrow = 0;
+    int cur_listed = 0;
+    bool cur_overflow = false;
+    if (cur.valid) {
+        cull_load(cur, bc, 0, iv, ent);
+        const Marks mk = mark(cur, iv);
+        bool fit;
+        const int rel = try_add(mk, ent, mk.total > 0, 0, fit);
+        if (rel > kScatterList) cur_overflow = true;
+        else { cur_listed = rel; fetchp(cur, bc, tid, cur_listed, x, y, a, qrow); }
+    }
+    while (cur.valid) {
+        // (a) wave 0 stages the item after next; the next item's table reads start now and land while
+        //     this item is scanned
+        if (!dynamic) {
+            if (wave == 0) stage_item(seq, bnn);
+            ++seq;
+            if (nxt.valid) cull_load(nxt, bn, 0, iv, ent);
+        }
+        // (b) scan this item
+        {
+            const int ng = s_nsrc[bc] * p.Lq;
+            int listed = cur_listed;
+            int2 iv2[U];
+            unsigned ent2[U], ent3[U];
+            if (cur_overflow) {         // the first batch did not fit when it was compacted early: redo it here
+                cull_load(cur, bc, 0, iv2, ent2);
+                const Marks mk = mark(cur, iv2);
+                __syncthreads();
+                listed = add_batch(cur, bc, mk, ent2, 0, x, y, a, qrow);
+                if (ng > kBatch) cull_load(cur, bc, kBatch, iv2, ent2);
+                if (ng <= kBatch || listed >= kScatterThreads) {
+                    scan_points(cur, bc, listed, false, x, y, a, qrow);
+                    __syncthreads();
+                    listed = 0;
+                }
+            } else {
+                if (ng > kBatch) cull_load(cur, bc, kBatch, iv2, ent2);
+                if (ng <= kBatch || listed >= kScatterThreads) {
+                    scan_points(cur, bc, listed, true, x, y, a, qrow);
+                    if (ng > kBatch) __syncthreads();
+                    listed = 0;
+                }   // else: a sparse first batch of many -- keep accumulating (the primed pass is dropped)
+            }
+            for (int gi0 = kBatch; gi0 < ng; gi0 += kBatch) {
+                const Marks mk = mark(cur, iv2);
+#pragma unroll
+                for (int u = 0; u < U; ++u) ent3[u] = ent2[u];
+                if (gi0 + kBatch < ng) cull_load(cur, bc, gi0 + kBatch, iv2, ent2);      // next batch's reads fly
+                listed = add_batch(cur, bc, mk, ent3, listed, x, y, a, qrow);
+                if (gi0 + kBatch < ng && listed < kScatterThreads) continue;      // not yet a full pass
+                scan_points(cur, bc, listed, false, x, y, a, qrow);
+                if (gi0 + kBatch < ng) __syncthreads();
+                listed = 0;
+            }
+        }
+        // (c) last hit group of this item
+        consume(cur, pend);
+        pend.bits = 0;
+        if (dynamic) {                  // claim the next item now that this one is scanned
+            if (wave == 0) stage_item(seq, bn);
+            ++seq;
+        }
+        __syncthreads();                // (d) every add of this item is in the band; s_list is free
+        if (dynamic) {
+            nxt = load_item(bn);
+            if (nxt.valid) cull_load(nxt, bn, 0, iv, ent);
+        }
+        const int flush_vecs = cur.direct ? 0 : (cur.r1 - cur.r0 + 1) * cur.W * D / 4;
+        flush(cur, 0, flush_vecs / 2);  // first half of the flush hides the table reads (dynamic order)
+        // (e) compact the next item's first batch and start its first scan pass
+        int nxt_listed = 0;
+        bool nxt_overflow = false;
+        if (nxt.valid) {
+            const Marks mk = mark(nxt, iv);
+            bool fit;
+            const int rel = try_add(mk, ent, mk.total > 0, 0, fit);
+            if (rel > kScatterList) nxt_overflow = true;
+            else { nxt_listed = rel; fetchp(nxt, bn, tid, nxt_listed, x, y, a, qrow); }
+        }
+        // (f) the rest of the flush hides the first scan pass's reads
+        flush(cur, flush_vecs / 2, flush_vecs);
+        __syncthreads();
+        cur = nxt; cur_listed = nxt_listed; cur_overflow = nxt_overflow;
+        if (dynamic) {
+            const int tmp = bc; bc = bn; bn = tmp;
+            nxt.valid = 0;
+        } else {
+            nxt = load_item(bnn);
+            const int tmp = bc; bc = bn; bn = bnn; bnn = tmp;
+        }
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // generic kernels: any D / M / L / P, any dtype (fp64 included).  Correctness path for shapes the
@@ -1527,7 +1989,7 @@ bool scatter_applicable(const Params &p)
     const char *mode = getenv("MSDA_BWD_MODE");
     if (mode && !strcmp(mode, "atomic")) return false;
     if (p.L > kScatterMaxLevels || (p.D % 4) != 0) return false;
-    if (1 + p.frames * p.window > kScatterMaxSources || p.Lq >= (1 << 24)) return false;
+    if (1 + p.frames * p.window > kScatterMaxSources || p.Lq >= (1 << 24)) return false;   // survivor-list entry fields
     if (p.window == 0 && p.LA != p.L) return false;
     return true;
 }
@@ -1628,6 +2090,18 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
             return fail(MSDA_ERR_HIP, "msda backward: cannot reserve the requested LDS budget%s");
         lds_limit_set = cap_bytes;
     }
+    if (p.cull_points) {
+        static int lds_limit_points = 0;
+        if (cap_bytes > lds_limit_points) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_value_points_kernel<T, G>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, cap_bytes) != hipSuccess)
+                return fail(MSDA_ERR_HIP, "msda backward: cannot reserve the LDS budget of the scatter kernel%s");
+            lds_limit_points = cap_bytes;
+        }
+        hipLaunchKernelGGL((msda_bwd_value_points_kernel<T, G>), dim3(grid), dim3(kScatterThreads),
+                           (size_t)cap_bytes, stream, p, cap_bytes / 8, env_int("MSDA_SCATTER_DBG", 0));
+        return check_launch("msda backward (LDS scatter kernel, per-point culling)");
+    }
     hipLaunchKernelGGL((msda_bwd_value_lds_kernel<T, G>), dim3(grid), dim3(kScatterThreads),
                        (size_t)cap_bytes, stream, p, cap_bytes / 8, env_int("MSDA_SCATTER_DBG", 0));
     return check_launch("msda backward (LDS scatter kernel)");
@@ -1686,6 +2160,8 @@ int run(int dtype, const Params &p_in, bool bwd, hipStream_t stream)
 {
     Params p = p_in;
     p.dbg = env_int("MSDA_DBG", 0);
+    // culling records per point when a level has <= 4 points (MSDA_BWD_CULL=2: force (min, max) intervals)
+    p.cull_points = bwd && p.bbox && p.PA <= 4 && p.PB <= 4 && env_int("MSDA_BWD_CULL", 1) != 2;
     if (p.groups == 0 || p.Lq == 0) return MSDA_OK;
     bool taken = false;
     int rc = MSDA_OK;

@@ -11,7 +11,9 @@ b = bench.make_clip_batch(a, dev, dt, 1)
 gv = torch.zeros(b["value"].shape, dtype=torch.float32, device=dev)
 gl_c, ga_c = torch.empty_like(b["loc_c"]), torch.empty_like(b["aw_c"])
 gl_t, ga_t = torch.empty_like(b["loc_t"]), torch.empty_like(b["aw_t"])
+T, M, W, L = a.frames, b["value"].shape[2], b["ftab"].shape[1], b["shapes"].shape[0]
 for _ in range(3):
-    _native.temporal_backward(b["value"], b["shapes"], b["lsi"], b["ftab"], b["loc_c"], b["aw_c"], b["loc_t"], b["aw_t"], b["grad_out"], a.clips, gv, gl_c, ga_c, gl_t, ga_t)
+    ws = _native.bwd_workspace(dev, a.clips * T, a.queries, M, L * (1 + W))
+    _native.temporal_backward(b["value"], b["shapes"], b["lsi"], b["ftab"], b["loc_c"], b["aw_c"], b["loc_t"], b["aw_t"], b["grad_out"], a.clips, gv, gl_c, ga_c, gl_t, ga_t, workspace=ws)
 torch.cuda.synchronize()
 print("done")
