@@ -1392,7 +1392,8 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
     constexpr int U = 2;                  // groups per thread per cull batch
     constexpr int kBatch = U * kScatterThreads;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    double *band = reinterpret_cast<double *>(lds_raw);
+    double *band = reinterpret_cast<double *>(lds_raw) + G * VEC;       // one guard pixel before (and after) the band
+    cap_slots -= 2 * G * VEC;
     __shared__ int s_H[kScatterMaxLevels], s_W[kScatterMaxLevels], s_R[kScatterMaxLevels],
         s_first[kScatterMaxLevels + 1], s_lsi[kScatterMaxLevels];
     __shared__ int s_src_t[3][kScatterMaxSources], s_src_vl[3][kScatterMaxSources], s_nsrc[3];
@@ -1588,19 +1589,29 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
             }
             return;
         }
-        // branch-free ds_add_f64, exactly as in msda_bwd_value_lds_kernel
-        const int o1 = D, o2 = W * D, o3 = (W + 1) * D;
-        const int safe = (h.bits & 1) ? 0 : (h.bits & 2) ? o1 : (h.bits & 4) ? o2 : o3;
-        const int a0 = (h.bits & 1) ? 0 : safe, a1 = (h.bits & 2) ? o1 : safe;
-        const int a2 = (h.bits & 4) ? o2 : safe, a3 = (h.bits & 8) ? o3 : safe;
-        double *pixel = band + h.pix * D;
+        if (dbg & 8) {          // measurement: everything but the LDS adds
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) acc += h.g[c];
+            if (acc * h.w0 == 123.456f) band[0] = 1.0;
+            return;
+        }
+        // Branch-free ds_add_f64 (terms as in msda_bwd_value_lds_kernel).  The weights of corners this band
+        // does not own are already 0; such a corner adds 0.0 at a harmless address: a row the band does
+        // not own is replaced by the other row of the point, a column outside the map falls on the
+        // neighbouring pixel (one guard pixel sits before and after the band).  With D = G * VEC a
+        // compile-time constant the x+1 corner is an immediate offset of the same address register.
+        constexpr int kD = G * VEC;
+        const int top_pix = (h.bits & 3) ? h.pix : h.pix + W;
+        const int bot_pix = (h.bits & 12) ? h.pix + W : h.pix;
+        double *top = band + top_pix * kD + sub, *bot = band + bot_pix * kD + sub;
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
-            double *dst = pixel + ((c + team) % VEC) * G + sub;
-            unsafeAtomicAdd(dst + a0, (double)(h.w0 * h.g[c]));
-            unsafeAtomicAdd(dst + a1, (double)(h.w1 * h.g[c]));
-            unsafeAtomicAdd(dst + a2, (double)(h.w2 * h.g[c]));
-            unsafeAtomicAdd(dst + a3, (double)(h.w3 * h.g[c]));
+            const int ch = ((c + team) % VEC) * G;
+            unsafeAtomicAdd(top + ch, (double)(h.w0 * h.g[c]));
+            unsafeAtomicAdd(top + ch + kD, (double)(h.w1 * h.g[c]));
+            unsafeAtomicAdd(bot + ch, (double)(h.w2 * h.g[c]));
+            unsafeAtomicAdd(bot + ch + kD, (double)(h.w3 * h.g[c]));
         }
     };
     auto fetchp = [&](const Item &it, int buf, int i, int listed, float &x, float &y, float &a, int &qrow) {
@@ -1657,7 +1668,7 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
                 h.w2 = __shfl(wa2, from, kWave); h.w3 = __shfl(wa3, from, kWave);
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) h.g[c] = 0.f;
-                if (h.bits) {
+                if (h.bits && !(dbg & 32)) {
                     const T *go = static_cast<const T *>(p.grad_out) + (int64_t)h_q * MD + it.m * D;
 #pragma unroll
                     for (int c = 0; c < VEC; ++c) h.g[c] = Store<T>::get(go + ((c + team) % VEC) * G + sub);
@@ -1706,8 +1717,8 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
     // its table reads overlap the first half of the flush instead.
     int bc = 0, bn = 1, bnn = 2;
     if (wave == 0) { stage_item(0, bc); if (!dynamic) stage_item(1, bn); else if (lane == 0) s_dec[bn][0] = 0; }
-    for (int i = tid * 2; i < cap_slots; i += kScatterThreads * 2)
-        *reinterpret_cast<uint4 *>(band + i) = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid * 2; i < cap_slots + 2 * G * VEC; i += kScatterThreads * 2)
+        *reinterpret_cast<uint4 *>(band - G * VEC + i) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     Item cur = load_item(bc), nxt = load_item(bn);
     int64_t seq = dynamic ? 1 : 2;
@@ -1808,6 +1819,27 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
     }
 }
 
+
+// The LDS scatter kernels OVERWRITE every pixel of a level whose row fits the band budget.  Pixels they
+// do not own -- levels that take the float-atomic branch, or rows of `value` outside every level when
+// spatial_shapes does not tile [0, S) -- are zero-filled here, so that callers need not memset grad_value.
+__global__ void __launch_bounds__(256)
+msda_zero_unowned_kernel(const Params p, int cap_slots)
+{
+    const int MD = p.M * p.D;
+    const int64_t total = (int64_t)p.groups * p.S;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = idx % p.S;
+        bool owned = false;
+        for (int l = 0; l < p.L; ++l) {
+            const int64_t H = p.shapes[2 * l], W = p.shapes[2 * l + 1], start = p.lsi[l];
+            if (s >= start && s < start + H * W) { owned = cap_slots / max((int64_t)1, W * p.D) > 0; break; }
+        }
+        if (owned) continue;
+        float *dst = static_cast<float *>(p.grad_value) + idx * MD;
+        for (int c = 0; c < MD; ++c) dst[c] = 0.f;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // generic kernels: any D / M / L / P, any dtype (fp64 included).  Correctness path for shapes the
@@ -2036,6 +2068,8 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
         return check_launch("msda forward (tile kernel)");
     }
     if (!scatter_applicable(p)) {
+        if (hipMemsetAsync(p.grad_value, 0, (size_t)p.groups * p.S * p.M * p.D * sizeof(float), stream) != hipSuccess)
+            return fail(MSDA_ERR_HIP, "msda backward: hipMemsetAsync(grad_value) failed%s");
         hipLaunchKernelGGL((msda_bwd_tile_kernel<T, G, true>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
         return check_launch("msda backward (tile kernel, global atomics)");
     }
@@ -2090,6 +2124,15 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
             return fail(MSDA_ERR_HIP, "msda backward: cannot reserve the requested LDS budget%s");
         lds_limit_set = cap_bytes;
     }
+    {
+        // pixels the scatter will not overwrite (normally none) are zero-filled first
+        const int slots = cap_bytes / 8 - (p.cull_points ? 2 * p.D : 0);
+        const int64_t rows = (int64_t)p.groups * p.S;
+        const unsigned zb = (unsigned)((rows + 255) / 256 < 16384 ? (rows + 255) / 256 : 16384);
+        hipLaunchKernelGGL(msda_zero_unowned_kernel, dim3(zb), dim3(256), 0, stream, p, slots);
+        rc = check_launch("msda backward (zero-fill of pixels outside the LDS bands)");
+        if (rc) return rc;
+    }
     if (p.cull_points) {
         static int lds_limit_points = 0;
         if (cap_bytes > lds_limit_points) {
@@ -2139,6 +2182,8 @@ int launch_generic(const Params &p, bool bwd, hipStream_t stream)
 {
     const int64_t rows = (int64_t)p.groups * p.Lq * p.M;
     if (bwd) {
+        if (hipMemsetAsync(p.grad_value, 0, (size_t)p.groups * p.S * p.M * p.D * sizeof(A), stream) != hipSuccess)
+            return fail(MSDA_ERR_HIP, "msda backward: hipMemsetAsync(grad_value) failed%s");
         const unsigned blocks = (unsigned)(rows < 65536 * 16 ? rows : 65536 * 16);
         hipLaunchKernelGGL((msda_bwd_generic_kernel<T, A>), dim3(blocks), dim3(kWave), 0, stream, p, rows);
         return check_launch("msda backward (generic kernel)");
@@ -2192,6 +2237,16 @@ int check_common(const void *value, const int64_t *shapes, const int64_t *lsi, i
     if (!value || !shapes || !lsi) return fail(MSDA_ERR_ARG, "msda: null pointer argument%s");
     if (groups < 0 || Lq < 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0)
         return fail(MSDA_ERR_ARG, "msda: sizes must be positive%s");
+    return MSDA_OK;
+}
+
+int zero_grad_value(int dtype, void *grad_value, int groups, int S, int M, int D, void *stream)
+{
+    if (dtype < MSDA_F32 || dtype > MSDA_F16) return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
+    if (!grad_value) return fail(MSDA_ERR_ARG, "msda backward: null grad_value%s");
+    const size_t bytes = (size_t)groups * S * M * D * (dtype == MSDA_F64 ? sizeof(double) : sizeof(float));
+    if (hipMemsetAsync(grad_value, 0, bytes, static_cast<hipStream_t>(stream)) != hipSuccess)
+        return fail(MSDA_ERR_HIP, "msda backward: hipMemsetAsync(grad_value) failed%s");
     return MSDA_OK;
 }
 
@@ -2256,7 +2311,8 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
     int rc = check_common(value, spatial_shapes, level_start_index, batch, spatial_size, num_heads,
                           channels, num_levels, num_query);
     if (rc) return rc;
-    if (batch == 0 || num_query == 0) return MSDA_OK;
+    if (batch == 0) return MSDA_OK;
+    if (num_query == 0) return zero_grad_value(dtype, grad_value, batch, spatial_size, num_heads, channels, stream);
     if (!sampling_loc || !attn_weight || !grad_out || !grad_value || !grad_sampling_loc ||
         !grad_attn_weight || num_point <= 0)
         return fail(MSDA_ERR_ARG, "msda_backward: null pointer or non-positive num_point%s");
@@ -2317,7 +2373,9 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
     if (rc) return rc;
     if (frames <= 0 || window < 0 || num_curr_point <= 0 || (window > 0 && num_temp_point <= 0))
         return fail(MSDA_ERR_ARG, "msda_temporal_backward: bad frames/window/points%s");
-    if (clips == 0 || num_query == 0) return MSDA_OK;
+    if (clips == 0) return MSDA_OK;
+    if (num_query == 0)
+        return zero_grad_value(dtype, grad_value, clips * frames, spatial_size, num_heads, channels, stream);
     if (!loc_curr || !aw_curr || !grad_out || !grad_value || !grad_loc_curr || !grad_aw_curr ||
         (window > 0 && (!frame_table || !loc_temp || !aw_temp || !grad_loc_temp || !grad_aw_temp)))
         return fail(MSDA_ERR_ARG, "msda_temporal_backward: null pointer argument%s");

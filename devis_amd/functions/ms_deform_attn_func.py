@@ -87,10 +87,12 @@ class MSDeformAttnFunction(Function):
         grad_output = grad_output.contiguous()
         N = value.shape[0]
         acc = _native.acc_dtype(value.dtype)
-        grad_value = torch.zeros(value.shape, dtype=acc, device=value.device)   # cu:121
-        grad_loc = torch.empty_like(loc)        # fully written by the kernel (skipped points -> 0)
+        # all three are fully written by the library (ABI v4: no zeros_like as in cu:121; skipped points -> 0)
+        live = N > 0 and loc.shape[1] > 0
+        grad_value = (torch.empty if live else torch.zeros)(value.shape, dtype=acc, device=value.device)
+        grad_loc = torch.empty_like(loc)
         grad_aw = torch.empty_like(aw)
-        if N > 0 and loc.shape[1] > 0:
+        if live:
             step = _im2col_step(N, ctx.im2col_step)
             for n in range(0, N, step):
                 _native.backward(value[n:n + step], shapes, lsi, loc[n:n + step], aw[n:n + step],
@@ -150,7 +152,7 @@ class MSDeformAttnTemporalFunction(Function):
         value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t = ctx.saved_tensors
         grad_output = grad_output.contiguous()
         acc = _native.acc_dtype(value.dtype)
-        grad_value = torch.zeros(value.shape, dtype=acc, device=value.device)
+        grad_value = torch.empty(value.shape, dtype=acc, device=value.device)      # overwritten (ABI v4)
         gloc_c, gaw_c = torch.empty_like(loc_c), torch.empty_like(aw_c)
         gloc_t, gaw_t = torch.empty_like(loc_t), torch.empty_like(aw_t)
         _native.temporal_backward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, grad_output,

@@ -20,10 +20,11 @@
  *     ms_deform_im2col_cuda.cuh:948-952,1321-1325) launch failures ARE reported;
  *   - `dtype` names the storage type of value / sampling_loc / attn_weight / out / grad_out /
  *     grad_sampling_loc / grad_attn_weight.  Arithmetic is fp32 for f32/bf16/f16 and fp64 for f64.
- *     `grad_value` is ALWAYS an accumulation buffer in the arithmetic type (float for f32/bf16/f16,
- *     double for f64), must be zero-filled by the caller (the reference does at::zeros_like,
- *     ms_deform_attn_cuda.cu:121); kernels either accumulate into it with hardware float atomics or
- *     overwrite whole level-row bands they own exclusively.
+ *     `grad_value` is ALWAYS in the arithmetic type (float for f32/bf16/f16, double for f64) and is
+ *     FULLY OVERWRITTEN (ABI v4): it need not be zeroed by the caller.  The reference zero-fills it
+ *     (at::zeros_like, ms_deform_attn_cuda.cu:121) because every one of its kernels accumulates with
+ *     atomics; here the LDS scatter owns and overwrites whole level-row bands, and the library zero-fills
+ *     on the stream only what a fallback kernel accumulates into -- saving a full pass over grad_value.
  *
  * Symbols:  N batch, S = sum_l H_l*W_l, M heads, D channels per head, Lq queries, L levels,
  *           P points;  spatial_shapes[l] = (H_l, W_l);  sampling_loc[..., 0] = x (width), 1 = y.
@@ -37,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 3
+#define MSDA_ABI_VERSION 4
 #define MSDA_BWD_WORKSPACE_BYTES 64   /* minimum device scratch of the backward entry points (ticket counters) */
 
 enum msda_dtype { MSDA_F32 = 0, MSDA_F64 = 1, MSDA_BF16 = 2, MSDA_F16 = 3 };
@@ -82,7 +83,7 @@ int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,
  * ms_deformable_col2im_gpu_kernel_* variant, ms_deform_im2col_cuda.cuh:301-920,956-1326).
  *
  *   grad_out          [N, Lq, M*D]         dtype
- *   grad_value        [N, S, M, D]         float (double for MSDA_F64); caller zero-fills; accumulated
+ *   grad_value        [N, S, M, D]         float (double for MSDA_F64); fully overwritten (need not be zeroed)
  *   grad_sampling_loc [N, Lq, M, L, P, 2]  dtype, fully overwritten (skipped points get 0)
  *   grad_attn_weight  [N, Lq, M, L, P]     dtype, fully overwritten
  *   workspace         device scratch private to this call until it completes, `workspace_bytes` long, whose
@@ -135,9 +136,9 @@ int msda_temporal_forward(int dtype, const void *value, const int64_t *spatial_s
                           int num_curr_point, int num_temp_point, void *out, void *stream);
 
 /*
- * Fused temporal backward.  grad_value [clips*frames, S, M, D] is the accumulation buffer (float /
- * double, zero-filled by the caller): contributions of the current-frame and of every temporal slot
- * land in it directly, replacing the reference's index_put-add backward of value[temporal_frames].
+ * Fused temporal backward.  grad_value [clips*frames, S, M, D] (float / double, fully overwritten, need
+ * not be zeroed): contributions of the current-frame and of every temporal slot land in it directly,
+ * replacing the reference's index_put-add backward of value[temporal_frames].
  * The four grad_loc / grad_aw outputs have the shapes of their inputs and are fully overwritten.
  * `workspace`: as for msda_backward.
  */

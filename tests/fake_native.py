@@ -28,7 +28,7 @@ def install(monkeypatch):
 
     def backward(value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_aw):
         gv, gl, ga = O.backward(_np(value), shapes.numpy(), lsi.numpy(), _np(loc), _np(aw), _np(grad_out))
-        grad_value.add_(torch.from_numpy(gv).to(grad_value.dtype))      # accumulate contract
+        grad_value.copy_(torch.from_numpy(gv).to(grad_value.dtype))      # overwrite contract (ABI v4)
         grad_loc.copy_(torch.from_numpy(gl).to(grad_loc.dtype))
         grad_aw.copy_(torch.from_numpy(ga).to(grad_aw.dtype))
 

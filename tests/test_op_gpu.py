@@ -273,7 +273,7 @@ def test_backward_without_workspace_static_schedule():
     from devis_amd import _native
     g, d = _golden_dict("op_devis_small")
     t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in d.items()}
-    gv = torch.zeros(t["value"].shape, device=DEV)
+    gv = torch.full(t["value"].shape, float("nan"), device=DEV)        # ABI v4: overwritten, not accumulated
     gl, ga = torch.empty_like(t["loc"]), torch.empty_like(t["aw"])
     N, S, M, D = t["value"].shape
     _, Lq, _, L, P, _ = t["loc"].shape
@@ -417,3 +417,43 @@ def test_backward_slab_kernel_forced(monkeypatch):
         got = _run_temporal(dt, torch.float32)
         for a, b in zip(got, ref):
             assert _maxabs(a, b) <= 2e-5 * max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("route", ["points", "intervals", "atomic", "generic", "direct_levels", "no_workspace"])
+def test_grad_value_is_overwritten(route, monkeypatch):
+    """ABI v4: grad_value need not be zeroed -- every backward route overwrites (or zero-fills) all of it,
+    including pixel rows of `value` that belong to no level (spatial_shapes not tiling [0, S))."""
+    from devis_amd import _native
+    if route == "intervals":
+        monkeypatch.setenv("MSDA_BWD_CULL", "2")
+    if route == "atomic":
+        monkeypatch.setenv("MSDA_BWD_MODE", "atomic")
+    if route == "generic":
+        monkeypatch.setenv("MSDA_FORCE_GENERIC", "1")
+    if route == "direct_levels":
+        monkeypatch.setenv("MSDA_SCATTER_LDS_KB", "2")          # no level row fits: float-atomic branch
+    rng = np.random.default_rng(5)
+    shapes = [(9, 7), (5, 4), (3, 2)]
+    d = make_inputs(5, 3, 8, 32, 41, shapes, 4)
+    pad = 5                                                       # rows of value outside every level
+    value = np.concatenate([d["value"], rng.standard_normal((3, pad, 8, 32))], axis=1)
+    ref = oracle_fwd_bwd(d)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in d.items()}
+    v = torch.from_numpy(value).float().to(DEV)
+    loc, aw, go = t["loc"].float(), t["aw"].float(), t["grad_out"].float().contiguous()
+    gv = torch.full(v.shape, float("nan"), device=DEV)
+    gl, ga = torch.empty_like(loc), torch.empty_like(aw)
+    if route == "no_workspace":
+        N, S, M, D = v.shape
+        _, Lq, _, L, P, _ = loc.shape
+        rc = _native.load().msda_backward(0, v.data_ptr(), t["shapes"].data_ptr(), t["lsi"].data_ptr(), loc.data_ptr(),
+                                          aw.data_ptr(), go.data_ptr(), N, S, M, D, L, Lq, P, gv.data_ptr(),
+                                          gl.data_ptr(), ga.data_ptr(), None, 0, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+    else:
+        _native.backward(v, t["shapes"], t["lsi"], loc, aw, go, gv, gl, ga)
+    got = gv.cpu().numpy()
+    S0 = d["value"].shape[1]
+    assert np.isfinite(got).all()
+    assert (got[:, S0:] == 0).all()
+    assert _maxabs(got[:, :S0], ref[1]) <= 2e-5 * max(1.0, np.abs(ref[1]).max())
