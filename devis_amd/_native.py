@@ -11,7 +11,7 @@ import torch
 
 from . import build as _build
 
-MSDA_ABI_VERSION = 4
+MSDA_ABI_VERSION = 5
 BWD_WORKSPACE_BYTES = 64
 _DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.float16: 3}
 
@@ -52,15 +52,15 @@ def load():
             raise RuntimeError("devis_amd: ABI version mismatch (library %d, binding %d); rebuild with "
                                "python -m devis_amd.build --force" % (lib.msda_version(), MSDA_ABI_VERSION))
         lib.msda_forward.restype = _ci
-        lib.msda_forward.argtypes = [_ci] + [_vp] * 5 + [_ci] * 7 + [_vp, _vp]
+        lib.msda_forward.argtypes = [_ci] + [_vp] * 5 + [_ci] * 7 + [_vp, _vp, _vp]
         lib.msda_backward.restype = _ci
-        lib.msda_backward.argtypes = [_ci] + [_vp] * 6 + [_ci] * 7 + [_vp] * 4 + [ctypes.c_longlong, _vp]
+        lib.msda_backward.argtypes = [_ci] + [_vp] * 6 + [_ci] * 7 + [_vp] * 4 + [ctypes.c_longlong, _vp, _vp]
         lib.msda_backward_workspace_bytes.restype = ctypes.c_longlong
         lib.msda_backward_workspace_bytes.argtypes = [_ci] * 4
         lib.msda_temporal_forward.restype = _ci
-        lib.msda_temporal_forward.argtypes = [_ci] + [_vp] * 8 + [_ci] * 10 + [_vp, _vp]
+        lib.msda_temporal_forward.argtypes = [_ci] + [_vp] * 8 + [_ci] * 10 + [_vp, _vp, _vp]
         lib.msda_temporal_backward.restype = _ci
-        lib.msda_temporal_backward.argtypes = [_ci] + [_vp] * 9 + [_ci] * 10 + [_vp] * 6 + [ctypes.c_longlong, _vp]
+        lib.msda_temporal_backward.argtypes = [_ci] + [_vp] * 9 + [_ci] * 10 + [_vp] * 6 + [ctypes.c_longlong, _vp, _vp]
         _lib = lib
     return _lib
 
@@ -91,12 +91,33 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def value_strides(value, frames=1):
+    """include/msda.h `value_strides` of a [G, S, M, D] tensor: None for the reference's dense layout, else
+    a 3 x int64 host array {clip, head, pixel}.  Accepted: unit channel stride and (for the temporal op)
+    frames of one clip evenly spaced by S pixels -- e.g. the head-major layout of :func:`head_major`.
+    Anything else fails like the reference's contiguity assert (ms_deform_attn_cuda.cu:28)."""
+    if value.is_contiguous():
+        return None
+    G, S, M, D = value.shape
+    sb, sp, sh, sd = value.stride()
+    if (D > 1 and sd != 1) or sp <= 0 or sh < 0 or sb < 0 or (frames > 1 and sb != S * sp):
+        raise RuntimeError("value tensor has to be contiguous (or head-major, see devis_amd.head_major)")
+    return (ctypes.c_int64 * 3)(frames * sb, sh, sp)
+
+
+def head_major(value):
+    """The same [G, S, M, D] tensor stored head-major ([M, G, S, D] memory): the layout the gather kernels
+    read ~25 % faster (include/msda.h).  A per-head batched GEMM for value_proj writes it directly; this
+    helper makes a copy."""
+    return value.permute(2, 0, 1, 3).contiguous().permute(1, 2, 0, 3)
+
+
 def forward(value, shapes, lsi, loc, aw, out):
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = loc.shape
     with torch.cuda.device(value.device):
         rc = load().msda_forward(dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(aw),
-                                 N, S, M, D, L, Lq, P, _p(out), _stream(value))
+                                 N, S, M, D, L, Lq, P, _p(out), value_strides(value), _stream(value))
     _check(rc, "msda_forward")
 
 
@@ -116,7 +137,8 @@ def backward(value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_a
         ws = bwd_workspace(value.device, N, Lq, M, L)
         rc = load().msda_backward(dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(aw),
                                   _p(grad_out), N, S, M, D, L, Lq, P,
-                                  _p(grad_value), _p(grad_loc), _p(grad_aw), _p(ws), ws.numel() * 4, _stream(value))
+                                  _p(grad_value), _p(grad_loc), _p(grad_aw), _p(ws), ws.numel() * 4,
+                                  value_strides(value), _stream(value))
     _check(rc, "msda_backward")
 
 
@@ -129,7 +151,8 @@ def temporal_forward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, clips, 
     with torch.cuda.device(value.device):
         rc = load().msda_temporal_forward(
             dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(ftab), _p(loc_c), _p(aw_c),
-            _p(loc_t), _p(aw_t), clips, frames, window, S, M, D, L, Lq, Pc, Pt, _p(out), _stream(value))
+            _p(loc_t), _p(aw_t), clips, frames, window, S, M, D, L, Lq, Pc, Pt, _p(out),
+            value_strides(value, frames), _stream(value))
     _check(rc, "msda_temporal_forward")
 
 
@@ -145,5 +168,6 @@ def temporal_backward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, grad_o
         rc = load().msda_temporal_backward(
             dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(ftab), _p(loc_c), _p(aw_c),
             _p(loc_t), _p(aw_t), _p(grad_out), clips, frames, window, S, M, D, L, Lq, Pc, Pt,
-            _p(grad_value), _p(gloc_c), _p(gaw_c), _p(gloc_t), _p(gaw_t), _p(ws), ws.numel() * 4, _stream(value))
+            _p(grad_value), _p(gloc_c), _p(gaw_c), _p(gloc_t), _p(gaw_t), _p(ws), ws.numel() * 4,
+            value_strides(value, frames), _stream(value))
     _check(rc, "msda_temporal_backward")

@@ -143,6 +143,8 @@ struct Params {
     int groups, frames, window;
     int S, M, D, L, Lq;
     int LA, PA, LB, PB;
+    int64_t v_clip, v_head;     // element strides of `value`: between clips (= frames * S pixels), between heads
+    int v_pix;                  // ... and between consecutive pixels (standard [S, M, D]: frames*S*M*D, D, M*D)
     int cull_points;            // bbox entries are 4 x int16 top tap rows, one per POINT (PA, PB <= 4), not (min, max)
     int dbg;                    // measurement hooks (MSDA_DBG env), 0 in production
 };
@@ -301,7 +303,7 @@ __device__ __forceinline__ void build_chunk(const Params &p, const ChunkRef<T> &
                                             int4 *s_off, float4 *s_w, float4 *s_e, int lane,
                                             int *s_bb = nullptr, int nvl = 0)
 {
-    const int MD = p.M * p.D;
+    const int MD = p.v_pix;      // pixel stride of `value`
 #pragma unroll
     for (int k = 0; k < staged_per_lane<RPW>(); ++k) {
         const int i = lane + k * kWave;
@@ -351,7 +353,7 @@ msda_fwd_tile_kernel(const Params p)
     const int rows_valid = min(RPW, p.Lq - q0);
     const int MD = p.M * p.D;
     const T *__restrict__ value =
-        static_cast<const T *>(p.value) + (int64_t)clip * p.frames * p.S * MD + (m * p.D + sub * VEC);
+        static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head + sub * VEC;
     const int64_t row0 = ((int64_t)group * p.Lq + q0) * p.M + m;   // row of rr = 0; next row: + M
 
     float acc[VEC];
@@ -499,7 +501,7 @@ msda_fwd_slab_kernel(const Params p, int slab_elems)
     const int rows_valid = have_tile ? min(RPW, p.Lq - q0) : 0;
     const int D = p.D, MD = p.M * p.D;
     const T *__restrict__ value =
-        static_cast<const T *>(p.value) + (int64_t)clip * p.frames * p.S * MD + (m * D + sub * VEC);
+        static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head + sub * VEC;
     const T *slab_lane = slab + sub * VEC;
     const int64_t row0 = ((int64_t)group * p.Lq + q0) * p.M + m;
 
@@ -511,11 +513,11 @@ msda_fwd_slab_kernel(const Params p, int slab_elems)
         __syncthreads();                                   // every wave is done with the previous slab
         if (l0 < L) {
             constexpr int PXW = kWave / G;                 // pixels per LDS-DMA wave instruction
-            const T *src = static_cast<const T *>(p.value) +
-                           (((int64_t)clip * p.frames + f) * p.S + px0) * MD + m * D;
+            const T *src = static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head +
+                           ((int64_t)f * p.S + px0) * p.v_pix;
             for (int pb = wave * PXW; pb < npx; pb += kSlabWaves * PXW) {
                 const int px = min(pb + lane / G, npx - 1);
-                const T *gp = src + (int64_t)px * MD + (lane % G) * VEC;
+                const T *gp = src + (int64_t)px * p.v_pix + (lane % G) * VEC;
 #if defined(__HIP_DEVICE_COMPILE__)      // device-only builtin: keep the host pass (kernel stub) clean
                 __builtin_amdgcn_global_load_lds(
                     gp, (__attribute__((address_space(3))) void *)(slab + (size_t)pb * D), 16, 0, 0);
@@ -559,7 +561,7 @@ msda_fwd_slab_kernel(const Params p, int slab_elems)
                         Level lv; lv.H = s_sH[l]; lv.W = s_sW[l]; lv.start = s_sStart[l]; lv.pad = 0;
                         tp = make_taps(x, y, lv, D);               // offsets inside the slab (stride D)
                     } else {
-                        tp = make_taps(x, y, s_lvl[vl0 + l], MD);
+                        tp = make_taps(x, y, s_lvl[vl0 + l], p.v_pix);
                     }
                     s_off[rr * kRowSlots + pp] = make_int4(tp.off[0], tp.off[1], tp.off[2], tp.off[3]);
                     s_w[rr * kRowSlots + pp] = make_float4(tp.w[0] * a, tp.w[1] * a, tp.w[2] * a, tp.w[3] * a);
@@ -691,7 +693,7 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
     const int rows_valid = have_tile ? min(RPW, p.Lq - q0) : 0;
     const int D = p.D, MD = p.M * p.D;
     const T *__restrict__ value =
-        static_cast<const T *>(p.value) + (int64_t)clip * p.frames * p.S * MD + (m * D + sub * VEC);
+        static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head + sub * VEC;
     const T *slab_lane = slab + sub * VEC;
     const int64_t row0 = ((int64_t)group * p.Lq + q0) * p.M + m;
     const int64_t row = row0 + (int64_t)r * p.M;
@@ -705,11 +707,11 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
         __syncthreads();
         if (l0 < L) {
             constexpr int PXW = kWave / G;
-            const T *src = static_cast<const T *>(p.value) +
-                           (((int64_t)clip * p.frames + f) * p.S + px0) * MD + m * D;
+            const T *src = static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head +
+                           ((int64_t)f * p.S + px0) * p.v_pix;
             for (int pb = wave * PXW; pb < npx; pb += NW * PXW) {
                 const int px = min(pb + lane / G, npx - 1);
-                const T *gp = src + (int64_t)px * MD + (lane % G) * VEC;
+                const T *gp = src + (int64_t)px * p.v_pix + (lane % G) * VEC;
 #if defined(__HIP_DEVICE_COMPILE__)
                 __builtin_amdgcn_global_load_lds(
                     gp, (__attribute__((address_space(3))) void *)(slab + (size_t)pb * D), 16, 0, 0);
@@ -758,7 +760,7 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
                         Level lv; lv.H = s_sH[l]; lv.W = s_sW[l]; lv.start = s_sStart[l]; lv.pad = 0;
                         tp = make_taps(x, y, lv, D);
                     } else {
-                        tp = make_taps(x, y, s_lvl[vl], MD);
+                        tp = make_taps(x, y, s_lvl[vl], p.v_pix);
                     }
                     s_off[rr * kRowSlots + pp] = make_int4(tp.off[0], tp.off[1], tp.off[2], tp.off[3]);
                     s_w[rr * kRowSlots + pp] = make_float4(tp.w[0], tp.w[1], tp.w[2], tp.w[3]);
@@ -866,7 +868,8 @@ msda_bwd_tile_kernel(const Params p)
     const int r = lane / G, sub = lane % G;
     const int rows_valid = min(RPW, p.Lq - q0);
     const int MD = p.M * p.D;
-    const int64_t lane_off = (int64_t)clip * p.frames * p.S * MD + (m * p.D + sub * VEC);
+    // (the ATOMICS variant scatters grad_value at value's offsets: the host only takes it for the standard layout)
+    const int64_t lane_off = clip * p.v_clip + m * p.v_head + sub * VEC;
     const T *__restrict__ value = static_cast<const T *>(p.value) + lane_off;
     float *__restrict__ gvalue = static_cast<float *>(p.grad_value) + lane_off;
     const int64_t row0 = ((int64_t)group * p.Lq + q0) * p.M + m;
@@ -1882,7 +1885,7 @@ msda_fwd_generic_kernel(const Params p, int64_t total)
         const int m = (int)(row % p.M);
         const int group = (int)(row / ((int64_t)p.M * p.Lq));
         const int clip = group / p.frames, t = group - clip * p.frames;
-        const T *value = static_cast<const T *>(p.value) + (int64_t)clip * p.frames * p.S * MD + m * p.D + c;
+        const T *value = static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head + c;
         A acc = 0;
         for (int arr = 0; arr < 2; ++arr) {
             const T *loc = static_cast<const T *>(arr ? p.locB : p.locA);
@@ -1892,7 +1895,7 @@ msda_fwd_generic_kernel(const Params p, int64_t total)
                 const Level lv = make_level(p, t, (arr ? p.LA : 0) + pt / P);
                 const int64_t idx = row * LP + pt;
                 const GTaps<A> tp = make_gtaps<A>((A)Store<T>::get(loc + 2 * idx),
-                                                  (A)Store<T>::get(loc + 2 * idx + 1), lv, MD);
+                                                  (A)Store<T>::get(loc + 2 * idx + 1), lv, p.v_pix);
                 if (!tp.valid) continue;
                 A val = 0;
                 for (int k = 0; k < 4; ++k)
@@ -1923,9 +1926,8 @@ msda_bwd_generic_kernel(const Params p, int64_t rows)
         const int m = (int)(row % p.M);
         const int group = (int)(row / ((int64_t)p.M * p.Lq));
         const int clip = group / p.frames, t = group - clip * p.frames;
-        const int64_t base = (int64_t)clip * p.frames * p.S * MD + m * p.D;
-        const T *value = static_cast<const T *>(p.value) + base;
-        A *gvalue = static_cast<A *>(p.grad_value) + base;
+        const T *value = static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head;
+        A *gvalue = static_cast<A *>(p.grad_value) + (int64_t)clip * p.frames * p.S * MD + m * p.D;
         const T *go = static_cast<const T *>(p.grad_out) + row * p.D;
         for (int arr = 0; arr < 2; ++arr) {
             const T *loc = static_cast<const T *>(arr ? p.locB : p.locA);
@@ -1937,16 +1939,17 @@ msda_bwd_generic_kernel(const Params p, int64_t rows)
                 const Level lv = make_level(p, t, (arr ? p.LA : 0) + pt / P);
                 const int64_t idx = row * LP + pt;
                 const A a = (A)Store<T>::get(aw + idx);
+                // offsets in PIXELS: value and grad_value (always the standard layout) have different strides
                 const GTaps<A> tp = make_gtaps<A>((A)Store<T>::get(loc + 2 * idx),
-                                                  (A)Store<T>::get(loc + 2 * idx + 1), lv, MD);
+                                                  (A)Store<T>::get(loc + 2 * idx + 1), lv, 1);
                 A d[4] = {0, 0, 0, 0};
                 if (tp.valid) {
                     for (int c = lane; c < p.D; c += kWave) {
                         const A gc = (A)Store<T>::get(go + c);
                         for (int k = 0; k < 4; ++k) {
                             if (tp.valid & (1 << k)) {
-                                d[k] += gc * (A)Store<T>::get(value + tp.off[k] + c);
-                                atomic_accumulate(gvalue + tp.off[k] + c, tp.w[k] * a * gc);
+                                d[k] += gc * (A)Store<T>::get(value + tp.off[k] * p.v_pix + c);
+                                atomic_accumulate(gvalue + tp.off[k] * MD + c, tp.w[k] * a * gc);
                             }
                         }
                     }
@@ -2016,6 +2019,11 @@ int device_cus()
 
 // Can grad_value go through the LDS scatter kernel?  MSDA_BWD_MODE=atomic forces the one-kernel
 // backward with global atomics (kept for A/B measurements and as the any-shape path).
+bool standard_value_layout(const Params &p)
+{
+    return p.v_clip == (int64_t)p.frames * p.S * p.M * p.D && p.v_head == p.D && p.v_pix == p.M * p.D;
+}
+
 bool scatter_applicable(const Params &p)
 {
     const char *mode = getenv("MSDA_BWD_MODE");
@@ -2162,7 +2170,11 @@ int dispatch_tile(const Params &p, bool bwd, hipStream_t stream, bool &taken)
         (bwd && (!aligned16(p.grad_out) || !aligned16(p.grad_value))))
         return MSDA_OK;
     // element offsets inside one clip slab are 32-bit in the tap records
-    if ((int64_t)p.frames * p.S * p.M * p.D >= 0x7fffffffLL) return MSDA_OK;
+    if ((int64_t)p.frames * p.S * p.M * p.D >= 0x7fffffffLL || (int64_t)p.frames * p.S * p.v_pix >= 0x7fffffffLL)
+        return MSDA_OK;
+    if (p.v_clip % VEC || p.v_head % VEC || p.v_pix % VEC) return MSDA_OK;
+    // the one-kernel backward scatters grad_value (always dense) at value's offsets
+    if (bwd && !scatter_applicable(p) && !standard_value_layout(p)) return MSDA_OK;
     if (tile_lds_bytes(kWave / (G > 0 ? G : 1), p.LA + p.LB, bwd) > 60 * 1024) return MSDA_OK;
     taken = true;
     switch (G) {
@@ -2240,6 +2252,18 @@ int check_common(const void *value, const int64_t *shapes, const int64_t *lsi, i
     return MSDA_OK;
 }
 
+// `value_strides` (host pointer, may be null): element strides {between clips, between heads, between pixels}
+// of `value`; null = the standard dense [groups, S, M, D].
+int set_value_strides(Params &p, const int64_t *vs)
+{
+    p.v_clip = (int64_t)p.frames * p.S * p.M * p.D; p.v_head = p.D; p.v_pix = p.M * p.D;
+    if (!vs) return MSDA_OK;
+    if (vs[0] < 0 || vs[1] < 0 || vs[2] <= 0 || vs[2] > 0x7fffffffLL)
+        return fail(MSDA_ERR_ARG, "msda: bad value_strides%s");
+    p.v_clip = vs[0]; p.v_head = vs[1]; p.v_pix = (int)vs[2];
+    return MSDA_OK;
+}
+
 int zero_grad_value(int dtype, void *grad_value, int groups, int S, int M, int D, void *stream)
 {
     if (dtype < MSDA_F32 || dtype > MSDA_F16) return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
@@ -2280,7 +2304,7 @@ const char *msda_last_error(void) { return g_err; }
 int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,
                  const int64_t *level_start_index, const void *sampling_loc, const void *attn_weight,
                  int batch, int spatial_size, int num_heads, int channels, int num_levels,
-                 int num_query, int num_point, void *out, void *stream)
+                 int num_query, int num_point, void *out, const int64_t *value_strides, void *stream)
 {
     g_err[0] = 0;
     int rc = check_common(value, spatial_shapes, level_start_index, batch, spatial_size, num_heads,
@@ -2296,6 +2320,8 @@ int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,
     p.groups = batch; p.frames = 1; p.window = 0;
     p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
     p.LA = num_levels; p.PA = num_point; p.LB = 0; p.PB = 1;
+    rc = set_value_strides(p, value_strides);
+    if (rc) return rc;
     return run(dtype, p, false, static_cast<hipStream_t>(stream));
 }
 
@@ -2305,7 +2331,7 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
                   int batch, int spatial_size, int num_heads, int channels, int num_levels,
                   int num_query, int num_point,
                   void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
-                  void *workspace, long long workspace_bytes, void *stream)
+                  void *workspace, long long workspace_bytes, const int64_t *value_strides, void *stream)
 {
     g_err[0] = 0;
     int rc = check_common(value, spatial_shapes, level_start_index, batch, spatial_size, num_heads,
@@ -2325,6 +2351,8 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
     p.groups = batch; p.frames = 1; p.window = 0;
     p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
     p.LA = num_levels; p.PA = num_point; p.LB = 0; p.PB = 1;
+    rc = set_value_strides(p, value_strides);
+    if (rc) return rc;
     return run(dtype, p, true, static_cast<hipStream_t>(stream));
 }
 
@@ -2334,7 +2362,8 @@ int msda_temporal_forward(int dtype, const void *value, const int64_t *spatial_s
                           const void *loc_temp, const void *aw_temp,
                           int clips, int frames, int window, int spatial_size, int num_heads,
                           int channels, int num_levels, int num_query,
-                          int num_curr_point, int num_temp_point, void *out, void *stream)
+                          int num_curr_point, int num_temp_point, void *out, const int64_t *value_strides,
+                          void *stream)
 {
     g_err[0] = 0;
     int rc = check_common(value, spatial_shapes, level_start_index, clips, spatial_size, num_heads,
@@ -2353,6 +2382,8 @@ int msda_temporal_forward(int dtype, const void *value, const int64_t *spatial_s
     p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
     p.LA = num_levels; p.PA = num_curr_point;
     p.LB = window * num_levels; p.PB = window > 0 ? num_temp_point : 1;
+    rc = set_value_strides(p, value_strides);
+    if (rc) return rc;
     return run(dtype, p, false, static_cast<hipStream_t>(stream));
 }
 
@@ -2365,7 +2396,7 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
                            int num_curr_point, int num_temp_point,
                            void *grad_value, void *grad_loc_curr, void *grad_aw_curr,
                            void *grad_loc_temp, void *grad_aw_temp, void *workspace, long long workspace_bytes,
-                           void *stream)
+                           const int64_t *value_strides, void *stream)
 {
     g_err[0] = 0;
     int rc = check_common(value, spatial_shapes, level_start_index, clips, spatial_size, num_heads,
@@ -2390,6 +2421,8 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
     p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
     p.LA = num_levels; p.PA = num_curr_point;
     p.LB = window * num_levels; p.PB = window > 0 ? num_temp_point : 1;
+    rc = set_value_strides(p, value_strides);
+    if (rc) return rc;
     return run(dtype, p, true, static_cast<hipStream_t>(stream));
 }
 

@@ -25,7 +25,10 @@ def _check_inputs(named):
         _require(isinstance(t, torch.Tensor), "%s must be a tensor" % name)
         if not t.is_cuda:
             raise RuntimeError("Not implemented on the CPU (%s is not a GPU tensor)" % name)
-        _require(t.is_contiguous(), "%s tensor has to be contiguous" % name)
+        if name == "value" and t.dim() == 4:
+            _native.value_strides(t)        # dense or head-major (include/msda.h value_strides); raises otherwise
+        else:
+            _require(t.is_contiguous(), "%s tensor has to be contiguous" % name)
     dev = named[0][1].device
     for name, t in named:
         _require(t.device == dev, "%s must be on the same device as value" % name)

@@ -173,10 +173,13 @@ def test_devis_decoder_call_shapes_fp32():
 # ---------------------------------------------------------------------------------------------
 # fused temporal op
 # ---------------------------------------------------------------------------------------------
-def _run_temporal(d, dtype, clips=1):
+def _run_temporal(d, dtype, clips=1, head_major=False):
+    from devis_amd import _native
     from devis_amd.functions import MSDeformAttnTemporalFunction
     f = lambda k: torch.from_numpy(np.asarray(d[k], dtype=np.float64)).to(DEV, dtype).requires_grad_(True)
     v, lc, ac, lt, at = f("value"), f("loc_c"), f("aw_c"), f("loc_t"), f("aw_t")
+    if head_major:
+        v = _native.head_major(v.detach()).requires_grad_(True)
     shapes = torch.from_numpy(d["shapes"]).to(DEV)
     lsi = torch.from_numpy(d["lsi"]).to(DEV)
     ftab = torch.from_numpy(d["ftab"]).to(DEV)
@@ -280,7 +283,7 @@ def test_backward_without_workspace_static_schedule():
     lib = _native.load()
     rc = lib.msda_backward(0, t["value"].data_ptr(), t["shapes"].data_ptr(), t["lsi"].data_ptr(), t["loc"].data_ptr(),
                            t["aw"].data_ptr(), t["grad_out"].float().contiguous().data_ptr(), N, S, M, D, L, Lq, P,
-                           gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), None, 0,
+                           gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), None, 0, None,
                            torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     torch.cuda.synchronize()
@@ -448,7 +451,8 @@ def test_grad_value_is_overwritten(route, monkeypatch):
         _, Lq, _, L, P, _ = loc.shape
         rc = _native.load().msda_backward(0, v.data_ptr(), t["shapes"].data_ptr(), t["lsi"].data_ptr(), loc.data_ptr(),
                                           aw.data_ptr(), go.data_ptr(), N, S, M, D, L, Lq, P, gv.data_ptr(),
-                                          gl.data_ptr(), ga.data_ptr(), None, 0, torch.cuda.current_stream().cuda_stream)
+                                          gl.data_ptr(), ga.data_ptr(), None, 0, None,
+                                          torch.cuda.current_stream().cuda_stream)
         assert rc == 0
     else:
         _native.backward(v, t["shapes"], t["lsi"], loc, aw, go, gv, gl, ga)
@@ -457,3 +461,36 @@ def test_grad_value_is_overwritten(route, monkeypatch):
     assert np.isfinite(got).all()
     assert (got[:, S0:] == 0).all()
     assert _maxabs(got[:, :S0], ref[1]) <= 2e-5 * max(1.0, np.abs(ref[1]).max())
+
+
+@pytest.mark.parametrize("route", ["default", "tile", "atomic", "generic"])
+def test_head_major_value_layout(route, monkeypatch):
+    """value stored head-major ([M, N, S, D] memory behind the same [N, S, M, D] shape; include/msda.h
+    value_strides): same results, grad_value comes back dense."""
+    from devis_amd import _native
+    from devis_amd.functions import MSDeformAttnFunction
+    if route == "tile":
+        monkeypatch.setenv("MSDA_FWD_SLAB", "0"); monkeypatch.setenv("MSDA_BWD_SLAB", "0")
+    if route == "default":
+        monkeypatch.setenv("MSDA_FWD_SLAB", "1"); monkeypatch.setenv("MSDA_BWD_SLAB", "1")
+    if route == "atomic":
+        monkeypatch.setenv("MSDA_BWD_MODE", "atomic")
+    if route == "generic":
+        monkeypatch.setenv("MSDA_FORCE_GENERIC", "1")
+    g, d = _golden_dict("op_batched_im2col")
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in d.items()}
+    v = _native.head_major(t["value"].float()).requires_grad_(True)
+    assert not v.is_contiguous()
+    loc, aw = t["loc"].float().requires_grad_(True), t["aw"].float().requires_grad_(True)
+    out = MSDeformAttnFunction.apply(v, t["shapes"], t["lsi"], loc, aw, 2)
+    gv, gl, ga = torch.autograd.grad(out, (v, loc, aw), t["grad_out"].float())
+    assert gv.shape == v.shape
+    for got, key in ((out, "out"), (gv, "grad_value"), (gl, "grad_sampling_loc"), (ga, "grad_attn_weight")):
+        assert _maxabs(got.detach().cpu().numpy(), g[key]) <= 2e-5 * max(1.0, np.abs(g[key]).max()), key
+    # fused temporal op on a head-major clip batch
+    dt = make_temporal_inputs(49, 4, 3, 8, 32, 37, [(9, 7), (5, 4), (3, 2)], 4, 2)
+    ref = temporal_reference(*(np.asarray(dt[k], dtype=np.float64) if dt[k].dtype.kind == "f" else dt[k]
+                               for k in ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")))
+    got = _run_temporal(dt, torch.float32, head_major=True)
+    for a, b in zip(got, ref):
+        assert _maxabs(a, b) <= 2e-5 * max(1.0, np.abs(b).max())
