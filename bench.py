@@ -263,10 +263,13 @@ def main():
         use_slab = dtype == torch.float32 and slab_blocks >= 2 * n_cu
         fwd_name = "msda_fwd_slab_kernel" if use_slab else "msda_fwd_tile_kernel"
         gat_name = "msda_bwd_slab_kernel" if use_slab else "msda_bwd_tile_kernel"
+        # <= 4 points per level: the gather pass leaves per-point culling records and the pipelined scatter runs
+        pts = max(int(b["loc_c"].shape[4]), int(b["loc_t"].shape[4]))
+        sca_name = "msda_bwd_value_points_kernel" if pts <= 4 else "msda_bwd_value_lds_kernel"
         kernels = {
             fwd_name: (fwd_ms, fwd_med, ab["fwd"]),
             gat_name + " (grad_loc/grad_attn gather pass)": (gat_ms, gat_med, ab["bwd_gather"]),
-            "msda_bwd_value_lds_kernel (grad_value scatter)": (sca_ms, sca_med, ab["bwd_scatter"]),
+            sca_name + " (grad_value scatter)": (sca_ms, sca_med, ab["bwd_scatter"]),
         }
         dom = max(kernels, key=lambda k: kernels[k][0])
         d_ms, _, d_bytes = kernels[dom]
