@@ -1484,7 +1484,7 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
             s_dec[buf][0] = 1; s_dec[buf][1] = l; s_dec[buf][2] = m; s_dec[buf][3] = f; s_dec[buf][4] = clip;
             s_dec[buf][5] = r0; s_dec[buf][6] = r1; s_dec[buf][7] = direct ? 1 : 0;
             s_src_t[buf][0] = f; s_src_vl[buf][0] = l;
-            s_nsrc[buf] = (dbg & 4) ? 0 : 1 + (int)__popcll(bal);
+            s_nsrc[buf] = ((dbg & 4) || ((dbg >> 8) & (1 << l))) ? 0 : 1 + (int)__popcll(bal);    // dbg: skip all / a level's sources
         }
         if (hit) {
             const int n = 1 + (int)__popcll(bal & ((1ull << lane) - 1ull)), t = lane / p.window;
