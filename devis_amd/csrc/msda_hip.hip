@@ -804,8 +804,8 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
                     d1 = (bits & 2) ? d1 : 0.f;
                     d2 = (bits & 4) ? d2 : 0.f;
                     d3 = (bits & 8) ? d3 : 0.f;
-                    d0 = row_sum<G>(d0); d1 = row_sum<G>(d1); d2 = row_sum<G>(d2); d3 = row_sum<G>(d3);
-                    if (sub == (pp % G)) {
+                    if (!(p.dbg & 16)) { d0 = row_sum<G>(d0); d1 = row_sum<G>(d1); d2 = row_sum<G>(d2); d3 = row_sum<G>(d3); }
+                    if (sub == (pp % G) && !(p.dbg & 256)) {
                         const float a = e.x, lh = e.y, lw = e.z, hh = 1.f - lh, hw = 1.f - lw;
                         const Level lv = s_lvl[bits >> 4];
                         const float g_aw = w.x * d0 + w.y * d1 + w.z * d2 + w.w * d3;
@@ -815,7 +815,7 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
                     }
                 }
                 wave_sync();
-                if (r < rows_valid) {        // coalesced write-out, as in the tile kernel
+                if (r < rows_valid && !(p.dbg & 8)) {        // coalesced write-out, as in the tile kernel
                     const int64_t idx0 = row * LP + pt0 + c0;
                     const float *res = reinterpret_cast<const float *>(s_e + r * kRowSlots);
                     for (int el = sub; el < 2 * np; el += G)

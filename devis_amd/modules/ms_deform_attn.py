@@ -198,12 +198,24 @@ class TemporalMSDeformAttnBase(nn.Module):
         curr_offsets = self.sampling_offsets(query).view(T, Len_q, M, L, Pc, 2)
         return value, curr_offsets, temporal_offsets, weights_curr, weights_temporal
 
+    _table_cache = None     # (offset tensors, n_frames, device, table): shared by all layers of a transformer
+
     @staticmethod
     def _frame_table(temporal_offsets, n_frames, device):
-        """[T, W] absolute frame indices: frame_table[t] = temporal_offsets[t] + t (ref :339, :445)."""
+        """[T, W] absolute frame indices: frame_table[t] = temporal_offsets[t] + t (ref :339, :445).
+        The transformer hands the SAME offset tensors to every layer (devis_transformer.py:103-113), so
+        the table -- four tiny kernels per call, two calls per decoder layer -- is built once per list of
+        tensors and reused while the very same tensor objects come back."""
+        cached = TemporalMSDeformAttnBase._table_cache
+        if cached is not None and cached[1] == n_frames and cached[2] == device and \
+                len(cached[0]) == len(temporal_offsets) and \
+                all(a is b and a._version == v for (a, v), b in zip(cached[0], temporal_offsets)):
+            return cached[3]
         table = torch.stack([o.to(device) for o in temporal_offsets]) \
             + torch.arange(n_frames, device=device)[:, None]
-        return table.to(torch.int32).contiguous()
+        table = table.to(torch.int32).contiguous()
+        TemporalMSDeformAttnBase._table_cache = ([(o, o._version) for o in temporal_offsets], n_frames, device, table)
+        return table
 
     def _attend(self, value, shapes, level_start, temporal_offsets, loc_curr, w_curr, loc_temp, w_temp):
         """[T, Lq, C]: current-frame + temporal attention for every frame."""

@@ -129,3 +129,17 @@ def test_constructor_contract():
         m_plain = MSDeformAttn(32, 2, 4, 3)
         m_plain(torch.zeros(1, 2, 32), torch.zeros(1, 2, 2, 3), torch.zeros(1, 30, 32),
                 torch.tensor([[6, 4], [3, 2]]), torch.tensor([0, 24]), None)
+
+
+def test_frame_table_is_cached_per_offset_tensors():
+    """one table per list of offset tensors, rebuilt when they change."""
+    from devis_amd.modules import TemporalMSDeformAttnDecoder as Dec
+    offs = [torch.tensor([1, 2]), torch.tensor([-1, 1]), torch.tensor([-2, -1])]
+    a = Dec._frame_table(offs, 3, torch.device("cpu"))
+    assert a.dtype == torch.int32 and a.tolist() == [[1, 2], [0, 2], [0, 1]]
+    assert Dec._frame_table(list(offs), 3, torch.device("cpu")) is a          # same tensors, new list: hit
+    offs[1].add_(0)                                                            # in-place change: version bump
+    b = Dec._frame_table(offs, 3, torch.device("cpu"))
+    assert b is not a and b.tolist() == a.tolist()
+    c = Dec._frame_table([o.clone() for o in offs], 3, torch.device("cpu"))    # other tensors: miss
+    assert c is not b
