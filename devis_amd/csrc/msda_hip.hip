@@ -29,6 +29,7 @@
 // No CUDA compatibility layer, no hipify output: this file targets gfx950 only.
 
 #include <hip/hip_runtime.h>
+#include <utility>
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -804,8 +805,8 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
                     d1 = (bits & 2) ? d1 : 0.f;
                     d2 = (bits & 4) ? d2 : 0.f;
                     d3 = (bits & 8) ? d3 : 0.f;
-                    if (!(p.dbg & 16)) { d0 = row_sum<G>(d0); d1 = row_sum<G>(d1); d2 = row_sum<G>(d2); d3 = row_sum<G>(d3); }
-                    if (sub == (pp % G) && !(p.dbg & 256)) {
+                    d0 = row_sum<G>(d0); d1 = row_sum<G>(d1); d2 = row_sum<G>(d2); d3 = row_sum<G>(d3);
+                    if (sub == (pp % G)) {
                         const float a = e.x, lh = e.y, lw = e.z, hh = 1.f - lh, hw = 1.f - lw;
                         const Level lv = s_lvl[bits >> 4];
                         const float g_aw = w.x * d0 + w.y * d1 + w.z * d2 + w.w * d3;
@@ -815,7 +816,7 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
                     }
                 }
                 wave_sync();
-                if (r < rows_valid && !(p.dbg & 8)) {        // coalesced write-out, as in the tile kernel
+                if (r < rows_valid) {        // coalesced write-out, as in the tile kernel
                     const int64_t idx0 = row * LP + pt0 + c0;
                     const float *res = reinterpret_cast<const float *>(s_e + r * kRowSlots);
                     for (int el = sub; el < 2 * np; el += G)
@@ -1373,6 +1374,44 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
     }
 }
 
+// Broadcast of lane R of every team of G lanes to the whole team, R a compile-time constant: pure DPP for
+// G = 4 (quad_perm) and G = 8 (quad_perm, then row_half_mirror brings the other quad's copy), so the
+// scatter's hit hand-off does not go through the LDS crossbar its atomics are saturating.
+template <int G, int R>
+__device__ __forceinline__ int team_bcast(int v, int lane)
+{
+    if constexpr (G == 4) {
+        return __builtin_amdgcn_update_dpp(0, v, R | (R << 2) | (R << 4) | (R << 6), 0xf, 0xf, true);
+    } else if constexpr (G == 8) {
+        constexpr int q = R & 3;
+        const int t = __builtin_amdgcn_update_dpp(0, v, q | (q << 2) | (q << 4) | (q << 6), 0xf, 0xf, true);
+        const int u = __builtin_amdgcn_update_dpp(0, t, 0x141, 0xf, 0xf, true);       // row_half_mirror
+        return ((lane & 4) == (R & 4)) ? t : u;
+    } else {
+        return __shfl(v, (lane / G) * G + R, kWave);
+    }
+}
+template <int G, int R>
+__device__ __forceinline__ float team_bcast(float v, int lane)
+{
+    return __int_as_float(team_bcast<G, R>(__float_as_int(v), lane));
+}
+template <int G, int R> constexpr u64 team_lane_mask()       // lane R of every team
+{
+    u64 m = 0;
+    for (int j = 0; j < kWave / G; ++j) m |= 1ull << (j * G + R);
+    return m;
+}
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
 // msda_bwd_value_points_kernel -- the scatter for the common case PA, PB <= 4, where the gather pass
 // leaves the top tap row of every POINT (4 x int16 per (row, level)) in the workspace.  Same work items,
 // same band accumulators, same arithmetic and flush as msda_bwd_value_lds_kernel; what differs is
@@ -1658,17 +1697,18 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
             fetchp(it, buf, base + kScatterThreads + tid, listed, x, y, a, qrow);      // next pass's loads fly
             if (dbg & 2) continue;
             const u64 mask = __ballot(bits != 0);
-#pragma unroll 1
-            for (int R = 0; R < G; ++R) {
-                const u64 part = RPW == kWave ? mask : (mask >> (R * RPW)) & ((1ull << (RPW % kWave)) - 1ull);
-                if (!part) continue;
-                const int from = R * RPW + team;
+            // sub-round R: every team takes the hit of ITS OWN lane R (so the record moves by DPP, not
+            // through the LDS crossbar, when G is 4 or 8), loads the hit's grad_out and retires the
+            // previous hit's adds
+            auto sub_round = [&](auto Rc) {
+                constexpr int R = decltype(Rc)::value;
+                if (!(mask & team_lane_mask<G, R>())) return;
                 Hit h;
-                h.pix = __shfl(pix, from, kWave);
-                h.bits = __shfl(bits, from, kWave);
-                const int h_q = __shfl(qr, from, kWave);
-                h.w0 = __shfl(wa0, from, kWave); h.w1 = __shfl(wa1, from, kWave);
-                h.w2 = __shfl(wa2, from, kWave); h.w3 = __shfl(wa3, from, kWave);
+                h.pix = team_bcast<G, R>(pix, lane);
+                h.bits = team_bcast<G, R>(bits, lane);
+                const int h_q = team_bcast<G, R>(qr, lane);
+                h.w0 = team_bcast<G, R>(wa0, lane); h.w1 = team_bcast<G, R>(wa1, lane);
+                h.w2 = team_bcast<G, R>(wa2, lane); h.w3 = team_bcast<G, R>(wa3, lane);
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) h.g[c] = 0.f;
                 if (h.bits && !(dbg & 32)) {
@@ -1678,6 +1718,30 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
                 }
                 consume(it, pend);
                 pend = h;
+            };
+            if constexpr (G == 4 || G == 8) {
+                static_for<G>(sub_round);
+            } else {
+#pragma unroll 1
+                for (int R = 0; R < G; ++R) {
+                    if (!((mask >> R) & team_lane_mask<G, 0>())) continue;
+                    const int from = team * G + R;
+                    Hit h;
+                    h.pix = __shfl(pix, from, kWave);
+                    h.bits = __shfl(bits, from, kWave);
+                    const int h_q = __shfl(qr, from, kWave);
+                    h.w0 = __shfl(wa0, from, kWave); h.w1 = __shfl(wa1, from, kWave);
+                    h.w2 = __shfl(wa2, from, kWave); h.w3 = __shfl(wa3, from, kWave);
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) h.g[c] = 0.f;
+                    if (h.bits && !(dbg & 32)) {
+                        const T *go = static_cast<const T *>(p.grad_out) + (int64_t)h_q * MD + it.m * D;
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c) h.g[c] = Store<T>::get(go + ((c + team) % VEC) * G + sub);
+                    }
+                    consume(it, pend);
+                    pend = h;
+                }
             }
         }
     };
