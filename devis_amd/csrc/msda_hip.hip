@@ -1861,7 +1861,10 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
             if (nxt.valid) cull_load(nxt, bn, 0, iv, ent);
         }
         const int flush_vecs = cur.direct ? 0 : (cur.r1 - cur.r0 + 1) * cur.W * D / 4;
-        flush(cur, 0, flush_vecs / 2);  // first half of the flush hides the table reads (dynamic order)
+        // dynamic order: the first half of the flush hides the table reads just issued; static order: they
+        // landed long ago, so the whole flush can hide the first scan pass's reads instead
+        const int flush_cut = dynamic ? flush_vecs / 2 : 0;
+        flush(cur, 0, flush_cut);
         // (e) compact the next item's first batch and start its first scan pass
         int nxt_listed = 0;
         bool nxt_overflow = false;
@@ -1873,7 +1876,7 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
             else { nxt_listed = rel; fetchp(nxt, bn, tid, nxt_listed, x, y, a, qrow); }
         }
         // (f) the rest of the flush hides the first scan pass's reads
-        flush(cur, flush_vecs / 2, flush_vecs);
+        flush(cur, flush_cut, flush_vecs);
         __syncthreads();
         cur = nxt; cur_listed = nxt_listed; cur_overflow = nxt_overflow;
         if (dynamic) {
