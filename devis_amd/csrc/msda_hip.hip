@@ -1024,6 +1024,7 @@ msda_bwd_tile_kernel(const Params p)
 constexpr int kScatterThreads = 1024;
 constexpr int kScatterMaxLevels = 32;
 constexpr int kScatterMaxSources = 64;     // 1 + frames * window must fit
+constexpr int kPointsCapBytes = 142 * 1024;   // band budget of msda_bwd_value_points_kernel (dynamic LDS)
 constexpr int kScatterList = 3072;         // capacity of the survivor list (12 KiB of the 16 KiB LDS left by the band)
 typedef unsigned long long u64;
 
@@ -1438,8 +1439,11 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
     cap_slots -= 2 * G * VEC;
     __shared__ int s_H[kScatterMaxLevels], s_W[kScatterMaxLevels], s_R[kScatterMaxLevels],
         s_first[kScatterMaxLevels + 1], s_lsi[kScatterMaxLevels];
-    __shared__ int s_src_t[3][kScatterMaxSources], s_src_vl[3][kScatterMaxSources], s_nsrc[3];
-    __shared__ int s_dec[3][8];           // staged item: valid, l, m, f, clip, r0, r1, direct
+    __shared__ int s_nsrc[3];
+    __shared__ int s_dec[3][8];
+    // per source, precomputed when the item is staged: first culling-table entry, first loc/attn element, first query row
+    __shared__ long long s_src_tab[3][kScatterMaxSources], s_src_loc[3][kScatterMaxSources];
+    __shared__ int s_src_q0[3][kScatterMaxSources];           // staged item: valid, l, m, f, clip, r0, r1, direct
     __shared__ int s_list[kScatterList], s_cnt[3], s_valid;
     __shared__ int s_ftab[kScatterMaxSources];      // the frame table, read once
 
@@ -1522,12 +1526,19 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
         if (lane == 0) {
             s_dec[buf][0] = 1; s_dec[buf][1] = l; s_dec[buf][2] = m; s_dec[buf][3] = f; s_dec[buf][4] = clip;
             s_dec[buf][5] = r0; s_dec[buf][6] = r1; s_dec[buf][7] = direct ? 1 : 0;
-            s_src_t[buf][0] = f; s_src_vl[buf][0] = l;
+            const int64_t g = (int64_t)clip * p.frames + f;
+            s_src_tab[buf][0] = ((g * p.M + m) * VL + l) * p.Lq;
+            s_src_loc[buf][0] = (g * p.Lq * p.M + m) * ((int64_t)p.LA * p.PA) + l * p.PA;
+            s_src_q0[buf][0] = (int)(g * p.Lq);
             s_nsrc[buf] = ((dbg & 4) || ((dbg >> 8) & (1 << l))) ? 0 : 1 + (int)__popcll(bal);    // dbg: skip all / a level's sources
         }
         if (hit) {
             const int n = 1 + (int)__popcll(bal & ((1ull << lane) - 1ull)), t = lane / p.window;
-            s_src_t[buf][n] = t; s_src_vl[buf][n] = (lane - t * p.window) * L + l;
+            const int vl = (lane - t * p.window) * L + l;
+            const int64_t g = (int64_t)clip * p.frames + t;
+            s_src_tab[buf][n] = ((g * p.M + m) * VL + p.LA + vl) * p.Lq;
+            s_src_loc[buf][n] = (g * p.Lq * p.M + m) * ((int64_t)p.LB * p.PB) + vl * p.PB;
+            s_src_q0[buf][n] = (int)(g * p.Lq);
         }
     };
     auto load_item = [&](int buf) {
@@ -1538,16 +1549,9 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
         it.H = it.valid ? s_H[it.l] : 1; it.W = it.valid ? s_W[it.l] : 1;
         return it;
     };
-    auto source_of = [&](int buf, int k, int &t, int &vl, int &vlg, int &P, int &LP, const T *&loc, const T *&aw) {
-        t = s_src_t[buf][k]; vl = s_src_vl[buf][k];
-        const bool cur = (k == 0);
-        vlg = cur ? vl : p.LA + vl;
-        P = cur ? p.PA : p.PB;
-        LP = cur ? p.LA * p.PA : p.LB * p.PB;
-        loc = static_cast<const T *>(cur ? p.locA : p.locB);
-        aw = static_cast<const T *>(cur ? p.awA : p.awB);
-    };
     // the per-point rows of U groups per thread, all loads in flight together
+    const float inv_Lq = 1.0f / (float)p.Lq;
+    const int strideA = p.M * p.LA * p.PA, strideB = p.M * p.LB * p.PB;      // loc/attn elements per query
     auto cull_load = [&](const Item &it, int buf, int gi0, int2 (&iv)[U], unsigned (&ent)[U]) {
         const int ng = s_nsrc[buf] * p.Lq;
 #pragma unroll
@@ -1556,12 +1560,16 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
             iv[u] = make_int2((int)0x80008000u, (int)0x80008000u);
             ent[u] = 0u;
             if (gi < ng) {
-                const int k = gi / p.Lq, q = gi - k * p.Lq;
-                int t, vl, vlg, P, LP;
-                const T *loc, *aw;
-                source_of(buf, k, t, vl, vlg, P, LP, loc, aw);
-                const int64_t gm = (((int64_t)it.clip * p.frames + t) * p.M + it.m) * VL + vlg;
-                iv[u] = *reinterpret_cast<const int2 *>(p.bbox + (gm * p.Lq + q) * 2);
+                int k, q;
+                if (ng < (1 << 22)) {       // gi / Lq by reciprocal: exact to +-1 below 2^22, then fixed up
+                    k = (int)((float)gi * inv_Lq);
+                    q = gi - k * p.Lq;
+                    if (q < 0) { --k; q += p.Lq; }
+                    if (q >= p.Lq) { ++k; q -= p.Lq; }
+                } else {
+                    k = gi / p.Lq; q = gi - k * p.Lq;
+                }
+                iv[u] = *reinterpret_cast<const int2 *>(p.bbox + (s_src_tab[buf][k] + q) * 2);
                 ent[u] = ((unsigned)k << 26) | (unsigned)q;
             }
         }
@@ -1660,15 +1668,15 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
         x = y = -10.f; a = 0.f; qrow = 0;
         if (i < listed) {
             const unsigned e = (unsigned)s_list[i];
-            int t, vl, vlg, P, LP;
-            const T *loc, *aw;
-            source_of(buf, (int)(e >> 26), t, vl, vlg, P, LP, loc, aw);
-            const int64_t gq = ((int64_t)it.clip * p.frames + t) * p.Lq + (int)(e & 0xffffffu);
-            const int64_t idx = (gq * p.M + it.m) * LP + vl * P + (int)((e >> 24) & 3u);
+            const int k = (int)(e >> 26), q = (int)(e & 0xffffffu);
+            const bool curf = (k == 0);
+            const int64_t idx = s_src_loc[buf][k] + (int64_t)q * (curf ? strideA : strideB) + (int)((e >> 24) & 3u);
+            const T *loc = static_cast<const T *>(curf ? p.locA : p.locB);
+            const T *aw = static_cast<const T *>(curf ? p.awA : p.awB);
             x = Store<T>::get(loc + 2 * idx);
             y = Store<T>::get(loc + 2 * idx + 1);
             a = Store<T>::get(aw + idx);
-            qrow = (int)gq;
+            qrow = s_src_q0[buf][k] + q;
         }
     };
     // Scans the `listed` points of s_list (one per lane per pass); `primed`: the first pass's (x, y, attn)
@@ -2201,7 +2209,7 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     }
     {
         // pixels the scatter will not overwrite (normally none) are zero-filled first
-        const int slots = cap_bytes / 8 - (p.cull_points ? 2 * p.D : 0);
+        const int slots = (p.cull_points ? (cap_bytes < kPointsCapBytes ? cap_bytes : kPointsCapBytes) / 8 - 2 * p.D : cap_bytes / 8);
         const int64_t rows = (int64_t)p.groups * p.S;
         const unsigned zb = (unsigned)((rows + 255) / 256 < 16384 ? (rows + 255) / 256 : 16384);
         hipLaunchKernelGGL(msda_zero_unowned_kernel, dim3(zb), dim3(256), 0, stream, p, slots);
@@ -2210,14 +2218,15 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     }
     if (p.cull_points) {
         static int lds_limit_points = 0;
-        if (cap_bytes > lds_limit_points) {
+        const int cap_pts = cap_bytes < kPointsCapBytes ? cap_bytes : kPointsCapBytes;   // its static tables need ~17 KiB
+        if (cap_pts > lds_limit_points) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_value_points_kernel<T, G>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, cap_bytes) != hipSuccess)
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, cap_pts) != hipSuccess)
                 return fail(MSDA_ERR_HIP, "msda backward: cannot reserve the LDS budget of the scatter kernel%s");
-            lds_limit_points = cap_bytes;
+            lds_limit_points = cap_pts;
         }
         hipLaunchKernelGGL((msda_bwd_value_points_kernel<T, G>), dim3(grid), dim3(kScatterThreads),
-                           (size_t)cap_bytes, stream, p, cap_bytes / 8, env_int("MSDA_SCATTER_DBG", 0));
+                           (size_t)cap_pts, stream, p, cap_pts / 8, env_int("MSDA_SCATTER_DBG", 0));
         return check_launch("msda backward (LDS scatter kernel, per-point culling)");
     }
     hipLaunchKernelGGL((msda_bwd_value_lds_kernel<T, G>), dim3(grid), dim3(kScatterThreads),
