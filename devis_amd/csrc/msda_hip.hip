@@ -2106,6 +2106,7 @@ bool scatter_applicable(const Params &p)
     if (p.L > kScatterMaxLevels || (p.D % 4) != 0) return false;
     if (1 + p.frames * p.window > kScatterMaxSources || p.Lq >= (1 << 24)) return false;   // survivor-list entry fields
     if (p.window == 0 && p.LA != p.L) return false;
+    if ((int64_t)p.groups * p.Lq >= 0x7fffffffLL) return false;       // query rows are 32-bit in the hit records
     return true;
 }
 

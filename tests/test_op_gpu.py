@@ -254,7 +254,12 @@ def test_full_size_properties_cfg3():
 @pytest.mark.parametrize("env", [{"MSDA_BWD_MODE": "atomic"},            # one-kernel backward, global float atomics
                                  {"MSDA_SCATTER_LDS_KB": "1"},           # no level row fits LDS -> "direct" branch
                                  {"MSDA_SCATTER_LDS_KB": "8"},           # many thin bands, straddling points
-                                 {"MSDA_SCATTER_WG_PER_CU": "3"}])
+                                 {"MSDA_SCATTER_WG_PER_CU": "3"},
+                                 {"MSDA_SCATTER_DBG": "16"},             # static item order: the software pipeline
+                                 {"MSDA_SCATTER_DBG": "16", "MSDA_SCATTER_LDS_KB": "8"},
+                                 {"MSDA_BWD_CULL": "2"},                 # interval culling records (legacy scatter)
+                                 {"MSDA_BWD_CULL": "2", "MSDA_SCATTER_DBG": "16"},
+                                 {"MSDA_BWD_CULL": "0"}])                # no culling table at all
 def test_backward_alternate_routes(env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -494,3 +499,19 @@ def test_head_major_value_layout(route, monkeypatch):
     got = _run_temporal(dt, torch.float32, head_major=True)
     for a, b in zip(got, ref):
         assert _maxabs(a, b) <= 2e-5 * max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("env", [{}, {"MSDA_SCATTER_DBG": "16"}, {"MSDA_BWD_CULL": "2"}])
+def test_scatter_survivor_list_overflow(env, monkeypatch):
+    """More surviving points per cull batch than the survivor list holds (dense single-band levels, long
+    candidate ranges): the prefix-scan-and-retry path, in dynamic and static item order."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    d = make_inputs(77, 2, 8, 32, 2600, [(6, 5), (3, 3)], 4, "unit", np.float32)
+    ref = oracle_fwd_bwd(d, np.float64)
+    ref32 = oracle_fwd_bwd(d, np.float32)      # grad_loc: same-arithmetic oracle (cell borders, see above)
+    out, gv, gl, ga = _run_op(d, torch.float32)
+    assert _maxabs(out, ref[0]) <= 1e-5
+    assert _maxabs(gv, ref32[1]) <= 1e-4 * max(1.0, np.abs(ref[1]).max())
+    assert _maxabs(gl, ref32[2]) <= 1e-4 * max(1.0, np.abs(ref32[2]).max())
+    assert _maxabs(ga, ref32[3]) <= 1e-4 * max(1.0, np.abs(ref[3]).max())
