@@ -774,12 +774,14 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
                 const int4 *ro = s_off + r * kRowSlots;
                 const float4 *rw = s_w + r * kRowSlots;
                 const float4 *re = s_e + r * kRowSlots;
+                // The four reduced dots of point pp are kept by lane pp % G of the row; after G points (or
+                // at the chunk's end) every lane finishes ITS point at once -- cuh:123-158 rewritten on the
+                // reduced dots -- instead of one lane in G finishing each point under an exec mask.  The
+                // main loop then reads only the offsets record.
+                float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f;
 #pragma unroll 2
                 for (int pp = 0; pp < np; ++pp) {
                     const int4 o = ro[pp];
-                    const float4 w = rw[pp];
-                    const float4 e = re[pp];
-                    const int bits = __float_as_int(e.w);
                     const bool in_slab = (c0 + pp) / P >= l0;          // wave-uniform
                     float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
                     if (in_slab) {
@@ -801,18 +803,24 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
                         d2 = fmaf(g[c], v2[c], d2);
                         d3 = fmaf(g[c], v3[c], d3);
                     }
-                    d0 = (bits & 1) ? d0 : 0.f;
-                    d1 = (bits & 2) ? d1 : 0.f;
-                    d2 = (bits & 4) ? d2 : 0.f;
-                    d3 = (bits & 8) ? d3 : 0.f;
                     d0 = row_sum<G>(d0); d1 = row_sum<G>(d1); d2 = row_sum<G>(d2); d3 = row_sum<G>(d3);
-                    if (sub == (pp % G)) {
-                        const float a = e.x, lh = e.y, lw = e.z, hh = 1.f - lh, hw = 1.f - lw;
-                        const Level lv = s_lvl[bits >> 4];
-                        const float g_aw = w.x * d0 + w.y * d1 + w.z * d2 + w.w * d3;
-                        const float g_w = hh * (d1 - d0) + lh * (d3 - d2);
-                        const float g_h = hw * (d2 - d0) + lw * (d3 - d1);
-                        s_e[r * kRowSlots + pp] = make_float4((float)lv.W * g_w * a, (float)lv.H * g_h * a, g_aw, 0.f);
+                    const bool mine = sub == (pp & (G - 1));
+                    k0 = mine ? d0 : k0; k1 = mine ? d1 : k1; k2 = mine ? d2 : k2; k3 = mine ? d3 : k3;
+                    if ((pp & (G - 1)) == G - 1 || pp == np - 1) {      // wave-uniform
+                        const int mp = (pp & ~(G - 1)) + sub;
+                        if (mp <= pp) {
+                            const float4 w = rw[mp];
+                            const float4 e = re[mp];
+                            const int bits = __float_as_int(e.w);
+                            const float q0d = (bits & 1) ? k0 : 0.f, q1d = (bits & 2) ? k1 : 0.f;
+                            const float q2d = (bits & 4) ? k2 : 0.f, q3d = (bits & 8) ? k3 : 0.f;
+                            const float a = e.x, lh = e.y, lw = e.z, hh = 1.f - lh, hw = 1.f - lw;
+                            const Level lv = s_lvl[bits >> 4];
+                            const float g_aw = w.x * q0d + w.y * q1d + w.z * q2d + w.w * q3d;
+                            const float g_w = hh * (q1d - q0d) + lh * (q3d - q2d);
+                            const float g_h = hw * (q2d - q0d) + lw * (q3d - q1d);
+                            s_e[r * kRowSlots + mp] = make_float4((float)lv.W * g_w * a, (float)lv.H * g_h * a, g_aw, 0.f);
+                        }
                     }
                 }
                 wave_sync();
@@ -1666,7 +1674,7 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
     };
     auto fetchp = [&](const Item &it, int buf, int i, int listed, float &x, float &y, float &a, int &qrow) {
         x = y = -10.f; a = 0.f; qrow = 0;
-        if (i < listed) {
+        if (i < listed && !(dbg & 64)) {      // dbg 64: no loc/attn reads (measurement)
             const unsigned e = (unsigned)s_list[i];
             const int k = (int)(e >> 26), q = (int)(e & 0xffffffu);
             const bool curf = (k == 0);
