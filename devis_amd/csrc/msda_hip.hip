@@ -904,19 +904,19 @@ msda_bwd_tile_kernel(const Params p)
             const int4 *ro = s_off + r * kRowSlots;
             const float4 *rw = s_w + r * kRowSlots;
             const float4 *re = s_e + r * kRowSlots;
+            // The four reduced dots of point pp are kept by lane pp % G of the row; after G points (or at
+            // the chunk's end) every lane finishes ITS point at once (cuh:123-158 rewritten on the reduced
+            // dots) instead of one lane in G finishing each point under an exec mask.
+            float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f;
 #pragma unroll 2
             for (int pp = 0; pp < np; ++pp) {
                 const int4 o = ro[pp];
-                const float4 w = rw[pp];
-                const float4 e = re[pp];
-                const int bits = __float_as_int(e.w);
                 float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
                 Store<T>::load(value + o.x, v0);
                 Store<T>::load(value + o.y, v1);
                 Store<T>::load(value + o.z, v2);
                 Store<T>::load(value + o.w, v3);
-                // d_k = <grad_out row, corner k> over this lane's channels (0 for invalid corners:
-                // their weight is 0 in every formula below except the fraction terms, so mask here)
+                // d_k = <grad_out row, corner k> over this lane's channels
                 float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) {
@@ -925,14 +925,13 @@ msda_bwd_tile_kernel(const Params p)
                     d2 = fmaf(g[c], v2[c], d2);
                     d3 = fmaf(g[c], v3[c], d3);
                 }
-                d0 = (bits & 1) ? d0 : 0.f;
-                d1 = (bits & 2) ? d1 : 0.f;
-                d2 = (bits & 4) ? d2 : 0.f;
-                d3 = (bits & 8) ? d3 : 0.f;
-                // grad_value[corner k] += w_k * a * grad_out   (cuh:125,134,143,152)
-                const float a = e.x;
-                const float wa0 = w.x * a, wa1 = w.y * a, wa2 = w.z * a, wa3 = w.w * a;
                 if (ATOMICS) {
+                    // grad_value[corner k] += w_k * a * grad_out   (cuh:125,134,143,152)
+                    const float4 w = rw[pp];
+                    const float4 e = re[pp];
+                    const int bits = __float_as_int(e.w);
+                    const float a = e.x;
+                    const float wa0 = w.x * a, wa1 = w.y * a, wa2 = w.z * a, wa3 = w.w * a;
                     if (bits & 1) {
 #pragma unroll
                         for (int c = 0; c < VEC; ++c) atomic_accumulate(gvalue + o.x + c, wa0 * g[c]);
@@ -956,17 +955,28 @@ msda_bwd_tile_kernel(const Params p)
                     d2 = row_sum<G>(d2);
                     d3 = row_sum<G>(d3);
                 }
-                // one lane per (row, point) finishes: cuh:123-158 rewritten on the reduced dots
-                if (sub == (pp % G)) {
-                    const float lh = e.y, lw = e.z, hh = 1.f - lh, hw = 1.f - lw;
-                    const Level lv = s_lvl[bits >> 4];
-                    const float g_aw = w.x * d0 + w.y * d1 + w.z * d2 + w.w * d3;
-                    const float g_w = hh * (d1 - d0) + lh * (d3 - d2);
-                    const float g_h = hw * (d2 - d0) + lw * (d3 - d1);
-                    // park the point's three gradients in its (now consumed) LDS slot; they leave for
-                    // HBM below as whole rows -- one 4-byte store per point and component cost as much
-                    // as the entire gather (measured: 91 -> 52 us per clip without them)
-                    s_e[r * kRowSlots + pp] = make_float4((float)lv.W * g_w * a, (float)lv.H * g_h * a, g_aw, 0.f);
+                const bool mine = sub == (pp & (G - 1));
+                k0 = mine ? d0 : k0; k1 = mine ? d1 : k1; k2 = mine ? d2 : k2; k3 = mine ? d3 : k3;
+                if ((pp & (G - 1)) == G - 1 || pp == np - 1) {      // wave-uniform
+                    const int mp = (pp & ~(G - 1)) + sub;
+                    if (mp <= pp) {
+                        const float4 w = rw[mp];
+                        const float4 e = re[mp];
+                        const int bits = __float_as_int(e.w);
+                        // invalid corners count as zeros in every formula (their weight is not 0 in the
+                        // fraction terms, so mask the dots)
+                        const float q0d = (bits & 1) ? k0 : 0.f, q1d = (bits & 2) ? k1 : 0.f;
+                        const float q2d = (bits & 4) ? k2 : 0.f, q3d = (bits & 8) ? k3 : 0.f;
+                        const float a = e.x, lh = e.y, lw = e.z, hh = 1.f - lh, hw = 1.f - lw;
+                        const Level lv = s_lvl[bits >> 4];
+                        const float g_aw = w.x * q0d + w.y * q1d + w.z * q2d + w.w * q3d;
+                        const float g_w = hh * (q1d - q0d) + lh * (q3d - q2d);
+                        const float g_h = hw * (q2d - q0d) + lw * (q3d - q1d);
+                        // park the point's three gradients in its (now consumed) LDS slot; they leave for
+                        // HBM below as whole rows -- one 4-byte store per point and component cost as much
+                        // as the entire gather (measured: 91 -> 52 us per clip without them)
+                        s_e[r * kRowSlots + mp] = make_float4((float)lv.W * g_w * a, (float)lv.H * g_h * a, g_aw, 0.f);
+                    }
                 }
             }
             __syncthreads();
