@@ -1742,8 +1742,8 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
 #pragma unroll
                     for (int c = 0; c < VEC; ++c) h.g[c] = Store<T>::get(go + ((c + team) % VEC) * G + sub);
                 }
-                consume(it, pend);
-                pend = h;
+                // (8-channel lanes: no one-group-ahead pipelining, the second record does not fit the registers)
+                if constexpr (VEC > 4) { consume(it, h); } else { consume(it, pend); pend = h; }
             };
             if constexpr (G == 4 || G == 8) {
                 static_for<G>(sub_round);
@@ -1765,8 +1765,7 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
 #pragma unroll
                         for (int c = 0; c < VEC; ++c) h.g[c] = Store<T>::get(go + ((c + team) % VEC) * G + sub);
                     }
-                    consume(it, pend);
-                    pend = h;
+                    if constexpr (VEC > 4) { consume(it, h); } else { consume(it, pend); pend = h; }
                 }
             }
         }
