@@ -260,8 +260,8 @@ def main():
         # the library runs the slab forward when there are >= 2 workgroups of 16 tiles per CU, else the tile forward
         n_cu = torch.cuda.get_device_properties(device).multi_processor_count
         slab_blocks = args.clips * ((T * ((q + 7) // 8) + 15) // 16) * M
-        use_slab = dtype == torch.float32 and slab_blocks >= 2 * n_cu
-        fwd_name = "msda_fwd_slab_kernel" if use_slab else "msda_fwd_tile_kernel"
+        use_slab = slab_blocks >= 2 * n_cu
+        fwd_name = "msda_fwd_slab_kernel" if (use_slab and dtype == torch.float32) else "msda_fwd_tile_kernel"
         gat_name = "msda_bwd_slab_kernel" if use_slab else "msda_bwd_tile_kernel"
         # <= 4 points per level: the gather pass leaves per-point culling records and the pipelined scatter runs
         pts = max(int(b["loc_c"].shape[4]), int(b["loc_t"].shape[4]))

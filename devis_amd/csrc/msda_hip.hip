@@ -118,6 +118,46 @@ template <> struct Store<double> {
     __device__ static void put(double *p, double v) { *p = v; }
 };
 
+// Storage policy of the slab kernels: 4 channels per lane for every dtype (8-byte lanes for the 16-bit
+// types), so that a wave is 8 rows x 8 lanes at D = 32 whatever the dtype: the per-wave record area stays
+// 4.4 KiB, 16 waves fit beside the slab, and a 16-bit gather instruction touches 8 granules, not 16.
+template <typename T> struct SlabStore : Store<T> {};
+template <> struct SlabStore<bf16_t> {
+    static constexpr int VEC = 4;
+    __device__ static float get(const bf16_t *p) { return __bfloat162float(*p); }
+    __device__ static void put(bf16_t *p, float v) { *p = __float2bfloat16(v); }
+    __device__ static void load(const bf16_t *p, float (&v)[4]) {
+        const uint2 t = *reinterpret_cast<const uint2 *>(p);
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    }
+    __device__ static void store(bf16_t *p, const float (&v)[4]) {
+        uint32_t w[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16_t lo = __float2bfloat16(v[2 * i]), hi = __float2bfloat16(v[2 * i + 1]);
+            w[i] = (uint32_t)(*reinterpret_cast<const uint16_t *>(&lo)) |
+                   ((uint32_t)(*reinterpret_cast<const uint16_t *>(&hi)) << 16);
+        }
+        *reinterpret_cast<uint2 *>(p) = make_uint2(w[0], w[1]);
+    }
+};
+template <> struct SlabStore<f16_t> {
+    static constexpr int VEC = 4;
+    __device__ static float get(const f16_t *p) { return __half2float(*p); }
+    __device__ static void put(f16_t *p, float v) { *p = __float2half(v); }
+    __device__ static void load(const f16_t *p, float (&v)[4]) {
+        const uint2 t = *reinterpret_cast<const uint2 *>(p);
+        const float2 a = __half22float2(*reinterpret_cast<const __half2 *>(&t.x));
+        const float2 b = __half22float2(*reinterpret_cast<const __half2 *>(&t.y));
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    }
+    __device__ static void store(f16_t *p, const float (&v)[4]) {
+        const __half2 a = __floats2half2_rn(v[0], v[1]), b = __floats2half2_rn(v[2], v[3]);
+        *reinterpret_cast<uint2 *>(p) = make_uint2(*reinterpret_cast<const uint32_t *>(&a), *reinterpret_cast<const uint32_t *>(&b));
+    }
+};
+
 // hardware float atomics (global_atomic_add_f32 / _f64, no return value, no CAS loop)
 __device__ __forceinline__ void atomic_accumulate(float *p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_accumulate(double *p, double v) { unsafeAtomicAdd(p, v); }
@@ -454,7 +494,7 @@ template <typename T, int G, int NB>
 __global__ void __launch_bounds__(kSlabThreads)
 msda_fwd_slab_kernel(const Params p, int slab_elems)
 {
-    constexpr int VEC = Store<T>::VEC;
+    constexpr int VEC = SlabStore<T>::VEC;
     constexpr int RPW = kWave / G;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ int s_sH[kSlabMaxLevels], s_sW[kSlabMaxLevels], s_sStart[kSlabMaxLevels];
@@ -513,12 +553,13 @@ msda_fwd_slab_kernel(const Params p, int slab_elems)
     for (int f = 0; f < p.frames; ++f) {
         __syncthreads();                                   // every wave is done with the previous slab
         if (l0 < L) {
-            constexpr int PXW = kWave / G;                 // pixels per LDS-DMA wave instruction
+            constexpr int GS = G * VEC * (int)sizeof(T) >= 16 ? G * VEC * (int)sizeof(T) / 16 : 1;      // 16-byte DMA lanes per pixel
+            constexpr int PXW = kWave / GS;                 // pixels per LDS-DMA wave instruction
             const T *src = static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head +
                            ((int64_t)f * p.S + px0) * p.v_pix;
             for (int pb = wave * PXW; pb < npx; pb += kSlabWaves * PXW) {
-                const int px = min(pb + lane / G, npx - 1);
-                const T *gp = src + (int64_t)px * p.v_pix + (lane % G) * VEC;
+                const int px = min(pb + lane / GS, npx - 1);
+                const T *gp = src + (int64_t)px * p.v_pix + (lane % GS) * (16 / (int)sizeof(T));
 #if defined(__HIP_DEVICE_COMPILE__)      // device-only builtin: keep the host pass (kernel stub) clean
                 __builtin_amdgcn_global_load_lds(
                     gp, (__attribute__((address_space(3))) void *)(slab + (size_t)pb * D), 16, 0, 0);
@@ -552,9 +593,9 @@ msda_fwd_slab_kernel(const Params p, int slab_elems)
                     float x = -10.f, y = -10.f, a = 0.f;
                     if (rr < rows_valid && kk < npts) {
                         const int64_t idx = (row0 + (int64_t)rr * p.M) * LP + pt0 + kk;
-                        x = Store<T>::get(loc + 2 * idx);
-                        y = Store<T>::get(loc + 2 * idx + 1);
-                        a = Store<T>::get(aw + idx);
+                        x = SlabStore<T>::get(loc + 2 * idx);
+                        y = SlabStore<T>::get(loc + 2 * idx + 1);
+                        a = SlabStore<T>::get(aw + idx);
                     }
                     const int l = min(kk, npts - 1) / P;
                     Taps tp;
@@ -584,15 +625,15 @@ msda_fwd_slab_kernel(const Params p, int slab_elems)
                         const bool in_slab = min(c0 + pp + b, npts - 1) / P >= l0;     // wave-uniform
                         const T *base = in_slab ? slab_lane : value;
                         if (in_slab) {
-                            Store<T>::load(slab_lane + o[b].x, v[b][0]);
-                            Store<T>::load(slab_lane + o[b].y, v[b][1]);
-                            Store<T>::load(slab_lane + o[b].z, v[b][2]);
-                            Store<T>::load(slab_lane + o[b].w, v[b][3]);
+                            SlabStore<T>::load(slab_lane + o[b].x, v[b][0]);
+                            SlabStore<T>::load(slab_lane + o[b].y, v[b][1]);
+                            SlabStore<T>::load(slab_lane + o[b].z, v[b][2]);
+                            SlabStore<T>::load(slab_lane + o[b].w, v[b][3]);
                         } else {
-                            Store<T>::load(value + o[b].x, v[b][0]);
-                            Store<T>::load(value + o[b].y, v[b][1]);
-                            Store<T>::load(value + o[b].z, v[b][2]);
-                            Store<T>::load(value + o[b].w, v[b][3]);
+                            SlabStore<T>::load(value + o[b].x, v[b][0]);
+                            SlabStore<T>::load(value + o[b].y, v[b][1]);
+                            SlabStore<T>::load(value + o[b].z, v[b][2]);
+                            SlabStore<T>::load(value + o[b].w, v[b][3]);
                         }
                         (void)base;
                     }
@@ -613,7 +654,7 @@ msda_fwd_slab_kernel(const Params p, int slab_elems)
     }
     if (r < rows_valid) {
         T *out = static_cast<T *>(p.out) + (row0 + (int64_t)r * p.M) * D + sub * VEC;
-        Store<T>::store(out, acc);
+        SlabStore<T>::store(out, acc);
     }
 }
 
@@ -646,7 +687,7 @@ template <typename T, int G>
 __global__ void __launch_bounds__(kSlabThreads)
 msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
 {
-    constexpr int VEC = Store<T>::VEC;
+    constexpr int VEC = SlabStore<T>::VEC;
     constexpr int RPW = kWave / G;
     constexpr int NW = kSlabWaves;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -702,17 +743,18 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
     float g[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) g[c] = 0.f;
-    if (r < rows_valid) Store<T>::load(static_cast<const T *>(p.grad_out) + row * D + sub * VEC, g);
+    if (r < rows_valid) SlabStore<T>::load(static_cast<const T *>(p.grad_out) + row * D + sub * VEC, g);
 
     for (int f = 0; f < p.frames; ++f) {
         __syncthreads();
         if (l0 < L) {
-            constexpr int PXW = kWave / G;
+            constexpr int GS = G * VEC * (int)sizeof(T) >= 16 ? G * VEC * (int)sizeof(T) / 16 : 1;      // 16-byte DMA lanes per pixel
+            constexpr int PXW = kWave / GS;
             const T *src = static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head +
                            ((int64_t)f * p.S + px0) * p.v_pix;
             for (int pb = wave * PXW; pb < npx; pb += NW * PXW) {
-                const int px = min(pb + lane / G, npx - 1);
-                const T *gp = src + (int64_t)px * p.v_pix + (lane % G) * VEC;
+                const int px = min(pb + lane / GS, npx - 1);
+                const T *gp = src + (int64_t)px * p.v_pix + (lane % GS) * (16 / (int)sizeof(T));
 #if defined(__HIP_DEVICE_COMPILE__)
                 __builtin_amdgcn_global_load_lds(
                     gp, (__attribute__((address_space(3))) void *)(slab + (size_t)pb * D), 16, 0, 0);
@@ -751,9 +793,9 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
                     float x = -10.f, y = -10.f, a = 0.f;
                     if (rr < rows_valid && kk < npts) {
                         const int64_t idx = (row0 + (int64_t)rr * p.M) * LP + pt0 + kk;
-                        x = Store<T>::get(loc + 2 * idx);
-                        y = Store<T>::get(loc + 2 * idx + 1);
-                        a = Store<T>::get(aw + idx);
+                        x = SlabStore<T>::get(loc + 2 * idx);
+                        y = SlabStore<T>::get(loc + 2 * idx + 1);
+                        a = SlabStore<T>::get(aw + idx);
                     }
                     const int l = min(kk, npts - 1) / P, vl = vl0 + l;
                     Taps tp;
@@ -785,15 +827,15 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
                     const bool in_slab = (c0 + pp) / P >= l0;          // wave-uniform
                     float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
                     if (in_slab) {
-                        Store<T>::load(slab_lane + o.x, v0);
-                        Store<T>::load(slab_lane + o.y, v1);
-                        Store<T>::load(slab_lane + o.z, v2);
-                        Store<T>::load(slab_lane + o.w, v3);
+                        SlabStore<T>::load(slab_lane + o.x, v0);
+                        SlabStore<T>::load(slab_lane + o.y, v1);
+                        SlabStore<T>::load(slab_lane + o.z, v2);
+                        SlabStore<T>::load(slab_lane + o.w, v3);
                     } else {
-                        Store<T>::load(value + o.x, v0);
-                        Store<T>::load(value + o.y, v1);
-                        Store<T>::load(value + o.z, v2);
-                        Store<T>::load(value + o.w, v3);
+                        SlabStore<T>::load(value + o.x, v0);
+                        SlabStore<T>::load(value + o.y, v1);
+                        SlabStore<T>::load(value + o.z, v2);
+                        SlabStore<T>::load(value + o.w, v3);
                     }
                     float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
@@ -828,9 +870,9 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
                     const int64_t idx0 = row * LP + pt0 + c0;
                     const float *res = reinterpret_cast<const float *>(s_e + r * kRowSlots);
                     for (int el = sub; el < 2 * np; el += G)
-                        Store<T>::put(gloc + 2 * idx0 + el, res[(el >> 1) * 4 + (el & 1)]);
+                        SlabStore<T>::put(gloc + 2 * idx0 + el, res[(el >> 1) * 4 + (el & 1)]);
                     for (int el = sub; el < np; el += G)
-                        Store<T>::put(gaw + idx0 + el, res[el * 4 + 2]);
+                        SlabStore<T>::put(gaw + idx0 + el, res[el * 4 + 2]);
                 }
                 wave_sync();
             }
@@ -2135,25 +2177,31 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     const int64_t blocks = tiles * p.M;
     if (blocks > 0x7fffffffLL) return fail(MSDA_ERR_ARG, "msda: problem too large for one launch%s");
     const size_t lds = tile_lds_bytes(RPW, p.LA + p.LB, bwd, bwd && p.bbox != nullptr);
-    if (!bwd && sizeof(T) == 4 && p.LA == p.L && p.L <= kSlabMaxLevels) {
-        // slab forward: 16 waves per workgroup share the small levels in LDS; needs enough workgroups
-        const int tiles_per_clip = p.frames * ((p.Lq + RPW - 1) / RPW);
+    // the slab kernels run 4 channels per lane for every dtype (SlabStore): twice the lanes per row for 16-bit types
+    constexpr int GSL = SlabStore<T>::VEC == Store<T>::VEC ? G : 2 * G;
+    constexpr int RPWS = kWave / (GSL <= kWave ? GSL : kWave);
+    if constexpr (GSL <= kWave) if (!bwd && p.LA == p.L && p.L <= kSlabMaxLevels) {
+        // slab forward: 16 waves per workgroup share the small levels in LDS; needs enough workgroups.
+        // Picked automatically for 4-byte types only: for the 16-bit types the 16-byte-lane tile kernel (half
+        // the instructions per point) is as fast or faster (cfg2 bf16: 0.48 vs 0.57 ms); the gather pass
+        // below does profit (0.85 -> 0.75 ms) and takes the slab for every dtype.
+        const int tiles_per_clip = p.frames * ((p.Lq + RPWS - 1) / RPWS);
         const int blocks_per_clip = (tiles_per_clip + kSlabWaves - 1) / kSlabWaves;
         const int64_t slab_blocks = (int64_t)(p.groups / p.frames) * blocks_per_clip * p.M;
         const int mode = env_int("MSDA_FWD_SLAB", -1);                 // -1 auto, 0 off, 1 force
-        const size_t per_wave = (size_t)RPW * kRowSlots * 32 + (size_t)(p.LA + p.LB) * sizeof(Level);
+        const size_t per_wave = (size_t)RPWS * kRowSlots * 32 + (size_t)(p.LA + p.LB) * sizeof(Level);
         const long long slab_bytes = ((160 * 1024 - 1024 - (long long)kSlabWaves * (long long)per_wave) / 1024) * 1024;
-        if (mode != 0 && slab_bytes >= 16 * 1024 && (mode == 1 || slab_blocks >= 2 * device_cus()) &&
+        if (mode != 0 && slab_bytes >= 16 * 1024 && (mode == 1 || (slab_blocks >= 2 * device_cus() && sizeof(T) == 4)) &&
             slab_blocks <= 0x7fffffffLL) {
             const size_t total = (size_t)slab_bytes + kSlabWaves * per_wave;
             static size_t limit_set = 0;
             if (total > limit_set) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_slab_kernel<T, G, 4>),
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_slab_kernel<T, GSL, 4>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)total) != hipSuccess)
                     return fail(MSDA_ERR_HIP, "msda forward: cannot reserve the LDS budget of the slab kernel%s");
                 limit_set = total;
             }
-            hipLaunchKernelGGL((msda_fwd_slab_kernel<T, G, 4>), dim3((unsigned)slab_blocks), dim3(kSlabThreads),
+            hipLaunchKernelGGL((msda_fwd_slab_kernel<T, GSL, 4>), dim3((unsigned)slab_blocks), dim3(kSlabThreads),
                                total, stream, p, (int)(slab_bytes / (long long)sizeof(T)));
             return check_launch("msda forward (slab kernel)");
         }
@@ -2180,13 +2228,13 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     int rc = MSDA_OK;
     if (phases & 1) {
         bool done = false;
-        if (sizeof(T) == 4 && p.LA == p.L && p.L <= kSlabMaxLevels) {      // slab variant of the gather pass
-            const int tiles_per_clip = p.frames * ((p.Lq + RPW - 1) / RPW);
+        if constexpr (GSL <= kWave) if (p.LA == p.L && p.L <= kSlabMaxLevels) {      // slab variant of the gather pass
+            const int tiles_per_clip = p.frames * ((p.Lq + RPWS - 1) / RPWS);
             const int blocks_per_clip = (tiles_per_clip + kSlabWaves - 1) / kSlabWaves;
             const int64_t slab_blocks = (int64_t)(p.groups / p.frames) * blocks_per_clip * p.M;
             const int mode = env_int("MSDA_BWD_SLAB", -1);              // -1 auto, 0 off, 1 force
-            const size_t per_wave = (size_t)RPW * kRowSlots * 48 + (size_t)(p.LA + p.LB) * sizeof(Level) +
-                                    (p.bbox ? (size_t)RPW * p.L * 8 : 0);
+            const size_t per_wave = (size_t)RPWS * kRowSlots * 48 + (size_t)(p.LA + p.LB) * sizeof(Level) +
+                                    (p.bbox ? (size_t)RPWS * p.L * 8 : 0);
             const long long slab_bytes =
                 ((160 * 1024 - 1024 - (long long)kSlabWaves * (long long)per_wave) / 1024) * 1024;
             if (mode != 0 && slab_bytes >= 16 * 1024 && (mode == 1 || slab_blocks >= 2 * device_cus()) &&
@@ -2194,12 +2242,12 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
                 const size_t total = (size_t)slab_bytes + kSlabWaves * per_wave;
                 static size_t limit_set = 0;
                 if (total > limit_set) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_slab_kernel<T, G>),
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_slab_kernel<T, GSL>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)total) != hipSuccess)
                         return fail(MSDA_ERR_HIP, "msda backward: cannot reserve the LDS budget of the slab kernel%s");
                     limit_set = total;
                 }
-                hipLaunchKernelGGL((msda_bwd_slab_kernel<T, G>), dim3((unsigned)slab_blocks), dim3(kSlabThreads),
+                hipLaunchKernelGGL((msda_bwd_slab_kernel<T, GSL>), dim3((unsigned)slab_blocks), dim3(kSlabThreads),
                                    total, stream, p, (int)(slab_bytes / (long long)sizeof(T)), (int)per_wave);
                 rc = check_launch("msda backward (slab kernel, grad_loc/grad_attn)");
                 if (rc) return rc;

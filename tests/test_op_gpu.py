@@ -75,10 +75,14 @@ def test_generic_kernels_fp32(name, monkeypatch):
     assert _maxabs(ga, g["grad_attn_weight"]) <= 2e-5 * max(1.0, np.abs(g["grad_attn_weight"]).max())
 
 
+@pytest.mark.parametrize("slab", ["auto", "forced"])
 @pytest.mark.parametrize("dtype,tol_out,tol_rel", [(torch.bfloat16, 1e-2, 2e-2), (torch.float16, 1e-3, 4e-3)])
 @pytest.mark.parametrize("D", [32, 64, 8])
-def test_reduced_precision_vs_fp64_oracle_on_rounded_inputs(dtype, tol_out, tol_rel, D):
-    """bf16/f16 storage, fp32 arithmetic.  The oracle runs in fp64 on the SAME rounded inputs."""
+def test_reduced_precision_vs_fp64_oracle_on_rounded_inputs(dtype, tol_out, tol_rel, D, slab, monkeypatch):
+    """bf16/f16 storage, fp32 arithmetic.  The oracle runs in fp64 on the SAME rounded inputs.
+    `forced`: the slab kernels (4 channels = 8 bytes per lane for the 16-bit types)."""
+    if slab == "forced":
+        monkeypatch.setenv("MSDA_FWD_SLAB", "1"); monkeypatch.setenv("MSDA_BWD_SLAB", "1")
     d = make_inputs(7, 2, 8, D, 33, [(12, 20), (6, 10), (3, 5), (2, 3)], 4, "wide", np.float64, value_scale=1.0)
     d = round_to(d, dtype)
     ref = oracle_fwd_bwd(d, np.float64)
