@@ -63,6 +63,9 @@ def parse_args():
                          "of value forward, reduce-scatter of grad_value backward; strong scaling)")
     ap.add_argument("--pattern", choices=["fused", "reference"], default="fused",
                     help="fused: one launch per direction; reference: the 2*T calls per layer of the reference")
+    ap.add_argument("--value-layout", choices=["dense", "padded"], default="dense",
+                    help="dense = the reference's [N,S,M,D]; padded = one spare head slot per pixel row, what "
+                         "devis_amd's modules feed the op (functions.project_value; DESIGN.md section 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -145,6 +148,10 @@ def main():
     dtype = DTYPES[args.dtype]
     b = make_clip_batch(args, device, dtype, seed=1234 + rank)
     T, q, M, D, L, P, W, S = b["dims"]
+    if args.value_layout == "padded":
+        buf = torch.zeros((b["value"].shape[0], S, M + 1, D), dtype=dtype, device=device)
+        buf[:, :, :M] = b["value"]
+        b["value"] = buf[:, :, :M]
     leaves = [b[k].requires_grad_(True) for k in ("value", "loc_c", "aw_c", "loc_t", "aw_t")]
     t_shapes, t_lsi = None, None
     if args.pattern == "reference":
@@ -281,7 +288,8 @@ def main():
             prof = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
             w = prof["workload"]
             if (w["clips"], w["frames"], w["queries"], w["pyramid"], w["dtype"], w["locs"], w["pattern"]) == \
-                    (args.clips, args.frames, args.queries, args.pyramid, args.dtype, args.locs, args.pattern):
+                    (args.clips, args.frames, args.queries, args.pyramid, args.dtype, args.locs, args.pattern) \
+                    and args.value_layout == "dense":
                 k = prof["kernels"][dom]
                 traffic = k["fetch_bytes"] + k["write_bytes"]
         except (OSError, KeyError, ValueError):
@@ -336,8 +344,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "cfg3 DeVIS decoder temporal MSDeformAttn, one layer fwd+bwd: T=%d frames, "
                                    "%d queries/frame, L=4, K=4, C=256 (M=8xD=32), pyramid %s (S=%d), %d clips/GPU/step, "
-                                   "%s call pattern, %s sampling locations"
-                                   % (T, q, args.pyramid, S, args.clips, args.pattern, args.locs),
+                                   "%s call pattern, %s sampling locations, %s value layout"
+                                   % (T, q, args.pyramid, S, args.clips, args.pattern, args.locs, args.value_layout),
                        "clips_per_gpu": args.clips, "query_rows_per_step": rows_per_step,
                        "parallelism": ("clip-parallel x%d (no data-path collective)" % world) if args.mode == "clip-parallel"
                        else "one clip sharded x%d (all-gather value / reduce-scatter grad_value over RCCL)" % world},

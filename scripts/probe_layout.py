@@ -18,7 +18,14 @@ def timeit(fn, n=20):
     s.record()
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / n
-for name, v in (("dense", b["value"]), ("head-major", _native.head_major(b["value"]))):
+def padded(v, extra_heads=1):
+    """dense, but every pixel row padded by `extra_heads` head slots: pixel stride (M + extra) * D"""
+    G, S, M, D = v.shape
+    buf = torch.zeros(G, S, M + extra_heads, D, dtype=v.dtype, device=v.device)
+    buf[:, :, :M] = v
+    return buf[:, :, :M]
+for name, v in (("dense", b["value"]), ("head-major", _native.head_major(b["value"])), ("padded +1 head", padded(b["value"])),
+                ("padded +3 heads", padded(b["value"], 3))):
     fwd = lambda: _native.temporal_forward(v, b["shapes"], b["lsi"], b["ftab"], b["loc_c"], b["aw_c"], b["loc_t"], b["aw_t"], a.clips, out)
     def bwd():
         ws = _native.bwd_workspace(dev, a.clips * T, a.queries, M, L * (1 + W))

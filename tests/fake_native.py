@@ -19,7 +19,9 @@ def install(monkeypatch):
 
     def _check_inputs(named):
         for name, t in named:
-            if not t.is_contiguous():
+            if name == "value" and t.dim() == 4:
+                _native.value_strides(t)             # dense, head-major or padded rows
+            elif not t.is_contiguous():
                 raise RuntimeError("%s tensor has to be contiguous" % name)
 
     def forward(value, shapes, lsi, loc, aw, out):

@@ -488,6 +488,16 @@ def test_head_major_value_layout(route, monkeypatch):
         monkeypatch.setenv("MSDA_FORCE_GENERIC", "1")
     g, d = _golden_dict("op_batched_im2col")
     t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in d.items()}
+    # dense rows padded by one head slot (what devis_amd.functions.project_value produces)
+    vd = t["value"].float()
+    buf = torch.full((vd.shape[0], vd.shape[1], vd.shape[2] + 1, vd.shape[3]), float("nan"), device=DEV)
+    buf[:, :, :vd.shape[2]] = vd
+    vp = buf[:, :, :vd.shape[2]].requires_grad_(True)
+    loc0, aw0 = t["loc"].float().requires_grad_(True), t["aw"].float().requires_grad_(True)
+    outp = MSDeformAttnFunction.apply(vp, t["shapes"], t["lsi"], loc0, aw0, 3)
+    gp = torch.autograd.grad(outp, (vp, loc0, aw0), t["grad_out"].float())
+    for got, key in zip((outp,) + gp, ("out", "grad_value", "grad_sampling_loc", "grad_attn_weight")):
+        assert _maxabs(got.detach().cpu().numpy(), g[key]) <= 2e-5 * max(1.0, np.abs(g[key]).max()), key
     v = _native.head_major(t["value"].float()).requires_grad_(True)
     assert not v.is_contiguous()
     loc, aw = t["loc"].float().requires_grad_(True), t["aw"].float().requires_grad_(True)
