@@ -1,0 +1,74 @@
+"""GPU: long randomised parity sweep (op + fused temporal op vs the CPU oracle) over shapes, dtypes, value
+layouts and kernel routes -- a one-off soak beyond tests/test_fuzz_gpu.py.  Usage: fuzz_long.py [first] [count]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from helpers import make_inputs, make_temporal_inputs, oracle_fwd_bwd, round_to, temporal_reference
+from devis_amd import _native
+from devis_amd.functions import MSDeformAttnFunction, MSDeformAttnTemporalFunction
+DEV = "cuda:0"
+ROUTES = [{}, {"MSDA_SCATTER_DBG": "16"}, {"MSDA_FWD_SLAB": "1", "MSDA_BWD_SLAB": "1"}, {"MSDA_BWD_CULL": "2"},
+          {"MSDA_BWD_CULL": "0"}, {"MSDA_SCATTER_LDS_KB": "6"}, {"MSDA_SCATTER_DBG": "16", "MSDA_FWD_SLAB": "1", "MSDA_BWD_SLAB": "1"},
+          {"MSDA_FWD_SLAB": "0", "MSDA_BWD_SLAB": "0"}]
+KEYS = ["MSDA_SCATTER_DBG", "MSDA_FWD_SLAB", "MSDA_BWD_SLAB", "MSDA_BWD_CULL", "MSDA_SCATTER_LDS_KB"]
+def maxabs(a, b): return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max()) if a.size else 0.0
+def layout(v, kind):
+    if kind == 1: return _native.head_major(v)
+    if kind == 2:
+        buf = torch.full((v.shape[0], v.shape[1], v.shape[2] + 1, v.shape[3]), float("nan"), dtype=v.dtype, device=v.device)
+        buf[:, :, :v.shape[2]] = v
+        return buf[:, :, :v.shape[2]]
+    return v
+def shapes_of(rng, L, big):
+    hi = (40, 60) if big else (14, 17)
+    return [(int(rng.integers(1, hi[0])), int(rng.integers(1, hi[1]))) for _ in range(L)]
+first, count = int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 200
+bad = 0
+for seed in range(first, first + count):
+    rng = np.random.default_rng(50000 + seed)
+    for k in KEYS: os.environ.pop(k, None)
+    route = ROUTES[int(rng.integers(0, len(ROUTES)))]
+    os.environ.update(route)
+    lay = int(rng.integers(0, 3))
+    big = rng.random() < 0.25
+    if seed % 2 == 0:
+        D = int(rng.choice([4, 8, 16, 32, 32, 32, 64, 128, 12])); M = int(rng.choice([1, 2, 4, 8, 8, 16]))
+        L, P = int(rng.integers(1, 6)), int(rng.integers(1, 7))
+        N, Lq = int(rng.integers(1, 5)), int(rng.integers(1, 3000 if big else 80))
+        d = make_inputs(seed, N, M, D, Lq, shapes_of(rng, L, big), P, "wide" if rng.random() < 0.7 else "unit", np.float32, value_scale=1.0)
+        ref, ref64 = oracle_fwd_bwd(d, np.float32), oracle_fwd_bwd(d, np.float64)
+        f = lambda k: torch.from_numpy(np.asarray(d[k], dtype=np.float64)).to(DEV, torch.float32)
+        v = layout(f("value"), lay).requires_grad_(True); l = f("loc").requires_grad_(True); a = f("aw").requires_grad_(True)
+        step = int(rng.choice([1, N, 64]))
+        out = MSDeformAttnFunction.apply(v, torch.from_numpy(d["shapes"]).to(DEV), torch.from_numpy(d["lsi"]).to(DEV), l, a, step)
+        g = torch.autograd.grad(out, (v, l, a), f("grad_out"))
+        got = [t.detach().double().cpu().numpy() for t in (out,) + tuple(g)]
+        errs = [maxabs(got[0], ref64[0]) / max(1.0, np.abs(ref64[0]).max())] + [maxabs(x, y) / max(1.0, np.abs(y).max()) for x, y in zip(got[1:], ref[1:])]
+        cfg = dict(kind="op", D=D, M=M, L=L, P=P, N=N, Lq=Lq, big=big, lay=lay, route=route)
+        ok = errs[0] <= 1e-5 and max(errs[1:]) <= 1e-4
+    else:
+        D = int(rng.choice([8, 16, 32, 32, 64])); M = int(rng.choice([2, 4, 8, 8]))
+        L, Pc, Pt = int(rng.integers(1, 5)), int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        T = int(rng.integers(2, 7)); W = int(rng.integers(1, T))
+        ftab = rng.integers(0, T, size=(T, W)).astype(np.int32)
+        Lq = int(rng.integers(1, 900 if big else 60))
+        d = make_temporal_inputs(seed, T, W, M, D, Lq, shapes_of(rng, L, big), Pc, Pt, ftab=ftab, dtype=np.float32)
+        keys = ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")
+        ref = temporal_reference(*(np.asarray(d[k], dtype=np.float64) if d[k].dtype.kind == "f" else d[k] for k in keys))
+        f = lambda k: torch.from_numpy(np.asarray(d[k], dtype=np.float64)).to(DEV, torch.float32)
+        v = layout(f("value"), lay).requires_grad_(True)
+        lc, ac, lt, at = (f(k).requires_grad_(True) for k in ("loc_c", "aw_c", "loc_t", "aw_t"))
+        out = MSDeformAttnTemporalFunction.apply(v, torch.from_numpy(d["shapes"]).to(DEV), torch.from_numpy(d["lsi"]).to(DEV),
+                                                 torch.from_numpy(d["ftab"]).to(DEV), lc, ac, lt, at, 1)
+        g = torch.autograd.grad(out, (v, lc, ac, lt, at), f("grad_out"))
+        got = [t.detach().double().cpu().numpy() for t in (out,) + tuple(g)]
+        errs = [maxabs(x, y) / max(1.0, np.abs(y).max()) for x, y in zip(got, ref)]
+        cfg = dict(kind="temporal", D=D, M=M, L=L, Pc=Pc, Pt=Pt, T=T, W=W, Lq=Lq, big=big, lay=lay, route=route)
+        # grad_loc (indices 2, 4) vs an fp64 reference flips cells at pixel borders: judged loosely
+        ok = max(errs[0], errs[1], errs[3], errs[5]) <= 1e-4
+    if not ok:
+        bad += 1
+        print("MISMATCH seed", seed, cfg, ["%.2e" % e for e in errs], flush=True)
+torch.cuda.synchronize()
+print("fuzz_long: seeds %d..%d done, %d mismatches" % (first, first + count - 1, bad))
