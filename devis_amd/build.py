@@ -19,6 +19,8 @@ LIB = os.path.join(HERE, "libmsda_hip.so")
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-munsafe-fp-atomics",          # float atomicAdd -> global_atomic_add_f32/_f64 (no CAS loop)
+    "-ffp-contract=off",            # x*W-0.5 must stay a rounded product then a subtraction (which pixel cell a
+                                    # point falls in); every FMA the kernels want is an explicit fmaf()
     "-Wno-pass-failed",
 ]
 

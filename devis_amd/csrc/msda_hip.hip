@@ -39,6 +39,13 @@
 
 #include "msda.h"
 
+// No implicit FMA contraction anywhere in this file: HIP's __fmul_rn / __fsub_rn are plain `*` / `-` unless
+// OCML_BASIC_ROUNDED_OPERATIONS is defined, and hipcc contracts by default, so `x * W - 0.5` could become one
+// FMA in some inlining contexts and not in others -- forward, gather pass and scatter would then disagree with
+// each other (and with the oracle) about the pixel cell of a point that sits within one ulp of a border.
+// Every FMA the kernels want is spelled fmaf().  (devis_amd/build.py also passes -ffp-contract=off.)
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr int kWave = 64;   // gfx950 wavefront
