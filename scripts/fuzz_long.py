@@ -53,18 +53,22 @@ for seed in range(first, first + count):
         T = int(rng.integers(2, 7)); W = int(rng.integers(1, T))
         ftab = rng.integers(0, T, size=(T, W)).astype(np.int32)
         Lq = int(rng.integers(1, 900 if big else 60))
-        d = make_temporal_inputs(seed, T, W, M, D, Lq, shapes_of(rng, L, big), Pc, Pt, ftab=ftab, dtype=np.float32)
+        clips = int(rng.integers(1, 4))
+        shp = shapes_of(rng, L, big)
+        ds = [make_temporal_inputs(seed * 7 + c, T, W, M, D, Lq, shp, Pc, Pt, ftab=ftab, dtype=np.float32) for c in range(clips)]
         keys = ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")
-        ref = temporal_reference(*(np.asarray(d[k], dtype=np.float64) if d[k].dtype.kind == "f" else d[k] for k in keys))
-        f = lambda k: torch.from_numpy(np.asarray(d[k], dtype=np.float64)).to(DEV, torch.float32)
+        refs = [temporal_reference(*(np.asarray(d[k], dtype=np.float64) if d[k].dtype.kind == "f" else d[k] for k in keys)) for d in ds]
+        ref = [np.concatenate([r[i] for r in refs], 0) for i in range(6)]
+        d = ds[0]
+        f = lambda k: torch.from_numpy(np.concatenate([np.asarray(x[k], dtype=np.float64) for x in ds], 0)).to(DEV, torch.float32)
         v = layout(f("value"), lay).requires_grad_(True)
         lc, ac, lt, at = (f(k).requires_grad_(True) for k in ("loc_c", "aw_c", "loc_t", "aw_t"))
         out = MSDeformAttnTemporalFunction.apply(v, torch.from_numpy(d["shapes"]).to(DEV), torch.from_numpy(d["lsi"]).to(DEV),
-                                                 torch.from_numpy(d["ftab"]).to(DEV), lc, ac, lt, at, 1)
+                                                 torch.from_numpy(d["ftab"]).to(DEV), lc, ac, lt, at, clips)
         g = torch.autograd.grad(out, (v, lc, ac, lt, at), f("grad_out"))
         got = [t.detach().double().cpu().numpy() for t in (out,) + tuple(g)]
         errs = [maxabs(x, y) / max(1.0, np.abs(y).max()) for x, y in zip(got, ref)]
-        cfg = dict(kind="temporal", D=D, M=M, L=L, Pc=Pc, Pt=Pt, T=T, W=W, Lq=Lq, big=big, lay=lay, route=route)
+        cfg = dict(kind="temporal", D=D, M=M, L=L, Pc=Pc, Pt=Pt, T=T, W=W, Lq=Lq, clips=clips, big=big, lay=lay, route=route)
         # grad_loc (indices 2, 4) vs an fp64 reference flips cells at pixel borders: judged loosely
         ok = max(errs[0], errs[1], errs[3], errs[5]) <= 1e-4
     if not ok:
