@@ -11,7 +11,7 @@ import torch
 
 from . import build as _build
 
-MSDA_ABI_VERSION = 5
+MSDA_ABI_VERSION = 6
 BWD_WORKSPACE_BYTES = 64
 _DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.float16: 3}
 
@@ -19,6 +19,7 @@ _DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.floa
 EXPORTED_SYMBOLS = (
     "msda_version", "msda_last_error", "msda_forward", "msda_backward",
     "msda_temporal_forward", "msda_temporal_backward", "msda_backward_workspace_bytes",
+    "msda_prep_forward", "msda_prep_backward",
 )
 
 _lib = None
@@ -61,6 +62,10 @@ def load():
         lib.msda_temporal_forward.argtypes = [_ci] + [_vp] * 8 + [_ci] * 10 + [_vp, _vp, _vp]
         lib.msda_temporal_backward.restype = _ci
         lib.msda_temporal_backward.argtypes = [_ci] + [_vp] * 9 + [_ci] * 10 + [_vp] * 6 + [ctypes.c_longlong, _vp, _vp]
+        lib.msda_prep_forward.restype = _ci
+        lib.msda_prep_forward.argtypes = [_ci] + [_vp] * 7 + [ctypes.c_longlong] + [_ci] * 6 + [_vp] * 5
+        lib.msda_prep_backward.restype = _ci
+        lib.msda_prep_backward.argtypes = [_ci] + [_vp] * 9 + [ctypes.c_longlong] + [_ci] * 6 + [_vp] * 5
         _lib = lib
     return _lib
 
@@ -171,3 +176,21 @@ def temporal_backward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, grad_o
             _p(grad_value), _p(gloc_c), _p(gaw_c), _p(gloc_t), _p(gaw_t), _p(ws), ws.numel() * 4,
             value_strides(value, frames), _stream(value))
     _check(rc, "msda_temporal_backward")
+
+
+def prep_forward(off_c, off_t, logit_c, logit_t, ref_c, ref_t, shapes, rows, M, L, W, Pc, Pt, loc_c, loc_t, aw_c, aw_t):
+    """msda_prep_forward (include/msda.h): joint softmax + sampling locations in one pass."""
+    with torch.cuda.device(off_c.device):
+        rc = load().msda_prep_forward(dtype_code(off_c.dtype), _p(off_c), _p(off_t), _p(logit_c), _p(logit_t), _p(ref_c),
+                                      _p(ref_t), _p(shapes), rows, M, L, W, Pc, Pt, ref_c.shape[-1],
+                                      _p(loc_c), _p(loc_t), _p(aw_c), _p(aw_t), _stream(off_c))
+    _check(rc, "msda_prep_forward")
+
+
+def prep_backward(gloc_c, gloc_t, gaw_c, gaw_t, aw_c, aw_t, ref_c, ref_t, shapes, rows, M, L, W, Pc, Pt,
+                  goff_c, goff_t, glogit_c, glogit_t):
+    with torch.cuda.device(gloc_c.device):
+        rc = load().msda_prep_backward(dtype_code(gloc_c.dtype), _p(gloc_c), _p(gloc_t), _p(gaw_c), _p(gaw_t), _p(aw_c),
+                                       _p(aw_t), _p(ref_c), _p(ref_t), _p(shapes), rows, M, L, W, Pc, Pt, ref_c.shape[-1],
+                                       _p(goff_c), _p(goff_t), _p(glogit_c), _p(glogit_t), _stream(gloc_c))
+    _check(rc, "msda_prep_backward")

@@ -2111,6 +2111,119 @@ msda_bwd_generic_kernel(const Params p, int64_t rows)
 }
 
 // ------------------------------------------------------------------------------------------------
+// pre-op fusion: the modules' chain between their Linears and the operator --
+// cat(logits) -> softmax -> split -> reshape, and reference + offsets / normalizer (or the box form) for
+// the current-frame and the temporal points (ref ms_deform_attn.py:105-121, 225-266, 327-352) -- as ONE
+// pass over the Linear outputs that writes sampling_loc / attn_weight in the operator's layouts, and ONE
+// pass back.  loc / attn are still materialised (the decoder returns them); what disappears are the ~10
+// elementwise passes and copies in between.
+// Mapping: one 32-lane half-wave per (row, head) walks that head's n = L*Pc + W*L*Pt points (lane j takes
+// points j, j+32, ...); the joint softmax is two half-wave butterflies.
+// ------------------------------------------------------------------------------------------------
+struct PrepParams {
+    const void *off_c, *off_t;        // [rows, M, L, Pc, 2], [rows, M, W*L, Pt, 2]   raw sampling offsets
+    const void *logit_c, *logit_t;    // [rows, M, L*Pc], [rows, M, W*L*Pt]           raw attention logits
+    const void *ref_c, *ref_t;        // [rows, L, d], [rows, W*L, d]                 reference points (d = 2 | 4)
+    const int64_t *shapes;            // [L, 2] (H, W)
+    void *loc_c, *loc_t, *aw_c, *aw_t;            // forward outputs (backward: aw_* are inputs)
+    const void *gloc_c, *gloc_t, *gaw_c, *gaw_t;  // backward inputs
+    void *goff_c, *goff_t, *glogit_c, *glogit_t;  // backward outputs
+    int64_t rows;
+    int M, L, W, Pc, Pt, d;
+};
+
+template <typename A> __device__ __forceinline__ A half_wave_max(A v)
+{
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { const A u = __shfl_xor(v, o, 32); v = u > v ? u : v; }
+    return v;
+}
+template <typename A> __device__ __forceinline__ A half_wave_sum(A v)
+{
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+    return v;
+}
+__device__ __forceinline__ float prep_exp(float x) { return expf(x); }
+__device__ __forceinline__ double prep_exp(double x) { return exp(x); }
+
+template <typename T, typename A, bool BWD>
+__global__ void __launch_bounds__(256)
+msda_prep_kernel(const PrepParams p)
+{
+    const int lane = threadIdx.x % 32;
+    const int nc = p.L * p.Pc, nt = p.W * p.L * p.Pt, n = nc + nt;
+    const int64_t pairs = p.rows * p.M;
+    for (int64_t pair = (int64_t)blockIdx.x * 8 + threadIdx.x / 32; pair < pairs; pair += (int64_t)gridDim.x * 8) {
+        const int64_t row = pair / p.M;
+        const T *lc = static_cast<const T *>(BWD ? p.aw_c : p.logit_c) + pair * nc;
+        const T *lt = static_cast<const T *>(BWD ? p.aw_t : p.logit_t) + pair * nt;
+        if (!BWD) {
+            // ---- joint softmax over the n logits of this (row, head)   (ref :252-258 / F.softmax)
+            A mx = -INFINITY;
+            for (int e = lane; e < n; e += 32) {
+                const A v = (A)Store<T>::get(e < nc ? lc + e : lt + (e - nc));
+                mx = v > mx ? v : mx;
+            }
+            mx = half_wave_max<A>(mx);
+            A sum = 0;
+            for (int e = lane; e < n; e += 32) sum += prep_exp((A)Store<T>::get(e < nc ? lc + e : lt + (e - nc)) - mx);
+            sum = half_wave_sum<A>(sum);
+            T *ac = static_cast<T *>(p.aw_c) + pair * nc, *at = static_cast<T *>(p.aw_t) + pair * nt;
+            for (int e = lane; e < n; e += 32) {
+                const A v = prep_exp((A)Store<T>::get(e < nc ? lc + e : lt + (e - nc)) - mx) / sum;
+                Store<T>::put(e < nc ? ac + e : at + (e - nc), v);
+            }
+        } else {
+            // ---- softmax backward: g_logit = p * (g - sum_j p_j g_j)
+            const T *gc = static_cast<const T *>(p.gaw_c) + pair * nc, *gt = static_cast<const T *>(p.gaw_t) + pair * nt;
+            A dot = 0;
+            for (int e = lane; e < n; e += 32)
+                dot += (A)Store<T>::get(e < nc ? lc + e : lt + (e - nc)) * (A)Store<T>::get(e < nc ? gc + e : gt + (e - nc));
+            dot = half_wave_sum<A>(dot);
+            T *oc = static_cast<T *>(p.glogit_c) + pair * nc, *ot = static_cast<T *>(p.glogit_t) + pair * nt;
+            for (int e = lane; e < n; e += 32) {
+                const A pe = (A)Store<T>::get(e < nc ? lc + e : lt + (e - nc));
+                const A ge = (A)Store<T>::get(e < nc ? gc + e : gt + (e - nc));
+                Store<T>::put(e < nc ? oc + e : ot + (e - nc), pe * (ge - dot));
+            }
+        }
+        // ---- sampling locations (ref :112-121): 2-d refs add offsets in pixels of the level, boxes add them
+        // as a fraction of half the box; backward: the same factors on grad_loc
+        for (int e = lane; e < n; e += 32) {
+            const bool cur = e < nc;
+            const int ee = cur ? e : e - nc, P = cur ? p.Pc : p.Pt;
+            const int vl = ee / P;                            // level (current) or slot*L + level (temporal)
+            const int l = cur ? vl : vl % p.L;
+            const int64_t idx = (pair * (cur ? nc : nt) + ee) * 2;
+            const T *ref = static_cast<const T *>(cur ? p.ref_c : p.ref_t) + (row * (cur ? p.L : p.W * p.L) + vl) * p.d;
+            const T *in = static_cast<const T *>(BWD ? (cur ? p.gloc_c : p.gloc_t) : (cur ? p.off_c : p.off_t)) + idx;
+            T *out = static_cast<T *>(BWD ? (cur ? p.goff_c : p.goff_t) : (cur ? p.loc_c : p.loc_t)) + idx;
+            const A x = (A)Store<T>::get(in), y = (A)Store<T>::get(in + 1);
+            if (p.d == 2) {
+                const A nx = (A)p.shapes[2 * l + 1], ny = (A)p.shapes[2 * l];      // (W_l, H_l)
+                if (!BWD) {
+                    Store<T>::put(out, (A)Store<T>::get(ref) + x / nx);
+                    Store<T>::put(out + 1, (A)Store<T>::get(ref + 1) + y / ny);
+                } else {
+                    Store<T>::put(out, x / nx);
+                    Store<T>::put(out + 1, y / ny);
+                }
+            } else {
+                const A bw = (A)Store<T>::get(ref + 2), bh = (A)Store<T>::get(ref + 3);
+                if (!BWD) {
+                    Store<T>::put(out, (A)Store<T>::get(ref) + x / (A)P * bw * (A)0.5);
+                    Store<T>::put(out + 1, (A)Store<T>::get(ref + 1) + y / (A)P * bh * (A)0.5);
+                } else {
+                    Store<T>::put(out, x * (A)0.5 * bw / (A)P);
+                    Store<T>::put(out + 1, y * (A)0.5 * bh / (A)P);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 thread_local char g_err[512] = "";
@@ -2437,6 +2550,33 @@ void attach_workspace(Params &p, void *workspace, long long bytes, int batch, in
         p.bbox = reinterpret_cast<int *>(p.workspace) + MSDA_BWD_WORKSPACE_BYTES / 4;
 }
 
+template <typename T, typename A>
+int launch_prep(const PrepParams &p, bool bwd, hipStream_t stream)
+{
+    const int64_t pairs = p.rows * p.M;
+    const int64_t want = (pairs + 7) / 8;
+    const unsigned blocks = (unsigned)(want < 65536 * 4 ? want : 65536 * 4);
+    if (bwd) hipLaunchKernelGGL((msda_prep_kernel<T, A, true>), dim3(blocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((msda_prep_kernel<T, A, false>), dim3(blocks), dim3(256), 0, stream, p);
+    return check_launch(bwd ? "msda prep backward" : "msda prep forward");
+}
+
+int run_prep(int dtype, const PrepParams &p, bool bwd, void *stream)
+{
+    if (p.rows < 0 || p.M <= 0 || p.L <= 0 || p.W < 0 || p.Pc <= 0 || (p.W > 0 && p.Pt <= 0) || (p.d != 2 && p.d != 4))
+        return fail(MSDA_ERR_ARG, "msda prep: bad sizes (rows, heads, levels, window, points, reference dim)%s");
+    if (!p.shapes || !p.ref_c || (p.W > 0 && !p.ref_t)) return fail(MSDA_ERR_ARG, "msda prep: null pointer argument%s");
+    if (p.rows == 0) return MSDA_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case MSDA_F32: return launch_prep<float, float>(p, bwd, st);
+        case MSDA_F64: return launch_prep<double, double>(p, bwd, st);
+        case MSDA_BF16: return launch_prep<bf16_t, float>(p, bwd, st);
+        case MSDA_F16: return launch_prep<f16_t, float>(p, bwd, st);
+        default: return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -2573,6 +2713,48 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
     rc = set_value_strides(p, value_strides);
     if (rc) return rc;
     return run(dtype, p, true, static_cast<hipStream_t>(stream));
+}
+
+int msda_prep_forward(int dtype, const void *offsets_curr, const void *offsets_temp, const void *logits_curr,
+                      const void *logits_temp, const void *ref_curr, const void *ref_temp,
+                      const int64_t *spatial_shapes, long long rows, int num_heads, int num_levels, int window,
+                      int num_curr_point, int num_temp_point, int ref_dim,
+                      void *loc_curr, void *loc_temp, void *aw_curr, void *aw_temp, void *stream)
+{
+    g_err[0] = 0;
+    PrepParams p;
+    memset(&p, 0, sizeof(p));
+    p.off_c = offsets_curr; p.off_t = offsets_temp; p.logit_c = logits_curr; p.logit_t = logits_temp;
+    p.ref_c = ref_curr; p.ref_t = ref_temp; p.shapes = spatial_shapes;
+    p.loc_c = loc_curr; p.loc_t = loc_temp; p.aw_c = aw_curr; p.aw_t = aw_temp;
+    p.rows = rows; p.M = num_heads; p.L = num_levels; p.W = window; p.Pc = num_curr_point;
+    p.Pt = window > 0 ? num_temp_point : 1; p.d = ref_dim;
+    if (rows > 0 && (!offsets_curr || !logits_curr || !loc_curr || !aw_curr ||
+                     (window > 0 && (!offsets_temp || !logits_temp || !loc_temp || !aw_temp))))
+        return fail(MSDA_ERR_ARG, "msda_prep_forward: null pointer argument%s");
+    return run_prep(dtype, p, false, stream);
+}
+
+int msda_prep_backward(int dtype, const void *grad_loc_curr, const void *grad_loc_temp, const void *grad_aw_curr,
+                       const void *grad_aw_temp, const void *aw_curr, const void *aw_temp, const void *ref_curr,
+                       const void *ref_temp, const int64_t *spatial_shapes, long long rows, int num_heads,
+                       int num_levels, int window, int num_curr_point, int num_temp_point, int ref_dim,
+                       void *grad_offsets_curr, void *grad_offsets_temp, void *grad_logits_curr,
+                       void *grad_logits_temp, void *stream)
+{
+    g_err[0] = 0;
+    PrepParams p;
+    memset(&p, 0, sizeof(p));
+    p.gloc_c = grad_loc_curr; p.gloc_t = grad_loc_temp; p.gaw_c = grad_aw_curr; p.gaw_t = grad_aw_temp;
+    p.aw_c = const_cast<void *>(aw_curr); p.aw_t = const_cast<void *>(aw_temp);
+    p.ref_c = ref_curr; p.ref_t = ref_temp; p.shapes = spatial_shapes;
+    p.goff_c = grad_offsets_curr; p.goff_t = grad_offsets_temp; p.glogit_c = grad_logits_curr; p.glogit_t = grad_logits_temp;
+    p.rows = rows; p.M = num_heads; p.L = num_levels; p.W = window; p.Pc = num_curr_point;
+    p.Pt = window > 0 ? num_temp_point : 1; p.d = ref_dim;
+    if (rows > 0 && (!grad_loc_curr || !grad_aw_curr || !aw_curr || !grad_offsets_curr || !grad_logits_curr ||
+                     (window > 0 && (!grad_loc_temp || !grad_aw_temp || !aw_temp || !grad_offsets_temp || !grad_logits_temp))))
+        return fail(MSDA_ERR_ARG, "msda_prep_backward: null pointer argument%s");
+    return run_prep(dtype, p, true, stream);
 }
 
 }  // extern "C"

@@ -253,3 +253,58 @@ def project_value(x, linear, n_heads, padding_mask=None, pad_heads=1):
             value = value.masked_fill(padding_mask[..., None], float(0))
         return value.view(x.shape[0], x.shape[1], n_heads, linear.out_features // n_heads)
     return _PaddedValueProj.apply(x, linear.weight, linear.bias, n_heads, pad_heads, padding_mask)
+
+
+class MSDeformPrepFunction(Function):
+    """Joint softmax + sampling-location arithmetic of the (temporal) modules as one fused pass each way
+    (include/msda.h msda_prep_forward/backward).
+
+    ``apply(off_c [R,M,L,Pc,2], off_t [R,M,W*L,Pt,2] | None, logit_c [R,M,L*Pc], logit_t [R,M,W*L*Pt] | None,
+    ref_c [R,L,d], ref_t [R,W*L,d] | None, spatial_shapes [L,2])`` with R = frames*queries rows ->
+    ``(loc_c, loc_t, aw_c, aw_t)`` in the operator's layouts (``loc_t``/``aw_t`` are None without a
+    temporal part).  Same arithmetic as ref ms_deform_attn.py:112-121 (locations) and :252-258 (softmax)."""
+
+    @staticmethod
+    def forward(ctx, off_c, off_t, logit_c, logit_t, ref_c, ref_t, shapes):
+        R, M, L, Pc, _ = off_c.shape
+        W = 0 if off_t is None else off_t.shape[2] // L
+        Pt = 1 if off_t is None else off_t.shape[3]
+        off_c, logit_c, ref_c = off_c.contiguous(), logit_c.contiguous(), ref_c.contiguous()
+        if W:
+            off_t, logit_t, ref_t = off_t.contiguous(), logit_t.contiguous(), ref_t.contiguous()
+        loc_c, aw_c = torch.empty_like(off_c), torch.empty((R, M, L, Pc), dtype=off_c.dtype, device=off_c.device)
+        loc_t = torch.empty_like(off_t) if W else None
+        aw_t = torch.empty((R, M, W * L, Pt), dtype=off_c.dtype, device=off_c.device) if W else None
+        _native.prep_forward(off_c, off_t, logit_c, logit_t, ref_c, ref_t, shapes, R, M, L, W, Pc, Pt,
+                             loc_c, loc_t, aw_c, aw_t)
+        ctx.save_for_backward(aw_c, aw_t, ref_c, ref_t, shapes, off_c, off_t)
+        ctx.dims = (R, M, L, W, Pc, Pt)
+        return loc_c, loc_t, aw_c, aw_t
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloc_c, gloc_t, gaw_c, gaw_t):
+        aw_c, aw_t, ref_c, ref_t, shapes, off_c, off_t = ctx.saved_tensors
+        R, M, L, W, Pc, Pt = ctx.dims
+        zeros = lambda like: torch.zeros_like(like)
+        gloc_c = zeros(off_c) if gloc_c is None else gloc_c.contiguous()
+        gaw_c = zeros(aw_c) if gaw_c is None else gaw_c.contiguous()
+        if W:
+            gloc_t = zeros(off_t) if gloc_t is None else gloc_t.contiguous()
+            gaw_t = zeros(aw_t) if gaw_t is None else gaw_t.contiguous()
+        goff_c, glogit_c = torch.empty_like(off_c), torch.empty((R, M, L * Pc), dtype=off_c.dtype, device=off_c.device)
+        goff_t = torch.empty_like(off_t) if W else None
+        glogit_t = torch.empty((R, M, W * L * Pt), dtype=off_c.dtype, device=off_c.device) if W else None
+        _native.prep_backward(gloc_c, gloc_t, gaw_c, gaw_t, aw_c, aw_t, ref_c, ref_t, shapes, R, M, L, W, Pc, Pt,
+                              goff_c, goff_t, glogit_c, glogit_t)
+
+        def ref_grad(gloc, off, ref, P):
+            # d loc / d ref: 1 on (x, y); boxes: d loc / d (w, h) = offsets / P * 0.5   (ref :112-121)
+            g = gloc.sum((1, 3))                                       # over heads and points -> [R, levels, 2]
+            if ref.shape[-1] == 2:
+                return g
+            return torch.cat((g, (gloc * (off / P * 0.5)).sum((1, 3))), -1)
+
+        gref_c = ref_grad(gloc_c, off_c, ref_c, Pc) if ctx.needs_input_grad[4] else None
+        gref_t = ref_grad(gloc_t, off_t, ref_t, Pt) if (W and ctx.needs_input_grad[5]) else None
+        return goff_c, goff_t, glogit_c, glogit_t, gref_c, gref_t, None

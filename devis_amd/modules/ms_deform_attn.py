@@ -18,7 +18,8 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
-from ..functions import MSDeformAttnFunction, MSDeformAttnTemporalFunction, project_value
+from ..functions import (MSDeformAttnFunction, MSDeformAttnTemporalFunction, MSDeformPrepFunction,
+                         project_value)
 
 
 def _is_power_of_2(n):
@@ -71,6 +72,7 @@ def _locations(reference, offsets, normalizer, n_points):
 
 class MSDeformAttn(nn.Module):
     value_pad_heads = 1     # spare head slots per pixel row of `value` (0 = the reference's dense layout)
+    fused_prep = True       # softmax + sampling-location arithmetic in one fused pass (False: torch ops)
 
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
         """Multi-Scale Deformable Attention Module (ref ``ms_deform_attn.py:30-132``).
@@ -123,11 +125,23 @@ class MSDeformAttn(nn.Module):
         # value_proj writes value[N, S, M, D] with one spare head slot per pixel row (SURVEY f-3): same
         # numbers as ref :118-121, a layout the gather kernels read ~15 % faster; value_pad_heads = 0: dense
         value = project_value(input_flatten, self.value_proj, M, input_padding_mask, self.value_pad_heads)
-        offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
-        weights = F.softmax(self.attention_weights(query).view(N, Len_q, M, L * P), -1)
-        weights = weights.view(N, Len_q, M, L, P)
-        locations = _locations(reference_points[:, :, None, :, None, :], offsets,
-                               _normalizer(input_spatial_shapes), P)
+        if reference_points.shape[-1] not in (2, 4):
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+                reference_points.shape[-1]))
+        if self.fused_prep and query.is_cuda:
+            # softmax + location arithmetic in one pass (SURVEY f-2); same numbers as the branch below
+            R = N * Len_q
+            locations, _, weights, _ = MSDeformPrepFunction.apply(
+                self.sampling_offsets(query).view(R, M, L, P, 2), None,
+                self.attention_weights(query).view(R, M, L * P), None,
+                reference_points.reshape(R, L, reference_points.shape[-1]), None, input_spatial_shapes)
+            locations, weights = locations.view(N, Len_q, M, L, P, 2), weights.view(N, Len_q, M, L, P)
+        else:
+            offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
+            weights = F.softmax(self.attention_weights(query).view(N, Len_q, M, L * P), -1)
+            weights = weights.view(N, Len_q, M, L, P)
+            locations = _locations(reference_points[:, :, None, :, None, :], offsets,
+                                   _normalizer(input_spatial_shapes), P)
         output = MSDeformAttnFunction.apply(value, input_spatial_shapes,
                                             input_level_start_index, locations.contiguous(),
                                             weights.contiguous(), self.im2col_step)
@@ -138,6 +152,7 @@ class TemporalMSDeformAttnBase(nn.Module):
     """Shared part of the temporal modules (ref ``:137-285``)."""
 
     fused = True   # False: replay the reference's 2*T-call pattern (same results)
+    fused_prep = True       # joint softmax + sampling-location arithmetic in one fused pass (False: torch ops)
     value_pad_heads = 1     # spare head slots per pixel row of `value` (0 = the reference's dense layout)
 
     def __init__(self, n_frames=36, d_model=256, n_levels=4, t_window=2, n_heads=8, n_curr_points=4,
@@ -199,6 +214,33 @@ class TemporalMSDeformAttnBase(nn.Module):
         weights_temporal = weights[..., L * Pc:].reshape(T, Len_q, M, W * L, Pt)
         curr_offsets = self.sampling_offsets(query).view(T, Len_q, M, L, Pc, 2)
         return value, curr_offsets, temporal_offsets, weights_curr, weights_temporal
+
+    def _value_and_sampling(self, query, input_flatten, ref_curr, ref_temp, shapes):
+        """value [T,S,M,D], loc_curr [T,Lq,M,L,Pc,2], loc_temp [T,Lq,M,W*L,Pt,2], w_curr [T,Lq,M,L,Pc],
+        w_temp [T,Lq,M,W*L,Pt] from the query, reference points ``ref_curr [T,Lq,L,d]`` / ``ref_temp``
+        (broadcastable to ``[T,Lq,W*L,d]``) and the current-frame ``shapes [L,2]`` (ref :225-266 followed by
+        the location arithmetic of :327-352 / :436-452).  On the GPU the softmax and the location
+        arithmetic are one fused pass each way (SURVEY f-2); ``fused_prep = False`` uses torch ops."""
+        T, Len_q, _ = query.shape
+        M, L, W = self.n_heads, self.n_levels, self.t_window
+        Pc, Pt = self.n_curr_points, self.n_temporal_points
+        d = ref_curr.shape[-1]
+        if not (self.fused_prep and query.is_cuda):
+            value, off_curr, off_temp, w_curr, w_temp = self._compute_deformable_attention(query, input_flatten)
+            normalizer = _normalizer(shapes)
+            loc_curr = _locations(ref_curr[:, :, None, :, None, :], off_curr, normalizer, Pc)
+            loc_temp = _locations(ref_temp[:, :, None, :, None, :], off_temp, normalizer.repeat(W, 1), Pt)
+            return value, loc_curr, loc_temp, w_curr, w_temp
+        R = T * Len_q
+        value = project_value(input_flatten, self.value_proj, M, None, self.value_pad_heads)
+        loc_c, loc_t, w_c, w_t = MSDeformPrepFunction.apply(
+            self.sampling_offsets(query).view(R, M, L, Pc, 2),
+            self.temporal_sampling_offsets(query).view(R, M, W * L, Pt, 2),
+            self.attention_weights(query).view(R, M, L * Pc),
+            self.temporal_attention_weights(query).view(R, M, W * L * Pt),
+            ref_curr.reshape(R, L, d), ref_temp.expand(T, Len_q, W * L, d).reshape(R, W * L, d), shapes)
+        return (value, loc_c.view(T, Len_q, M, L, Pc, 2), loc_t.view(T, Len_q, M, W * L, Pt, 2),
+                w_c.view(T, Len_q, M, L, Pc), w_t.view(T, Len_q, M, W * L, Pt))
 
     _table_cache = None     # (offset tensors, n_frames, device, table): shared by all layers of a transformer
 
@@ -267,20 +309,15 @@ class TemporalMSDeformAttnDecoder(TemporalMSDeformAttnBase):
         if reference_points.shape[-1] not in (2, 4):
             raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
                 reference_points.shape[-1]))
-        value, off_curr, off_temp, w_curr, w_temp = self._compute_deformable_attention(query, input_flatten)
-
         W = self.t_window
-        normalizer = _normalizer(input_spatial_shapes[0])
-        loc_curr = _locations(reference_points[:, :, None, :, None, :], off_curr, normalizer,
-                              self.n_curr_points)
         if self.dec_instance_aware_att:
             # reference point of the SAME instance in each of the other frames (ref :342-344)
             table = self._frame_table(temporal_offsets, T, reference_points.device).long()
             ref_t = reference_points[table].permute(0, 2, 1, 3, 4).flatten(2, 3)      # [T, q, W*L, d]
         else:
             ref_t = reference_points.repeat(1, 1, W, 1)                               # ref :346-347
-        loc_temp = _locations(ref_t[:, :, None, :, None, :], off_temp, normalizer.repeat(W, 1),
-                              self.n_temporal_points)
+        value, loc_curr, loc_temp, w_curr, w_temp = self._value_and_sampling(
+            query, input_flatten, reference_points, ref_t, input_spatial_shapes[0])
 
         output = self._attend(value, input_spatial_shapes, input_level_start_index, temporal_offsets,
                               loc_curr, w_curr, loc_temp, w_temp)
@@ -296,12 +333,9 @@ class TemporalMSDeformAttnEncoder(TemporalMSDeformAttnBase):
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
                 input_level_start_index, temporal_offsets):
         assert reference_points.shape[-1] == 2
-        value, off_curr, off_temp, w_curr, w_temp = self._compute_deformable_attention(query, input_flatten)
-        normalizer = _normalizer(input_spatial_shapes[0])
-        loc_curr = _locations(reference_points[:, :, None, :, None, :], off_curr, normalizer,
-                              self.n_curr_points)
-        ref_t = reference_points[:, :, 0][:, :, None, None, None, :]
-        loc_temp = _locations(ref_t, off_temp, normalizer.repeat(self.t_window, 1), self.n_temporal_points)
+        # temporal sampling in the other frames starts from the level-0 reference point (ref :447)
+        value, loc_curr, loc_temp, w_curr, w_temp = self._value_and_sampling(
+            query, input_flatten, reference_points, reference_points[:, :, :1], input_spatial_shapes[0])
         output = self._attend(value, input_spatial_shapes, input_level_start_index, temporal_offsets,
                               loc_curr, w_curr, loc_temp, w_temp)
         return self.output_proj(output), None

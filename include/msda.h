@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 5
+#define MSDA_ABI_VERSION 6
 #define MSDA_BWD_WORKSPACE_BYTES 64   /* minimum device scratch of the backward entry points (ticket counters) */
 
 enum msda_dtype { MSDA_F32 = 0, MSDA_F64 = 1, MSDA_BF16 = 2, MSDA_F16 = 3 };
@@ -161,6 +161,38 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
                            void *grad_value, void *grad_loc_curr, void *grad_aw_curr,
                            void *grad_loc_temp, void *grad_aw_temp, void *workspace, long long workspace_bytes,
                            const int64_t *value_strides, void *stream);
+
+/*
+ * Pre-op fusion: everything the modules do between their Linears and the operator
+ * (ms_deform_attn.py:105-121, 225-266, 327-352) in one pass -- the JOINT softmax over a (row, head)'s
+ * L*Pc current-frame + window*L*Pt temporal logits, split into the two attention tensors, and the sampling
+ * locations  ref + offsets / (W_l, H_l)  (ref_dim 2)  or  ref_xy + offsets / P * ref_wh * 0.5  (ref_dim 4,
+ * boxes) -- written in the layouts msda_temporal_forward takes.  window = 0: the plain module (temporal
+ * pointers unused).  rows = frames * queries; every tensor is dense:
+ *
+ *   offsets_curr [rows, M, L, Pc, 2]       offsets_temp [rows, M, window*L, Pt, 2]      (Linear outputs, viewed)
+ *   logits_curr  [rows, M, L*Pc]           logits_temp  [rows, M, window*L*Pt]
+ *   ref_curr     [rows, L, ref_dim]        ref_temp     [rows, window*L, ref_dim]
+ *   spatial_shapes [L, 2] int64 (H, W), device
+ *   loc_curr / aw_curr, loc_temp / aw_temp: shapes of the offsets / logits, fully overwritten.
+ */
+int msda_prep_forward(int dtype, const void *offsets_curr, const void *offsets_temp, const void *logits_curr,
+                      const void *logits_temp, const void *ref_curr, const void *ref_temp,
+                      const int64_t *spatial_shapes, long long rows, int num_heads, int num_levels, int window,
+                      int num_curr_point, int num_temp_point, int ref_dim,
+                      void *loc_curr, void *loc_temp, void *aw_curr, void *aw_temp, void *stream);
+
+/*
+ * Its backward: grad_offsets = grad_loc scaled by the same per-level (or per-box) factors, grad_logits =
+ * aw * (grad_aw - sum_j aw_j grad_aw_j) over the joint softmax.  Gradients of the reference points are sums
+ * of grad_loc over heads and points and are left to the caller (they are only needed in the decoder).
+ */
+int msda_prep_backward(int dtype, const void *grad_loc_curr, const void *grad_loc_temp, const void *grad_aw_curr,
+                       const void *grad_aw_temp, const void *aw_curr, const void *aw_temp, const void *ref_curr,
+                       const void *ref_temp, const int64_t *spatial_shapes, long long rows, int num_heads,
+                       int num_levels, int window, int num_curr_point, int num_temp_point, int ref_dim,
+                       void *grad_offsets_curr, void *grad_offsets_temp, void *grad_logits_curr,
+                       void *grad_logits_temp, void *stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ dev = "cuda:0"
 T, C = 6, 256
 
 
-def run(kind, pyr, fused, pad=1, reps=10):
+def run(kind, pyr, fused, pad=1, prep=True, reps=10):
     torch.manual_seed(0)
     shapes = torch.tensor(PYR[pyr], device=dev)
     lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
@@ -32,6 +32,7 @@ def run(kind, pyr, fused, pad=1, reps=10):
     src = torch.randn(T, S, C, device=dev, requires_grad=True)
     mod.fused = fused
     mod.value_pad_heads = pad
+    mod.fused_prep = prep
 
     def step():
         out = mod(query, ref, src, (shapes, t_shapes), (lsi, t_lsi), offs)[0]
@@ -45,10 +46,11 @@ def run(kind, pyr, fused, pad=1, reps=10):
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
-    print(f"{kind:8s} pyramid {pyr} (S={S}) fused={fused!s:5s} value_pad_heads={pad}: {ms:8.3f} ms per layer fwd+bwd (whole module incl. Linears/softmax)", flush=True)
+    print(f"{kind:8s} pyramid {pyr} (S={S}) fused={fused!s:5s} value_pad_heads={pad} fused_prep={prep!s:5s}: {ms:8.3f} ms per layer fwd+bwd (whole module incl. Linears/softmax)", flush=True)
 
 
 for kind, pyr in (("decoder", "A"), ("encoder", "A"), ("decoder", "B"), ("encoder", "B")):
-    run(kind, pyr, True, 1)
-    run(kind, pyr, True, 0)
-    run(kind, pyr, False, 0)
+    run(kind, pyr, True, 1, True)
+    run(kind, pyr, True, 1, False)
+    run(kind, pyr, True, 0, False)
+    run(kind, pyr, False, 0, False)

@@ -55,3 +55,52 @@ def test_devis_sized_decoder_layer_runs_and_fused_equals_loop():
         outs.append((ret[0].detach(), gq, gs))
     for a, b in zip(*outs):
         assert (a - b).abs().max().item() <= 1e-3 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-6)])
+@pytest.mark.parametrize("d", [2, 4])
+@pytest.mark.parametrize("W", [0, 3])
+def test_prep_function_matches_torch_ops(dtype, tol, d, W):
+    """MSDeformPrepFunction (SURVEY f-2: joint softmax + sampling locations in one fused pass) against the
+    torch ops of ref ms_deform_attn.py:112-121 / :252-258 -- outputs and every gradient, 2-d and box
+    reference points, with and without a temporal part."""
+    import torch.nn.functional as F
+    from devis_amd.functions import MSDeformPrepFunction
+    DEV = "cuda:0"
+    g = torch.Generator().manual_seed(11 + d + W)
+    R, M, L, Pc, Pt = 37, 8, 3, 4, 2
+    shapes = torch.tensor([[9, 7], [5, 4], [3, 2]], device=DEV)
+    mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64).to(DEV, dtype).requires_grad_(True)
+    off_c, lg_c = mk(R, M, L, Pc, 2), mk(R, M, L * Pc)
+    ref_c = torch.rand(R, L, d, generator=g, dtype=torch.float64).to(DEV, dtype).requires_grad_(True)
+    off_t = lg_t = ref_t = None
+    if W:
+        off_t, lg_t = mk(R, M, W * L, Pt, 2), mk(R, M, W * L * Pt)
+        ref_t = torch.rand(R, W * L, d, generator=g, dtype=torch.float64).to(DEV, dtype).requires_grad_(True)
+
+    def torch_path():
+        norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).to(dtype)
+        def loc(ref, off, nrm, P):
+            r = ref[:, None, :, None, :]
+            return r + off / nrm[None, None, :, None, :] if d == 2 else r[..., :2] + off / P * r[..., 2:] * 0.5
+        logits = lg_c if not W else torch.cat([lg_c, lg_t], 2)
+        w = F.softmax(logits, -1)
+        outs = [loc(ref_c, off_c, norm, Pc), w[..., :L * Pc].reshape(R, M, L, Pc)]
+        if W:
+            outs += [loc(ref_t, off_t, norm.repeat(W, 1), Pt), w[..., L * Pc:].reshape(R, M, W * L, Pt)]
+        return outs
+
+    def fused_path():
+        lc, lt, ac, at = MSDeformPrepFunction.apply(off_c, off_t, lg_c, lg_t, ref_c, ref_t, shapes)
+        return [lc, ac] + ([lt, at] if W else [])
+
+    leaves = [t for t in (off_c, lg_c, ref_c, off_t, lg_t, ref_t) if t is not None]
+    results = []
+    for path in (torch_path, fused_path):
+        outs = path()
+        gen = torch.Generator().manual_seed(5)
+        cot = [torch.randn(o.shape, generator=gen, dtype=torch.float64).to(DEV, dtype) for o in outs]
+        grads = torch.autograd.grad(outs, leaves, cot)
+        results.append([o.detach() for o in outs] + list(grads))
+    for a, b in zip(*results):
+        assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
