@@ -2300,7 +2300,7 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     // the slab kernels run 4 channels per lane for every dtype (SlabStore): twice the lanes per row for 16-bit types
     constexpr int GSL = SlabStore<T>::VEC == Store<T>::VEC ? G : 2 * G;
     constexpr int RPWS = kWave / (GSL <= kWave ? GSL : kWave);
-    if constexpr (GSL <= kWave) if (!bwd && p.LA == p.L && p.L <= kSlabMaxLevels) {
+    if constexpr (GSL >= 4 && GSL <= kWave) if (!bwd && p.LA == p.L && p.L <= kSlabMaxLevels) {   // (1- and 2-lane rows spill)
         // slab forward: 16 waves per workgroup share the small levels in LDS; needs enough workgroups.
         // Picked automatically for 4-byte types only: for the 16-bit types the 16-byte-lane tile kernel (half
         // the instructions per point) is as fast or faster (cfg2 bf16: 0.48 vs 0.57 ms); the gather pass
@@ -2348,7 +2348,7 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     int rc = MSDA_OK;
     if (phases & 1) {
         bool done = false;
-        if constexpr (GSL <= kWave) if (p.LA == p.L && p.L <= kSlabMaxLevels) {      // slab variant of the gather pass
+        if constexpr (GSL >= 4 && GSL <= kWave) if (p.LA == p.L && p.L <= kSlabMaxLevels) {      // slab variant of the gather pass
             const int tiles_per_clip = p.frames * ((p.Lq + RPWS - 1) / RPWS);
             const int blocks_per_clip = (tiles_per_clip + kSlabWaves - 1) / kSlabWaves;
             const int64_t slab_blocks = (int64_t)(p.groups / p.frames) * blocks_per_clip * p.M;
