@@ -21,10 +21,19 @@
 //   * blockIdx -> (query tile, head) with head = blockIdx % M: workgroups are dealt round-robin to the
 //     8 XCDs, so with M = 8 each XCD's private 4 MiB L2 only ever sees ONE head's 1/8 slice of the
 //     value maps (XCD-aware mapping; affects speed only, never results).
-//   * backward: per-point partial dot products <grad_out, corner_k> are reduced across the G lanes
-//     with DPP/shuffle butterflies (no LDS round trip, no serial thread-0 sum as in cuh:376-394);
-//     grad_value uses hardware fp32/fp64 global atomics (global_atomic_add_f32/f64, no CAS loop).
+//   * "slab" variants of the forward and of the backward gather pass: 16 waves share a workgroup and an
+//     LDS slab of the small pyramid levels of one source frame (staged with LDS-DMA), taking half of the
+//     taps off the L1/TA path.
+//   * backward = two passes.  Gather pass (grad_loc / grad_attn): per-point partial dot products
+//     <grad_out, corner_k> are reduced across the G lanes with DPP butterflies (no LDS round trip, no
+//     serial thread-0 sum as in cuh:376-394), lane pp % G keeps the sums of point pp and G points are
+//     finished at once; it also leaves per-point culling records.  Scatter pass (grad_value): privatised
+//     in LDS per (clip, frame, head, band of pixel rows), accumulated in fp64 with ds_add_f64, software-
+//     pipelined over the items, hit records handed to the lane teams by DPP; grad_value is OVERWRITTEN.
+//     A one-kernel backward with hardware float global atomics remains as the fallback.
 //   * generic kernels (any D, any dtype incl. fp64) back the shapes the tile kernels do not take.
+//   * msda_prep_kernel: the modules' joint softmax + sampling-location arithmetic as one pass each way.
+//   * no implicit FMA contraction in this file (see the pragma below).
 //
 // No CUDA compatibility layer, no hipify output: this file targets gfx950 only.
 
