@@ -53,6 +53,21 @@ __global__ void __launch_bounds__(kThreads) k(float *out, int iters)
             double *b = reinterpret_cast<double *>(band);
 #pragma unroll
             for (int c = 0; c < 4; ++c) unsafeAtomicAdd(b + (pix >> 1) * 32 + ((c + team) & 3) * 8 + sub, (double)v);
+        } else if (MODE == 11) {    // ds_add_f64, all 64 lanes on 64 consecutive doubles (random 512-byte segment per instruction)
+            double *b = reinterpret_cast<double *>(band);
+            const int seg = __builtin_amdgcn_readfirstlane(pix) % 14;          // wave-uniform segment of 64 doubles
+#pragma unroll
+            for (int c = 0; c < 4; ++c) unsafeAtomicAdd(b + ((seg + 3 * c) % 14) * 64 + lane, (double)v);
+        } else if (MODE == 12) {    // ds_add_f64, lanes of a team 4 doubles apart (stride 32 B), start rotated per team
+            double *b = reinterpret_cast<double *>(band);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) unsafeAtomicAdd(b + (pix >> 1) * 32 + 4 * sub + ((c + team) & 3), (double)v);
+        } else if (MODE == 13) {    // ds_add_f64, two teams of 32 lanes, each on 32 consecutive doubles
+            double *b = reinterpret_cast<double *>(band);
+            const int half = lane >> 5, l32 = lane & 31;
+            const int px = (__builtin_amdgcn_readfirstlane(pix) + 7 * half) % 28;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) unsafeAtomicAdd(b + ((px + 5 * c) % 28) * 32 + l32, (double)v);
         } else if (MODE == 10) {    // ds_max_f32 / ds_min style float op for reference
 #pragma unroll
             for (int c = 0; c < 4; ++c) atomicMax(reinterpret_cast<int *>(band) + pix * 32 + ((c + team) & 3) * 8 + sub, (int)(s & 255));
@@ -97,7 +112,10 @@ int main()
     run<1>("ds_add_u32 rotated octets", 4);
     run<2>("ds_add_u64 rotated octets", 4);
     run<8>("ds_pk_add_f16", 2);
-    run<9>("ds_add_f64", 4);
+    run<9>("ds_add_f64 rotated octets", 4);
+    run<11>("ds_add_f64 64 lanes contiguous", 4);
+    run<13>("ds_add_f64 2 x 32 lanes contiguous", 4);
+    run<12>("ds_add_f64 team lanes 32 B apart", 4);
     run<10>("ds_max_i32", 4);
     run<3>("RMW float4 (non-atomic)", 1);
     run<4>("RMW 4 x b32 (non-atomic)", 4);
