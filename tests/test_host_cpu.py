@@ -143,3 +143,28 @@ def test_frame_table_is_cached_per_offset_tensors():
     assert b is not a and b.tolist() == a.tolist()
     c = Dec._frame_table([o.clone() for o in offs], 3, torch.device("cpu"))    # other tensors: miss
     assert c is not b
+
+
+def test_project_value_padded_equals_dense_linear():
+    """functions.project_value (SURVEY f-3): value_proj written with a padded pixel stride gives the same
+    value tensor and the same gradients (input, weight, bias) as the reference's dense Linear + masked_fill
+    (ms_deform_attn.py:118-121); only the strides differ."""
+    from devis_amd.functions import project_value
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(24, 32).double()
+    x = torch.randn(2, 13, 24, dtype=torch.float64, requires_grad=True)
+    mask = torch.rand(2, 13) < 0.3
+    cot = torch.randn(2, 13, 4, 8, dtype=torch.float64)
+    res = []
+    for pad in (0, 1, 3):
+        v = project_value(x, lin, 4, mask, pad_heads=pad)
+        assert v.shape == (2, 13, 4, 8)
+        assert v.is_contiguous() == (pad == 0)
+        if pad:
+            assert v.stride() == (13 * (4 + pad) * 8, (4 + pad) * 8, 8, 1)
+        g = torch.autograd.grad(v, (x, lin.weight, lin.bias), cot)
+        res.append([v.detach().clone()] + [t.clone() for t in g])
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-13)
+    assert (res[1][0][mask] == 0).all()
