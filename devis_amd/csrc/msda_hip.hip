@@ -174,6 +174,16 @@ template <> struct SlabStore<f16_t> {
     }
 };
 
+// Gather load of one 16-/8-byte lane vector at  base + (element offset from the tap record) + (this lane's
+// byte offset):  `base` is wave-uniform (it lives in SGPRs), so the access is the saddr form with ONE 32-bit
+// VGPR offset -- one v_lshl_add_u32 per load instead of a sign extension and a 64-bit add per load.
+template <typename S, typename T, int N>
+__device__ __forceinline__ void gather_load(const T *base, int elem_off, unsigned lane_bytes, float (&v)[N])
+{
+    const unsigned off = ((unsigned)elem_off * (unsigned)sizeof(T)) + lane_bytes;
+    S::load(reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + off), v);
+}
+
 // hardware float atomics (global_atomic_add_f32 / _f64, no return value, no CAS loop)
 __device__ __forceinline__ void atomic_accumulate(float *p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_accumulate(double *p, double v) { unsafeAtomicAdd(p, v); }
@@ -409,8 +419,8 @@ msda_fwd_tile_kernel(const Params p)
     const int r = lane / G, sub = lane % G;
     const int rows_valid = min(RPW, p.Lq - q0);
     const int MD = p.M * p.D;
-    const T *__restrict__ value =
-        static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head + sub * VEC;
+    const T *__restrict__ vbase = static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head;   // wave-uniform
+    const unsigned lane_bytes = (unsigned)(sub * VEC * (int)sizeof(T));
     const int64_t row0 = ((int64_t)group * p.Lq + q0) * p.M + m;   // row of rr = 0; next row: + M
 
     float acc[VEC];
@@ -441,10 +451,10 @@ msda_fwd_tile_kernel(const Params p)
             for (int b = 0; b < NB; ++b) { o[b] = ro[pp + b]; w[b] = rw[pp + b]; }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                Store<T>::load(value + o[b].x, v[b][0]);
-                Store<T>::load(value + o[b].y, v[b][1]);
-                Store<T>::load(value + o[b].z, v[b][2]);
-                Store<T>::load(value + o[b].w, v[b][3]);
+                gather_load<Store<T>>(vbase, o[b].x, lane_bytes, v[b][0]);
+                gather_load<Store<T>>(vbase, o[b].y, lane_bytes, v[b][1]);
+                gather_load<Store<T>>(vbase, o[b].z, lane_bytes, v[b][2]);
+                gather_load<Store<T>>(vbase, o[b].w, lane_bytes, v[b][3]);
             }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
@@ -557,8 +567,8 @@ msda_fwd_slab_kernel(const Params p, int slab_elems)
     const int r = lane / G, sub = lane % G;
     const int rows_valid = have_tile ? min(RPW, p.Lq - q0) : 0;
     const int D = p.D, MD = p.M * p.D;
-    const T *__restrict__ value =
-        static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head + sub * VEC;
+    const T *__restrict__ vbase = static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head;   // wave-uniform
+    const unsigned lane_bytes = (unsigned)(sub * VEC * (int)sizeof(T));
     const T *slab_lane = slab + sub * VEC;
     const int64_t row0 = ((int64_t)group * p.Lq + q0) * p.M + m;
 
@@ -598,6 +608,7 @@ msda_fwd_slab_kernel(const Params p, int slab_elems)
             const int pt0 = sl < 0 ? 0 : sl * L * P;
             const int vl0 = sl < 0 ? 0 : p.LA + sl * L;    // virtual level of the slot's level 0
             const int npts = nlev * P;
+            const int first_slab_pt = l0 < nlev ? l0 * P : 0x7fffffff;     // points of levels >= l0 read the slab
 #pragma unroll 1
             for (int c0 = 0; c0 < npts; c0 += kPch) {
                 // ---- stage: tap records of this chunk (one point per lane and step), LDS or global flavour
@@ -638,20 +649,18 @@ msda_fwd_slab_kernel(const Params p, int slab_elems)
                     for (int b = 0; b < NB; ++b) { o[b] = ro[pp + b]; w[b] = rw[pp + b]; }
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
-                        const bool in_slab = min(c0 + pp + b, npts - 1) / P >= l0;     // wave-uniform
-                        const T *base = in_slab ? slab_lane : value;
+                        const bool in_slab = c0 + pp + b >= first_slab_pt;             // wave-uniform
                         if (in_slab) {
                             SlabStore<T>::load(slab_lane + o[b].x, v[b][0]);
                             SlabStore<T>::load(slab_lane + o[b].y, v[b][1]);
                             SlabStore<T>::load(slab_lane + o[b].z, v[b][2]);
                             SlabStore<T>::load(slab_lane + o[b].w, v[b][3]);
                         } else {
-                            SlabStore<T>::load(value + o[b].x, v[b][0]);
-                            SlabStore<T>::load(value + o[b].y, v[b][1]);
-                            SlabStore<T>::load(value + o[b].z, v[b][2]);
-                            SlabStore<T>::load(value + o[b].w, v[b][3]);
+                            gather_load<SlabStore<T>>(vbase, o[b].x, lane_bytes, v[b][0]);
+                            gather_load<SlabStore<T>>(vbase, o[b].y, lane_bytes, v[b][1]);
+                            gather_load<SlabStore<T>>(vbase, o[b].z, lane_bytes, v[b][2]);
+                            gather_load<SlabStore<T>>(vbase, o[b].w, lane_bytes, v[b][3]);
                         }
-                        (void)base;
                     }
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
@@ -750,8 +759,8 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
     const int r = lane / G, sub = lane % G;
     const int rows_valid = have_tile ? min(RPW, p.Lq - q0) : 0;
     const int D = p.D, MD = p.M * p.D;
-    const T *__restrict__ value =
-        static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head + sub * VEC;
+    const T *__restrict__ vbase = static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head;   // wave-uniform
+    const unsigned lane_bytes = (unsigned)(sub * VEC * (int)sizeof(T));
     const T *slab_lane = slab + sub * VEC;
     const int64_t row0 = ((int64_t)group * p.Lq + q0) * p.M + m;
     const int64_t row = row0 + (int64_t)r * p.M;
@@ -795,6 +804,7 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
             const int pt0 = sl < 0 ? 0 : sl * L * P;
             const int vl0 = sl < 0 ? 0 : p.LA + sl * L;
             const int npts = nlev * P;
+            const int first_slab_pt = l0 < nlev ? l0 * P : 0x7fffffff;     // points of levels >= l0 read the slab
             if (s_bb) {
                 for (int j = lane; j < RPW * nlev; j += kWave) init_tap_rows(s_bb + 2 * j, p.cull_points != 0);
                 wave_sync();
@@ -840,7 +850,7 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
 #pragma unroll 2
                 for (int pp = 0; pp < np; ++pp) {
                     const int4 o = ro[pp];
-                    const bool in_slab = (c0 + pp) / P >= l0;          // wave-uniform
+                    const bool in_slab = c0 + pp >= first_slab_pt;     // wave-uniform
                     float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
                     if (in_slab) {
                         SlabStore<T>::load(slab_lane + o.x, v0);
@@ -848,10 +858,10 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
                         SlabStore<T>::load(slab_lane + o.z, v2);
                         SlabStore<T>::load(slab_lane + o.w, v3);
                     } else {
-                        SlabStore<T>::load(value + o.x, v0);
-                        SlabStore<T>::load(value + o.y, v1);
-                        SlabStore<T>::load(value + o.z, v2);
-                        SlabStore<T>::load(value + o.w, v3);
+                        gather_load<SlabStore<T>>(vbase, o.x, lane_bytes, v0);
+                        gather_load<SlabStore<T>>(vbase, o.y, lane_bytes, v1);
+                        gather_load<SlabStore<T>>(vbase, o.z, lane_bytes, v2);
+                        gather_load<SlabStore<T>>(vbase, o.w, lane_bytes, v3);
                     }
                     float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
@@ -937,7 +947,8 @@ msda_bwd_tile_kernel(const Params p)
     const int MD = p.M * p.D;
     // (the ATOMICS variant scatters grad_value at value's offsets: the host only takes it for the standard layout)
     const int64_t lane_off = clip * p.v_clip + m * p.v_head + sub * VEC;
-    const T *__restrict__ value = static_cast<const T *>(p.value) + lane_off;
+    const T *__restrict__ vbase = static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head;   // wave-uniform
+    const unsigned lane_bytes = (unsigned)(sub * VEC * (int)sizeof(T));
     float *__restrict__ gvalue = static_cast<float *>(p.grad_value) + lane_off;
     const int64_t row0 = ((int64_t)group * p.Lq + q0) * p.M + m;
     const int64_t row = row0 + (int64_t)r * p.M;
@@ -970,10 +981,10 @@ msda_bwd_tile_kernel(const Params p)
             for (int pp = 0; pp < np; ++pp) {
                 const int4 o = ro[pp];
                 float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
-                Store<T>::load(value + o.x, v0);
-                Store<T>::load(value + o.y, v1);
-                Store<T>::load(value + o.z, v2);
-                Store<T>::load(value + o.w, v3);
+                gather_load<Store<T>>(vbase, o.x, lane_bytes, v0);
+                gather_load<Store<T>>(vbase, o.y, lane_bytes, v1);
+                gather_load<Store<T>>(vbase, o.z, lane_bytes, v2);
+                gather_load<Store<T>>(vbase, o.w, lane_bytes, v3);
                 // d_k = <grad_out row, corner k> over this lane's channels
                 float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
@@ -2441,7 +2452,8 @@ int dispatch_tile(const Params &p, bool bwd, hipStream_t stream, bool &taken)
         (bwd && (!aligned16(p.grad_out) || !aligned16(p.grad_value))))
         return MSDA_OK;
     // element offsets inside one clip slab are 32-bit in the tap records
-    if ((int64_t)p.frames * p.S * p.M * p.D >= 0x7fffffffLL || (int64_t)p.frames * p.S * p.v_pix >= 0x7fffffffLL)
+    if ((int64_t)p.frames * p.S * p.M * p.D >= 0x7fffffffLL || (int64_t)p.frames * p.S * p.v_pix >= 0x7fffffffLL ||
+        (int64_t)p.frames * p.S * p.v_pix * (int64_t)sizeof(T) >= 0xffffffffLL)       // gather_load: 32-bit byte offsets
         return MSDA_OK;
     if (p.v_clip % VEC || p.v_head % VEC || p.v_pix % VEC) return MSDA_OK;
     // the one-kernel backward scatters grad_value (always dense) at value's offsets
