@@ -687,6 +687,25 @@ msda_fwd_slab_kernel(const Params p, int slab_elems)
 // lanes the butterfly is pure DPP (no LDS crossbar, no waits): quad_perm xor1 / xor2, row_half_mirror
 // (lane i <-> 7-i inside each 8), row_mirror (i <-> 15-i inside each 16); wider rows finish with
 // shuffles.  Every lane of the row ends up with the total.
+// <g, v> over a lane's VEC channels with separate even / odd partial sums: the pairs (g[2i], g[2i+1]) and
+// (v[2i], v[2i+1]) sit in adjacent registers, so the compiler emits v_pk_fma_f32 without operand shuffles
+// (the straightforward four-dots-at-once loop costs one v_mov per packed FMA).
+typedef float float2v __attribute__((ext_vector_type(2)));
+template <int N>
+__device__ __forceinline__ float dot_eo(const float (&g)[N], const float (&v)[N])
+{
+    float2v acc = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c + 1 < N; c += 2) {
+        const float2v gp = {g[c], g[c + 1]}, vp = {v[c], v[c + 1]};
+        acc = __builtin_elementwise_fma(gp, vp, acc);          // v_pk_fma_f32 on adjacent registers
+    }
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(acc.x), "v"(acc.y));     // (kept scalar: no re-packing with v_movs)
+    if (N & 1) r = fmaf(g[N - 1], v[N - 1], r);
+    return r;
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v)
 {
@@ -703,6 +722,36 @@ __device__ __forceinline__ float row_sum(float v)
     if (G >= 32) v += __shfl_xor(v, 16, kWave);
     if (G >= 64) v += __shfl_xor(v, 32, kWave);
     return v;
+}
+
+// The four dots of a point reduced over the G lanes of the row at once: four independent DPP butterflies
+// interleaved, each step ONE v_add_f32 with a DPP operand (the compiler's own lowering of row_sum is a
+// v_mov_b32_dpp per value plus a packed add: 1.5 instructions per value and step, and s_nops between
+// dependent steps; interleaving the four chains needs none).  G = 2, 4, 8, 16 only.
+template <int G>
+__device__ __forceinline__ void row_sum4(float &d0, float &d1, float &d2, float &d3)
+{
+    if constexpr (G == 2 || G == 4 || G == 8 || G == 16) {
+#define MSDA_DPP4(ctrl)                                                                                   \
+        "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                     \
+        "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                     \
+        "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                     \
+        "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        if constexpr (G == 2)
+            asm volatile("s_nop 1\n" MSDA_DPP4("quad_perm:[1,0,3,2]") : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+        else if constexpr (G == 4)
+            asm volatile("s_nop 1\n" MSDA_DPP4("quad_perm:[1,0,3,2]") MSDA_DPP4("quad_perm:[2,3,0,1]")
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+        else if constexpr (G == 8)
+            asm volatile("s_nop 1\n" MSDA_DPP4("quad_perm:[1,0,3,2]") MSDA_DPP4("quad_perm:[2,3,0,1]") MSDA_DPP4("row_half_mirror")
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+        else
+            asm volatile("s_nop 1\n" MSDA_DPP4("quad_perm:[1,0,3,2]") MSDA_DPP4("quad_perm:[2,3,0,1]") MSDA_DPP4("row_half_mirror")
+                         MSDA_DPP4("row_mirror") : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+#undef MSDA_DPP4
+    } else {
+        d0 = row_sum<G>(d0); d1 = row_sum<G>(d1); d2 = row_sum<G>(d2); d3 = row_sum<G>(d3);
+    }
 }
 
 // Backward gather pass (grad_loc / grad_attn) with the same workgroup-shared slab of the small levels.
@@ -863,15 +912,8 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
                         gather_load<SlabStore<T>>(vbase, o.z, lane_bytes, v2);
                         gather_load<SlabStore<T>>(vbase, o.w, lane_bytes, v3);
                     }
-                    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-#pragma unroll
-                    for (int c = 0; c < VEC; ++c) {
-                        d0 = fmaf(g[c], v0[c], d0);
-                        d1 = fmaf(g[c], v1[c], d1);
-                        d2 = fmaf(g[c], v2[c], d2);
-                        d3 = fmaf(g[c], v3[c], d3);
-                    }
-                    d0 = row_sum<G>(d0); d1 = row_sum<G>(d1); d2 = row_sum<G>(d2); d3 = row_sum<G>(d3);
+                    float d0 = dot_eo(g, v0), d1 = dot_eo(g, v1), d2 = dot_eo(g, v2), d3 = dot_eo(g, v3);
+                    row_sum4<G>(d0, d1, d2, d3);
                     const bool mine = sub == (pp & (G - 1));
                     k0 = mine ? d0 : k0; k1 = mine ? d1 : k1; k2 = mine ? d2 : k2; k3 = mine ? d3 : k3;
                     if ((pp & (G - 1)) == G - 1 || pp == np - 1) {      // wave-uniform
@@ -986,14 +1028,7 @@ msda_bwd_tile_kernel(const Params p)
                 gather_load<Store<T>>(vbase, o.z, lane_bytes, v2);
                 gather_load<Store<T>>(vbase, o.w, lane_bytes, v3);
                 // d_k = <grad_out row, corner k> over this lane's channels
-                float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) {
-                    d0 = fmaf(g[c], v0[c], d0);
-                    d1 = fmaf(g[c], v1[c], d1);
-                    d2 = fmaf(g[c], v2[c], d2);
-                    d3 = fmaf(g[c], v3[c], d3);
-                }
+                float d0 = dot_eo(g, v0), d1 = dot_eo(g, v1), d2 = dot_eo(g, v2), d3 = dot_eo(g, v3);
                 if (ATOMICS) {
                     // grad_value[corner k] += w_k * a * grad_out   (cuh:125,134,143,152)
                     const float4 w = rw[pp];
@@ -1018,12 +1053,7 @@ msda_bwd_tile_kernel(const Params p)
                         for (int c = 0; c < VEC; ++c) atomic_accumulate(gvalue + o.w + c, wa3 * g[c]);
                     }
                 }
-                if (!(p.dbg & 16)) {
-                    d0 = row_sum<G>(d0);
-                    d1 = row_sum<G>(d1);
-                    d2 = row_sum<G>(d2);
-                    d3 = row_sum<G>(d3);
-                }
+                if (!(p.dbg & 16)) row_sum4<G>(d0, d1, d2, d3);
                 const bool mine = sub == (pp & (G - 1));
                 k0 = mine ? d0 : k0; k1 = mine ? d1 : k1; k2 = mine ? d2 : k2; k3 = mine ? d3 : k3;
                 if ((pp & (G - 1)) == G - 1 || pp == np - 1) {      // wave-uniform
