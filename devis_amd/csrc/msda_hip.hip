@@ -1503,8 +1503,8 @@ __device__ __forceinline__ int team_bcast(int v, int lane)
     } else if constexpr (G == 8) {
         constexpr int q = R & 3;
         const int t = __builtin_amdgcn_update_dpp(0, v, q | (q << 2) | (q << 4) | (q << 6), 0xf, 0xf, true);
-        const int u = __builtin_amdgcn_update_dpp(0, t, 0x141, 0xf, 0xf, true);       // row_half_mirror
-        return ((lane & 4) == (R & 4)) ? t : u;
+        // row_half_mirror written only into the quads that do NOT hold lane R (bank_mask), the others keep t
+        return __builtin_amdgcn_update_dpp(t, t, 0x141, 0xf, (R & 4) ? 0x5 : 0xA, false);
     } else {
         return __shfl(v, (lane / G) * G + R, kWave);
     }
@@ -1772,13 +1772,16 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
         const int top_pix = (h.bits & 3) ? h.pix : h.pix + W;
         const int bot_pix = (h.bits & 12) ? h.pix + W : h.pix;
         double *top = band + top_pix * kD + sub, *bot = band + bot_pix * kD + sub;
+        const float2v w01 = {h.w0, h.w1}, w23 = {h.w2, h.w3};
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
             const int ch = ((c + team) % VEC) * G;
-            unsafeAtomicAdd(top + ch, (double)(h.w0 * h.g[c]));
-            unsafeAtomicAdd(top + ch + kD, (double)(h.w1 * h.g[c]));
-            unsafeAtomicAdd(bot + ch, (double)(h.w2 * h.g[c]));
-            unsafeAtomicAdd(bot + ch + kD, (double)(h.w3 * h.g[c]));
+            const float2v gg = {h.g[c], h.g[c]};
+            const float2v t01 = w01 * gg, t23 = w23 * gg;               // v_pk_mul_f32: the fp32 products of cuh:125-152
+            unsafeAtomicAdd(top + ch, (double)t01.x);
+            unsafeAtomicAdd(top + ch + kD, (double)t01.y);
+            unsafeAtomicAdd(bot + ch, (double)t23.x);
+            unsafeAtomicAdd(bot + ch + kD, (double)t23.y);
         }
     };
     auto fetchp = [&](const Item &it, int buf, int i, int listed, float &x, float &y, float &a, int &qrow) {
