@@ -2211,34 +2211,74 @@ msda_prep_kernel(const PrepParams p)
         const int64_t row = pair / p.M;
         const T *lc = static_cast<const T *>(BWD ? p.aw_c : p.logit_c) + pair * nc;
         const T *lt = static_cast<const T *>(BWD ? p.aw_t : p.logit_t) + pair * nt;
+        constexpr int NE = 8;                 // register-resident fast path: n <= 32 * NE logits per (row, head)
         if (!BWD) {
             // ---- joint softmax over the n logits of this (row, head)   (ref :252-258 / F.softmax)
-            A mx = -INFINITY;
-            for (int e = lane; e < n; e += 32) {
-                const A v = (A)Store<T>::get(e < nc ? lc + e : lt + (e - nc));
-                mx = v > mx ? v : mx;
-            }
-            mx = half_wave_max<A>(mx);
-            A sum = 0;
-            for (int e = lane; e < n; e += 32) sum += prep_exp((A)Store<T>::get(e < nc ? lc + e : lt + (e - nc)) - mx);
-            sum = half_wave_sum<A>(sum);
             T *ac = static_cast<T *>(p.aw_c) + pair * nc, *at = static_cast<T *>(p.aw_t) + pair * nt;
-            for (int e = lane; e < n; e += 32) {
-                const A v = prep_exp((A)Store<T>::get(e < nc ? lc + e : lt + (e - nc)) - mx) / sum;
-                Store<T>::put(e < nc ? ac + e : at + (e - nc), v);
+            if (n <= 32 * NE) {               // each logit is read once and exponentiated once
+                A v[NE];
+                A mx = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const int e = lane + 32 * i;
+                    v[i] = e < n ? (A)Store<T>::get(e < nc ? lc + e : lt + (e - nc)) : (A)-INFINITY;
+                    mx = v[i] > mx ? v[i] : mx;
+                }
+                mx = half_wave_max<A>(mx);
+                A sum = 0;
+#pragma unroll
+                for (int i = 0; i < NE; ++i) { v[i] = lane + 32 * i < n ? prep_exp(v[i] - mx) : (A)0; sum += v[i]; }
+                sum = half_wave_sum<A>(sum);
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const int e = lane + 32 * i;
+                    if (e < n) Store<T>::put(e < nc ? ac + e : at + (e - nc), v[i] / sum);
+                }
+            } else {
+                A mx = -INFINITY;
+                for (int e = lane; e < n; e += 32) {
+                    const A v = (A)Store<T>::get(e < nc ? lc + e : lt + (e - nc));
+                    mx = v > mx ? v : mx;
+                }
+                mx = half_wave_max<A>(mx);
+                A sum = 0;
+                for (int e = lane; e < n; e += 32) sum += prep_exp((A)Store<T>::get(e < nc ? lc + e : lt + (e - nc)) - mx);
+                sum = half_wave_sum<A>(sum);
+                for (int e = lane; e < n; e += 32) {
+                    const A v = prep_exp((A)Store<T>::get(e < nc ? lc + e : lt + (e - nc)) - mx) / sum;
+                    Store<T>::put(e < nc ? ac + e : at + (e - nc), v);
+                }
             }
         } else {
             // ---- softmax backward: g_logit = p * (g - sum_j p_j g_j)
             const T *gc = static_cast<const T *>(p.gaw_c) + pair * nc, *gt = static_cast<const T *>(p.gaw_t) + pair * nt;
-            A dot = 0;
-            for (int e = lane; e < n; e += 32)
-                dot += (A)Store<T>::get(e < nc ? lc + e : lt + (e - nc)) * (A)Store<T>::get(e < nc ? gc + e : gt + (e - nc));
-            dot = half_wave_sum<A>(dot);
             T *oc = static_cast<T *>(p.glogit_c) + pair * nc, *ot = static_cast<T *>(p.glogit_t) + pair * nt;
-            for (int e = lane; e < n; e += 32) {
-                const A pe = (A)Store<T>::get(e < nc ? lc + e : lt + (e - nc));
-                const A ge = (A)Store<T>::get(e < nc ? gc + e : gt + (e - nc));
-                Store<T>::put(e < nc ? oc + e : ot + (e - nc), pe * (ge - dot));
+            if (n <= 32 * NE) {
+                A pe[NE], ge[NE];
+                A dot = 0;
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const int e = lane + 32 * i;
+                    pe[i] = e < n ? (A)Store<T>::get(e < nc ? lc + e : lt + (e - nc)) : (A)0;
+                    ge[i] = e < n ? (A)Store<T>::get(e < nc ? gc + e : gt + (e - nc)) : (A)0;
+                    dot += pe[i] * ge[i];
+                }
+                dot = half_wave_sum<A>(dot);
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const int e = lane + 32 * i;
+                    if (e < n) Store<T>::put(e < nc ? oc + e : ot + (e - nc), pe[i] * (ge[i] - dot));
+                }
+            } else {
+                A dot = 0;
+                for (int e = lane; e < n; e += 32)
+                    dot += (A)Store<T>::get(e < nc ? lc + e : lt + (e - nc)) * (A)Store<T>::get(e < nc ? gc + e : gt + (e - nc));
+                dot = half_wave_sum<A>(dot);
+                for (int e = lane; e < n; e += 32) {
+                    const A pe = (A)Store<T>::get(e < nc ? lc + e : lt + (e - nc));
+                    const A ge = (A)Store<T>::get(e < nc ? gc + e : gt + (e - nc));
+                    Store<T>::put(e < nc ? oc + e : ot + (e - nc), pe * (ge - dot));
+                }
             }
         }
         // ---- sampling locations (ref :112-121): 2-d refs add offsets in pixels of the level, boxes add them
