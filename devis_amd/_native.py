@@ -11,7 +11,7 @@ import torch
 
 from . import build as _build
 
-MSDA_ABI_VERSION = 6
+MSDA_ABI_VERSION = 7
 BWD_WORKSPACE_BYTES = 64
 _DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.float16: 3}
 
@@ -63,9 +63,9 @@ def load():
         lib.msda_temporal_backward.restype = _ci
         lib.msda_temporal_backward.argtypes = [_ci] + [_vp] * 9 + [_ci] * 10 + [_vp] * 6 + [ctypes.c_longlong, _vp, _vp]
         lib.msda_prep_forward.restype = _ci
-        lib.msda_prep_forward.argtypes = [_ci] + [_vp] * 7 + [ctypes.c_longlong] + [_ci] * 6 + [_vp] * 5
+        lib.msda_prep_forward.argtypes = [_ci] + [_vp] * 7 + [ctypes.c_longlong] + [_ci] * 6 + [ctypes.c_longlong] + [_vp] * 5
         lib.msda_prep_backward.restype = _ci
-        lib.msda_prep_backward.argtypes = [_ci] + [_vp] * 9 + [ctypes.c_longlong] + [_ci] * 6 + [_vp] * 5
+        lib.msda_prep_backward.argtypes = [_ci] + [_vp] * 9 + [ctypes.c_longlong] + [_ci] * 6 + [ctypes.c_longlong] + [_vp] * 5
         _lib = lib
     return _lib
 
@@ -178,19 +178,19 @@ def temporal_backward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, grad_o
     _check(rc, "msda_temporal_backward")
 
 
-def prep_forward(off_c, off_t, logit_c, logit_t, ref_c, ref_t, shapes, rows, M, L, W, Pc, Pt, loc_c, loc_t, aw_c, aw_t):
+def prep_forward(off_c, off_t, logit_c, logit_t, ref_c, ref_t, shapes, rows, M, L, W, Pc, Pt, loc_c, loc_t, aw_c, aw_t, ld=0):
     """msda_prep_forward (include/msda.h): joint softmax + sampling locations in one pass."""
     with torch.cuda.device(off_c.device):
         rc = load().msda_prep_forward(dtype_code(off_c.dtype), _p(off_c), _p(off_t), _p(logit_c), _p(logit_t), _p(ref_c),
-                                      _p(ref_t), _p(shapes), rows, M, L, W, Pc, Pt, ref_c.shape[-1],
+                                      _p(ref_t), _p(shapes), rows, M, L, W, Pc, Pt, ref_c.shape[-1], ld,
                                       _p(loc_c), _p(loc_t), _p(aw_c), _p(aw_t), _stream(off_c))
     _check(rc, "msda_prep_forward")
 
 
 def prep_backward(gloc_c, gloc_t, gaw_c, gaw_t, aw_c, aw_t, ref_c, ref_t, shapes, rows, M, L, W, Pc, Pt,
-                  goff_c, goff_t, glogit_c, glogit_t):
+                  goff_c, goff_t, glogit_c, glogit_t, ld=0):
     with torch.cuda.device(gloc_c.device):
         rc = load().msda_prep_backward(dtype_code(gloc_c.dtype), _p(gloc_c), _p(gloc_t), _p(gaw_c), _p(gaw_t), _p(aw_c),
-                                       _p(aw_t), _p(ref_c), _p(ref_t), _p(shapes), rows, M, L, W, Pc, Pt, ref_c.shape[-1],
+                                       _p(aw_t), _p(ref_c), _p(ref_t), _p(shapes), rows, M, L, W, Pc, Pt, ref_c.shape[-1], ld,
                                        _p(goff_c), _p(goff_t), _p(glogit_c), _p(glogit_t), _stream(gloc_c))
     _check(rc, "msda_prep_backward")

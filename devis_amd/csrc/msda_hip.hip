@@ -2182,6 +2182,8 @@ struct PrepParams {
     const void *gloc_c, *gloc_t, *gaw_c, *gaw_t;  // backward inputs
     void *goff_c, *goff_t, *glogit_c, *glogit_t;  // backward outputs
     int64_t rows;
+    int64_t ld;                       // row stride of the Linear-side tensors (offsets / logits forward, their grads
+                                      // backward) when they are column slices of one fused matrix; 0 = each dense
     int M, L, W, Pc, Pt, d;
 };
 
@@ -2209,8 +2211,11 @@ msda_prep_kernel(const PrepParams p)
     const int64_t pairs = p.rows * p.M;
     for (int64_t pair = (int64_t)blockIdx.x * 8 + threadIdx.x / 32; pair < pairs; pair += (int64_t)gridDim.x * 8) {
         const int64_t row = pair / p.M;
-        const T *lc = static_cast<const T *>(BWD ? p.aw_c : p.logit_c) + pair * nc;
-        const T *lt = static_cast<const T *>(BWD ? p.aw_t : p.logit_t) + pair * nt;
+        const int m = (int)(pair - row * p.M);
+        // first element of this (row, head) in a Linear-side tensor with n_ (x2 for offsets) elements per head
+        auto raw = [&](int n_) { return p.ld ? row * p.ld + (int64_t)m * n_ : pair * n_; };
+        const T *lc = static_cast<const T *>(BWD ? p.aw_c : p.logit_c) + (BWD ? pair * nc : raw(nc));
+        const T *lt = static_cast<const T *>(BWD ? p.aw_t : p.logit_t) + (BWD ? pair * nt : raw(nt));
         constexpr int NE = 8;                 // register-resident fast path: n <= 32 * NE logits per (row, head)
         if (!BWD) {
             // ---- joint softmax over the n logits of this (row, head)   (ref :252-258 / F.softmax)
@@ -2252,7 +2257,7 @@ msda_prep_kernel(const PrepParams p)
         } else {
             // ---- softmax backward: g_logit = p * (g - sum_j p_j g_j)
             const T *gc = static_cast<const T *>(p.gaw_c) + pair * nc, *gt = static_cast<const T *>(p.gaw_t) + pair * nt;
-            T *oc = static_cast<T *>(p.glogit_c) + pair * nc, *ot = static_cast<T *>(p.glogit_t) + pair * nt;
+            T *oc = static_cast<T *>(p.glogit_c) + raw(nc), *ot = static_cast<T *>(p.glogit_t) + raw(nt);
             if (n <= 32 * NE) {
                 A pe[NE], ge[NE];
                 A dot = 0;
@@ -2288,10 +2293,11 @@ msda_prep_kernel(const PrepParams p)
             const int ee = cur ? e : e - nc, P = cur ? p.Pc : p.Pt;
             const int vl = ee / P;                            // level (current) or slot*L + level (temporal)
             const int l = cur ? vl : vl % p.L;
-            const int64_t idx = (pair * (cur ? nc : nt) + ee) * 2;
+            const int64_t idx = (pair * (cur ? nc : nt) + ee) * 2;                 // dense tensors (loc, grad_loc)
+            const int64_t ridx = raw(2 * (cur ? nc : nt)) + 2 * ee;                // Linear-side tensors
             const T *ref = static_cast<const T *>(cur ? p.ref_c : p.ref_t) + (row * (cur ? p.L : p.W * p.L) + vl) * p.d;
-            const T *in = static_cast<const T *>(BWD ? (cur ? p.gloc_c : p.gloc_t) : (cur ? p.off_c : p.off_t)) + idx;
-            T *out = static_cast<T *>(BWD ? (cur ? p.goff_c : p.goff_t) : (cur ? p.loc_c : p.loc_t)) + idx;
+            const T *in = static_cast<const T *>(BWD ? (cur ? p.gloc_c : p.gloc_t) : (cur ? p.off_c : p.off_t)) + (BWD ? idx : ridx);
+            T *out = static_cast<T *>(BWD ? (cur ? p.goff_c : p.goff_t) : (cur ? p.loc_c : p.loc_t)) + (BWD ? ridx : idx);
             const A x = (A)Store<T>::get(in), y = (A)Store<T>::get(in + 1);
             if (p.d == 2) {
                 const A nx = (A)p.shapes[2 * l + 1], ny = (A)p.shapes[2 * l];      // (W_l, H_l)
@@ -2812,7 +2818,7 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
 int msda_prep_forward(int dtype, const void *offsets_curr, const void *offsets_temp, const void *logits_curr,
                       const void *logits_temp, const void *ref_curr, const void *ref_temp,
                       const int64_t *spatial_shapes, long long rows, int num_heads, int num_levels, int window,
-                      int num_curr_point, int num_temp_point, int ref_dim,
+                      int num_curr_point, int num_temp_point, int ref_dim, long long raw_row_stride,
                       void *loc_curr, void *loc_temp, void *aw_curr, void *aw_temp, void *stream)
 {
     g_err[0] = 0;
@@ -2822,7 +2828,7 @@ int msda_prep_forward(int dtype, const void *offsets_curr, const void *offsets_t
     p.ref_c = ref_curr; p.ref_t = ref_temp; p.shapes = spatial_shapes;
     p.loc_c = loc_curr; p.loc_t = loc_temp; p.aw_c = aw_curr; p.aw_t = aw_temp;
     p.rows = rows; p.M = num_heads; p.L = num_levels; p.W = window; p.Pc = num_curr_point;
-    p.Pt = window > 0 ? num_temp_point : 1; p.d = ref_dim;
+    p.Pt = window > 0 ? num_temp_point : 1; p.d = ref_dim; p.ld = raw_row_stride;
     if (rows > 0 && (!offsets_curr || !logits_curr || !loc_curr || !aw_curr ||
                      (window > 0 && (!offsets_temp || !logits_temp || !loc_temp || !aw_temp))))
         return fail(MSDA_ERR_ARG, "msda_prep_forward: null pointer argument%s");
@@ -2833,8 +2839,8 @@ int msda_prep_backward(int dtype, const void *grad_loc_curr, const void *grad_lo
                        const void *grad_aw_temp, const void *aw_curr, const void *aw_temp, const void *ref_curr,
                        const void *ref_temp, const int64_t *spatial_shapes, long long rows, int num_heads,
                        int num_levels, int window, int num_curr_point, int num_temp_point, int ref_dim,
-                       void *grad_offsets_curr, void *grad_offsets_temp, void *grad_logits_curr,
-                       void *grad_logits_temp, void *stream)
+                       long long raw_row_stride, void *grad_offsets_curr, void *grad_offsets_temp,
+                       void *grad_logits_curr, void *grad_logits_temp, void *stream)
 {
     g_err[0] = 0;
     PrepParams p;
@@ -2844,7 +2850,7 @@ int msda_prep_backward(int dtype, const void *grad_loc_curr, const void *grad_lo
     p.ref_c = ref_curr; p.ref_t = ref_temp; p.shapes = spatial_shapes;
     p.goff_c = grad_offsets_curr; p.goff_t = grad_offsets_temp; p.glogit_c = grad_logits_curr; p.glogit_t = grad_logits_temp;
     p.rows = rows; p.M = num_heads; p.L = num_levels; p.W = window; p.Pc = num_curr_point;
-    p.Pt = window > 0 ? num_temp_point : 1; p.d = ref_dim;
+    p.Pt = window > 0 ? num_temp_point : 1; p.d = ref_dim; p.ld = raw_row_stride;
     if (rows > 0 && (!grad_loc_curr || !grad_aw_curr || !aw_curr || !grad_offsets_curr || !grad_logits_curr ||
                      (window > 0 && (!grad_loc_temp || !grad_aw_temp || !aw_temp || !grad_offsets_temp || !grad_logits_temp))))
         return fail(MSDA_ERR_ARG, "msda_prep_backward: null pointer argument%s");

@@ -308,3 +308,64 @@ class MSDeformPrepFunction(Function):
         gref_c = ref_grad(gloc_c, off_c, ref_c, Pc) if ctx.needs_input_grad[4] else None
         gref_t = ref_grad(gloc_t, off_t, ref_t, Pt) if (W and ctx.needs_input_grad[5]) else None
         return goff_c, goff_t, glogit_c, glogit_t, gref_c, gref_t, None
+
+
+class MSDeformPrepFusedFunction(Function):
+    """:class:`MSDeformPrepFunction` reading the offsets and logits as column slices of ONE matrix
+    ``y [R, M*L*Pc*2 + M*W*L*Pt*2 + M*L*Pc + M*W*L*Pt]`` -- the output of the module's four query-side Linears
+    run as a single GEMM (columns in that order) -- and writing their gradients as one matrix, so that the
+    Linears' backward is one dgrad and one wgrad GEMM as well.  ``apply(y, ref_c, ref_t | None, shapes, M, L, W,
+    Pc, Pt) -> (loc_c [R,M,L,Pc,2], loc_t, aw_c [R,M,L,Pc], aw_t)``."""
+
+    @staticmethod
+    def _cols(M, L, W, Pc, Pt):
+        n = [M * L * Pc * 2, M * W * L * Pt * 2, M * L * Pc, M * W * L * Pt]
+        o = [0, n[0], n[0] + n[1], n[0] + n[1] + n[2]]
+        return [(a, a + b) for a, b in zip(o, n)]
+
+    @staticmethod
+    def forward(ctx, y, ref_c, ref_t, shapes, M, L, W, Pc, Pt):
+        R = y.shape[0]
+        if y.stride(1) != 1:
+            y = y.contiguous()
+        cols = MSDeformPrepFusedFunction._cols(M, L, W, Pc, Pt)
+        assert y.shape[1] == cols[3][1]
+        v = [y[:, a:b] for a, b in cols]
+        ref_c = ref_c.contiguous()
+        ref_t = ref_t.contiguous() if W else None
+        loc_c = torch.empty((R, M, L, Pc, 2), dtype=y.dtype, device=y.device)
+        aw_c = torch.empty((R, M, L, Pc), dtype=y.dtype, device=y.device)
+        loc_t = torch.empty((R, M, W * L, Pt, 2), dtype=y.dtype, device=y.device) if W else None
+        aw_t = torch.empty((R, M, W * L, Pt), dtype=y.dtype, device=y.device) if W else None
+        _native.prep_forward(v[0], v[1] if W else None, v[2], v[3] if W else None, ref_c, ref_t, shapes, R, M, L, W,
+                             Pc, Pt if W else 1, loc_c, loc_t, aw_c, aw_t, ld=y.stride(0))
+        ctx.save_for_backward(aw_c, aw_t, ref_c, ref_t, shapes, y)
+        ctx.dims = (R, M, L, W, Pc, Pt)
+        return loc_c, loc_t, aw_c, aw_t
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloc_c, gloc_t, gaw_c, gaw_t):
+        aw_c, aw_t, ref_c, ref_t, shapes, y = ctx.saved_tensors
+        R, M, L, W, Pc, Pt = ctx.dims
+        cols = MSDeformPrepFusedFunction._cols(M, L, W, Pc, Pt)
+        gloc_c = torch.zeros_like(aw_c).unsqueeze(-1).repeat(1, 1, 1, 1, 2) if gloc_c is None else gloc_c.contiguous()
+        gaw_c = torch.zeros_like(aw_c) if gaw_c is None else gaw_c.contiguous()
+        if W:
+            gloc_t = torch.zeros_like(aw_t).unsqueeze(-1).repeat(1, 1, 1, 1, 2) if gloc_t is None else gloc_t.contiguous()
+            gaw_t = torch.zeros_like(aw_t) if gaw_t is None else gaw_t.contiguous()
+        gy = torch.empty((R, y.shape[1]), dtype=y.dtype, device=y.device)
+        g = [gy[:, a:b] for a, b in cols]
+        _native.prep_backward(gloc_c, gloc_t, gaw_c, gaw_t, aw_c, aw_t, ref_c, ref_t, shapes, R, M, L, W, Pc,
+                              Pt if W else 1, g[0], g[1] if W else None, g[2], g[3] if W else None, ld=gy.stride(0))
+
+        def ref_grad(gloc, off2d, ref, P):
+            gsum = gloc.sum((1, 3))
+            if ref.shape[-1] == 2:
+                return gsum
+            off = off2d.reshape(gloc.shape)
+            return torch.cat((gsum, (gloc * (off / P * 0.5)).sum((1, 3))), -1)
+
+        gref_c = ref_grad(gloc_c, y[:, cols[0][0]:cols[0][1]], ref_c, Pc) if ctx.needs_input_grad[1] else None
+        gref_t = ref_grad(gloc_t, y[:, cols[1][0]:cols[1][1]], ref_t, Pt) if (W and ctx.needs_input_grad[2]) else None
+        return gy, gref_c, gref_t, None, None, None, None, None, None

@@ -19,7 +19,7 @@ from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
 from ..functions import (MSDeformAttnFunction, MSDeformAttnTemporalFunction, MSDeformPrepFunction,
-                         project_value)
+                         MSDeformPrepFusedFunction, project_value)
 
 
 def _is_power_of_2(n):
@@ -131,10 +131,11 @@ class MSDeformAttn(nn.Module):
         if self.fused_prep and query.is_cuda:
             # softmax + location arithmetic in one pass (SURVEY f-2); same numbers as the branch below
             R = N * Len_q
-            locations, _, weights, _ = MSDeformPrepFunction.apply(
-                self.sampling_offsets(query).view(R, M, L, P, 2), None,
-                self.attention_weights(query).view(R, M, L * P), None,
-                reference_points.reshape(R, L, reference_points.shape[-1]), None, input_spatial_shapes)
+            y = F.linear(query.reshape(R, -1), torch.cat([self.sampling_offsets.weight, self.attention_weights.weight]),
+                         torch.cat([self.sampling_offsets.bias, self.attention_weights.bias]))
+            locations, _, weights, _ = MSDeformPrepFusedFunction.apply(
+                y, reference_points.reshape(R, L, reference_points.shape[-1]), None, input_spatial_shapes,
+                M, L, 0, P, 1)
             locations, weights = locations.view(N, Len_q, M, L, P, 2), weights.view(N, Len_q, M, L, P)
         else:
             offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
@@ -233,12 +234,14 @@ class TemporalMSDeformAttnBase(nn.Module):
             return value, loc_curr, loc_temp, w_curr, w_temp
         R = T * Len_q
         value = project_value(input_flatten, self.value_proj, M, None, self.value_pad_heads)
-        loc_c, loc_t, w_c, w_t = MSDeformPrepFunction.apply(
-            self.sampling_offsets(query).view(R, M, L, Pc, 2),
-            self.temporal_sampling_offsets(query).view(R, M, W * L, Pt, 2),
-            self.attention_weights(query).view(R, M, L * Pc),
-            self.temporal_attention_weights(query).view(R, M, W * L * Pt),
-            ref_curr.reshape(R, L, d), ref_temp.expand(T, Len_q, W * L, d).reshape(R, W * L, d), shapes)
+        # the four query-side Linears as ONE GEMM (same parameters, concatenated on the fly); the fused pass reads
+        # its output as column slices and returns one gradient matrix, so their backward is one dgrad + one wgrad
+        lins = (self.sampling_offsets, self.temporal_sampling_offsets, self.attention_weights,
+                self.temporal_attention_weights)
+        y = F.linear(query.reshape(R, -1), torch.cat([l.weight for l in lins]), torch.cat([l.bias for l in lins]))
+        loc_c, loc_t, w_c, w_t = MSDeformPrepFusedFunction.apply(
+            y, ref_curr.reshape(R, L, d), ref_temp.expand(T, Len_q, W * L, d).reshape(R, W * L, d), shapes,
+            M, L, W, Pc, Pt)
         return (value, loc_c.view(T, Len_q, M, L, Pc, 2), loc_t.view(T, Len_q, M, W * L, Pt, 2),
                 w_c.view(T, Len_q, M, L, Pc), w_t.view(T, Len_q, M, W * L, Pt))
 

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 6
+#define MSDA_ABI_VERSION 7
 #define MSDA_BWD_WORKSPACE_BYTES 64   /* minimum device scratch of the backward entry points (ticket counters) */
 
 enum msda_dtype { MSDA_F32 = 0, MSDA_F64 = 1, MSDA_BF16 = 2, MSDA_F16 = 3 };
@@ -174,25 +174,28 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
  *   logits_curr  [rows, M, L*Pc]           logits_temp  [rows, M, window*L*Pt]
  *   ref_curr     [rows, L, ref_dim]        ref_temp     [rows, window*L, ref_dim]
  *   spatial_shapes [L, 2] int64 (H, W), device
- *   loc_curr / aw_curr, loc_temp / aw_temp: shapes of the offsets / logits, fully overwritten.
+ *   loc_curr / aw_curr, loc_temp / aw_temp: shapes of the offsets / logits, dense, fully overwritten.
+ *   raw_row_stride: 0, or the row stride (elements) of offsets_* / logits_* when the four are column slices of
+ *   ONE matrix -- the output of the modules' four query-side Linears run as a single GEMM.
  */
 int msda_prep_forward(int dtype, const void *offsets_curr, const void *offsets_temp, const void *logits_curr,
                       const void *logits_temp, const void *ref_curr, const void *ref_temp,
                       const int64_t *spatial_shapes, long long rows, int num_heads, int num_levels, int window,
-                      int num_curr_point, int num_temp_point, int ref_dim,
+                      int num_curr_point, int num_temp_point, int ref_dim, long long raw_row_stride,
                       void *loc_curr, void *loc_temp, void *aw_curr, void *aw_temp, void *stream);
 
 /*
  * Its backward: grad_offsets = grad_loc scaled by the same per-level (or per-box) factors, grad_logits =
  * aw * (grad_aw - sum_j aw_j grad_aw_j) over the joint softmax.  Gradients of the reference points are sums
  * of grad_loc over heads and points and are left to the caller (they are only needed in the decoder).
+ * raw_row_stride: as above, for grad_offsets_* / grad_logits_* (column slices of one gradient matrix).
  */
 int msda_prep_backward(int dtype, const void *grad_loc_curr, const void *grad_loc_temp, const void *grad_aw_curr,
                        const void *grad_aw_temp, const void *aw_curr, const void *aw_temp, const void *ref_curr,
                        const void *ref_temp, const int64_t *spatial_shapes, long long rows, int num_heads,
                        int num_levels, int window, int num_curr_point, int num_temp_point, int ref_dim,
-                       void *grad_offsets_curr, void *grad_offsets_temp, void *grad_logits_curr,
-                       void *grad_logits_temp, void *stream);
+                       long long raw_row_stride, void *grad_offsets_curr, void *grad_offsets_temp,
+                       void *grad_logits_curr, void *grad_logits_temp, void *stream);
 
 #ifdef __cplusplus
 }

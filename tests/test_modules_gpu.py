@@ -104,3 +104,45 @@ def test_prep_function_matches_torch_ops(dtype, tol, d, W):
         results.append([o.detach() for o in outs] + list(grads))
     for a, b in zip(*results):
         assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("d", [2, 4])
+@pytest.mark.parametrize("W", [0, 3])
+def test_prep_fused_function_equals_prep_function(d, W):
+    """MSDeformPrepFusedFunction (offsets / logits as column slices of the single query-side GEMM's output, one
+    gradient matrix back) against MSDeformPrepFunction on the same numbers: outputs and all gradients."""
+    from devis_amd.functions import MSDeformPrepFunction, MSDeformPrepFusedFunction
+    DEV, dtype = "cuda:0", torch.float64
+    g = torch.Generator().manual_seed(23 + d + W)
+    R, M, L, Pc, Pt = 29, 8, 3, 4, 2
+    shapes = torch.tensor([[9, 7], [5, 4], [3, 2]], device=DEV)
+    cols = MSDeformPrepFusedFunction._cols(M, L, W, Pc, Pt if W else 1)
+    width = cols[3][1] if W else cols[2][1] + 0
+    if not W:
+        cols = MSDeformPrepFusedFunction._cols(M, L, 0, Pc, 1)
+        width = cols[3][1]
+    y = torch.randn(R, width, generator=g, dtype=torch.float64).to(DEV, dtype).requires_grad_(True)
+    ref_c = torch.rand(R, L, d, generator=g, dtype=torch.float64).to(DEV, dtype).requires_grad_(True)
+    ref_t = torch.rand(R, W * L, d, generator=g, dtype=torch.float64).to(DEV, dtype).requires_grad_(True) if W else None
+
+    def unfused():
+        off_c = y[:, cols[0][0]:cols[0][1]].reshape(R, M, L, Pc, 2)
+        lg_c = y[:, cols[2][0]:cols[2][1]].reshape(R, M, L * Pc)
+        off_t = y[:, cols[1][0]:cols[1][1]].reshape(R, M, W * L, Pt, 2) if W else None
+        lg_t = y[:, cols[3][0]:cols[3][1]].reshape(R, M, W * L * Pt) if W else None
+        return MSDeformPrepFunction.apply(off_c, off_t, lg_c, lg_t, ref_c, ref_t, shapes)
+
+    def fused():
+        return MSDeformPrepFusedFunction.apply(y, ref_c, ref_t, shapes, M, L, W, Pc, Pt if W else 1)
+
+    leaves = [t for t in (y, ref_c, ref_t) if t is not None]
+    results = []
+    for path in (unfused, fused):
+        outs = [o for o in path() if o is not None]
+        gen = torch.Generator().manual_seed(5)
+        cot = [torch.randn(o.shape, generator=gen, dtype=torch.float64).to(DEV, dtype) for o in outs]
+        grads = torch.autograd.grad(outs, leaves, cot)
+        results.append([o.detach() for o in outs] + list(grads))
+    for a, b in zip(*results):
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() <= 1e-12 * max(1.0, b.abs().max().item())
