@@ -1723,8 +1723,11 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
             int off = listed + wbase;
 #pragma unroll
             for (int b = 0; b < 4 * U; ++b) {
-                if ((mk.bal[b] >> lane) & 1ull)
-                    s_list[off + (int)__popcll(mk.bal[b] & ((1ull << lane) - 1ull))] = (int)(ent[b / 4] | ((unsigned)(b & 3) << 24));
+                // rank of this lane among the ballot's set bits: v_mbcnt_lo/hi (two instructions)
+                const unsigned lo = (unsigned)mk.bal[b], hi = (unsigned)(mk.bal[b] >> 32);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+                if ((lane < 32 ? lo >> lane : hi >> (lane - 32)) & 1u)
+                    s_list[off + rank] = (int)(ent[b / 4] | ((unsigned)(b & 3) << 24));
                 off += (int)__popcll(mk.bal[b]);
             }
         } else if (pendw && listed + wbase <= kScatterList && lane == 0) {
