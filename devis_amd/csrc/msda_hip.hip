@@ -1691,20 +1691,32 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
             }
         }
     };
-    struct Marks { u64 bal[4 * U]; int total; };
+    // Surviving points of this lane's U groups (bit 4u + j = point j of group u), their exclusive rank in the wave
+    // and the wave's total.  Entries are listed LANE-major: the points of one (query, head, level) stay adjacent in
+    // the list, so when several of them survive (local / clustered sampling) neighbouring lanes of the scan read
+    // the same 32-byte loc / 16-byte attn segment instead of one 64-byte granule each.
+    struct Marks { unsigned pm; int excl, total; };
     auto mark = [&](const Item &it, const int2 (&iv)[U]) {
         Marks mk;
-        mk.total = 0;
+        mk.pm = 0u;
         const int lo = min(it.r0 - 1, 32767), hi = min(it.r1, 32767);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int hr[4] = {(int)(short)(iv[u].x & 0xffff), iv[u].x >> 16, (int)(short)(iv[u].y & 0xffff), iv[u].y >> 16};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                mk.bal[4 * u + j] = __ballot(hr[j] >= lo && hr[j] <= hi);
-                mk.total += (int)__popcll(mk.bal[4 * u + j]);
-            }
+            for (int j = 0; j < 4; ++j) mk.pm |= (hr[j] >= lo && hr[j] <= hi) ? (1u << (4 * u + j)) : 0u;
         }
+        // wave-wide inclusive scan of the per-lane counts with DPP (row_shr 1, 2, 4, 8, then row_bcast 15 / 31)
+        const int cnt = __popc(mk.pm);
+        int v = cnt;
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+        mk.excl = v - cnt;
+        mk.total = __builtin_amdgcn_readlane(v, kWave - 1);
         return mk;
     };
     // One attempt at appending a batch's surviving points behind the `listed` entries of s_list, with ONE
@@ -1720,15 +1732,13 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
         wbase = __shfl(wbase, 0, kWave);
         fit = pendw && listed + wbase + mk.total <= kScatterList;
         if (fit) {
-            int off = listed + wbase;
+            int pos = listed + wbase + mk.excl;
 #pragma unroll
             for (int b = 0; b < 4 * U; ++b) {
-                // rank of this lane among the ballot's set bits: v_mbcnt_lo/hi (two instructions)
-                const unsigned lo = (unsigned)mk.bal[b], hi = (unsigned)(mk.bal[b] >> 32);
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-                if ((lane < 32 ? lo >> lane : hi >> (lane - 32)) & 1u)
-                    s_list[off + rank] = (int)(ent[b / 4] | ((unsigned)(b & 3) << 24));
-                off += (int)__popcll(mk.bal[b]);
+                if ((mk.pm >> b) & 1u) {
+                    s_list[pos] = (int)(ent[b / 4] | ((unsigned)(b & 3) << 24));
+                    ++pos;
+                }
             }
         } else if (pendw && listed + wbase <= kScatterList && lane == 0) {
             s_valid = listed + wbase;
