@@ -212,6 +212,8 @@ struct Params {
     int LA, PA, LB, PB;
     int64_t v_clip, v_head;     // element strides of `value`: between clips (= frames * S pixels), between heads
     int v_pix;                  // ... and between consecutive pixels (standard [S, M, D]: frames*S*M*D, D, M*D)
+    int *bsum;                  // bwd: [groups, M, LA+LB, ceil(Lq/64), 2] (min, max) top tap row over blocks of 64 queries
+                                // (built from the per-point records; lets long candidate ranges skip dead blocks) or null
     int cull_points;            // bbox entries are 4 x int16 top tap rows, one per POINT (PA, PB <= 4), not (min, max)
     int dbg;                    // measurement hooks (MSDA_DBG env), 0 in production
 };
@@ -1530,6 +1532,34 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f)
     static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
+// Coarse culling summary for long candidate ranges (encoder shapes, Lq = S): (min, max) top tap row over blocks
+// of kCullBlock consecutive queries of every (group, head, virtual level), reduced from the per-point records
+// the gather pass left.  One wave per block.
+constexpr int kCullBlock = 64;
+constexpr int kLiveWords = 64;          // up to 2048 cull batches per item take the block-summary pre-pass
+__global__ void __launch_bounds__(256)
+msda_cull_summary_kernel(const Params p)
+{
+    const int VL = p.LA + p.LB, nblk = (p.Lq + kCullBlock - 1) / kCullBlock;
+    const int64_t total = (int64_t)p.groups * p.M * VL * nblk;
+    const int lane = threadIdx.x % kWave;
+    for (int64_t e = (int64_t)blockIdx.x * 4 + threadIdx.x / kWave; e < total; e += (int64_t)gridDim.x * 4) {
+        const int64_t gmv = e / nblk;
+        const int q = (int)(e - gmv * nblk) * kCullBlock + lane;
+        int mn = 0x7fffffff, mx = -0x7fffffff - 1;
+        if (q < p.Lq) {
+            const int2 iv = *reinterpret_cast<const int2 *>(p.bbox + (gmv * p.Lq + q) * 2);
+            const int hr[4] = {(int)(short)(iv.x & 0xffff), iv.x >> 16, (int)(short)(iv.y & 0xffff), iv.y >> 16};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (hr[j] != kNoRow16) { mn = min(mn, hr[j]); mx = max(mx, hr[j]); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o, kWave)); mx = max(mx, __shfl_xor(mx, o, kWave)); }
+        if (lane == 0) *reinterpret_cast<int2 *>(p.bsum + e * 2) = make_int2(mn, mx);
+    }
+}
+
 // msda_bwd_value_points_kernel -- the scatter for the common case PA, PB <= 4, where the gather pass
 // leaves the top tap row of every POINT (4 x int16 per (row, level)) in the workspace.  Same work items,
 // same band accumulators, same arithmetic and flush as msda_bwd_value_lds_kernel; what differs is
@@ -1560,7 +1590,9 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
     __shared__ int s_dec[3][8];
     // per source, precomputed when the item is staged: first culling-table entry, first loc/attn element, first query row
     __shared__ long long s_src_tab[3][kScatterMaxSources], s_src_loc[3][kScatterMaxSources];
-    __shared__ int s_src_q0[3][kScatterMaxSources];           // staged item: valid, l, m, f, clip, r0, r1, direct
+    __shared__ int s_src_q0[3][kScatterMaxSources];
+    __shared__ int s_src_gmv[3][kScatterMaxSources];   // (group, head, virtual level) index of the source: row of p.bsum
+    __shared__ unsigned s_live[kLiveWords];            // bitmap of the cull batches that hold a live block           // staged item: valid, l, m, f, clip, r0, r1, direct
     __shared__ int s_list[kScatterList], s_cnt[3], s_valid;
     __shared__ int s_ftab[kScatterMaxSources];      // the frame table, read once
 
@@ -1647,6 +1679,7 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
             s_src_tab[buf][0] = ((g * p.M + m) * VL + l) * p.Lq;
             s_src_loc[buf][0] = (g * p.Lq * p.M + m) * ((int64_t)p.LA * p.PA) + l * p.PA;
             s_src_q0[buf][0] = (int)(g * p.Lq);
+            s_src_gmv[buf][0] = (int)((g * p.M + m) * VL + l);
             s_nsrc[buf] = ((dbg & 4) || ((dbg >> 8) & (1 << l))) ? 0 : 1 + (int)__popcll(bal);    // dbg: skip all / a level's sources
         }
         if (hit) {
@@ -1656,6 +1689,7 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
             s_src_tab[buf][n] = ((g * p.M + m) * VL + p.LA + vl) * p.Lq;
             s_src_loc[buf][n] = (g * p.Lq * p.M + m) * ((int64_t)p.LB * p.PB) + vl * p.PB;
             s_src_q0[buf][n] = (int)(g * p.Lq);
+            s_src_gmv[buf][n] = (int)((g * p.M + m) * VL + p.LA + vl);
         }
     };
     auto load_item = [&](int buf) {
@@ -1954,37 +1988,69 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
         // (b) scan this item
         {
             const int ng = s_nsrc[bc] * p.Lq;
+            const int nbat = (ng + kBatch - 1) / kBatch;
+            // Long candidate ranges (encoder shapes): a pre-pass over the 64-query block summaries marks the cull
+            // batches that hold a live block; with local sampling all but a few are skipped outright.
+            const bool skipping = p.bsum != nullptr && nbat > 4 && nbat <= 32 * kLiveWords;
+            if (skipping) {
+                if (tid < kLiveWords) s_live[tid] = 0u;
+                __syncthreads();
+                const int nblk = (p.Lq + kCullBlock - 1) / kCullBlock, nb_tot = s_nsrc[bc] * nblk;
+                const int lo = min(cur.r0 - 1, 32767), hi = min(cur.r1, 32767);
+                for (int b = tid; b < nb_tot; b += kScatterThreads) {
+                    const int ks = b / nblk, blk = b - ks * nblk;
+                    const int2 mm = *reinterpret_cast<const int2 *>(p.bsum + ((int64_t)s_src_gmv[bc][ks] * nblk + blk) * 2);
+                    if (mm.y >= lo && mm.x <= hi) {
+                        const int g0 = ks * p.Lq + blk * kCullBlock, g1 = min(g0 + kCullBlock, ks * p.Lq + p.Lq) - 1;
+                        atomicOr(&s_live[(g0 / kBatch) >> 5], 1u << ((g0 / kBatch) & 31));
+                        atomicOr(&s_live[(g1 / kBatch) >> 5], 1u << ((g1 / kBatch) & 31));
+                    }
+                }
+                __syncthreads();
+            }
+            auto next_live = [&](int b) {       // first batch >= b worth culling (nbat if none); workgroup-uniform
+                if (!skipping) return min(b, nbat);
+                while (b < nbat) {
+                    const unsigned w = s_live[b >> 5] >> (b & 31);
+                    if (w) return min(b + (int)__builtin_ctz(w), nbat);
+                    b = (b | 31) + 1;
+                }
+                return nbat;
+            };
             int listed = cur_listed;
             int2 iv2[U];
             unsigned ent2[U], ent3[U];
+            int b = next_live(1);
             if (cur_overflow) {         // the first batch did not fit when it was compacted early: redo it here
                 cull_load(cur, bc, 0, iv2, ent2);
                 const Marks mk = mark(cur, iv2);
                 __syncthreads();
                 listed = add_batch(cur, bc, mk, ent2, 0, x, y, a, qrow);
-                if (ng > kBatch) cull_load(cur, bc, kBatch, iv2, ent2);
-                if (ng <= kBatch || listed >= kScatterThreads) {
+                if (b < nbat) cull_load(cur, bc, b * kBatch, iv2, ent2);
+                if (b >= nbat || listed >= kScatterThreads) {
                     scan_points(cur, bc, listed, false, x, y, a, qrow);
                     __syncthreads();
                     listed = 0;
                 }
             } else {
-                if (ng > kBatch) cull_load(cur, bc, kBatch, iv2, ent2);
-                if (ng <= kBatch || listed >= kScatterThreads) {
+                if (b < nbat) cull_load(cur, bc, b * kBatch, iv2, ent2);
+                if (b >= nbat || listed >= kScatterThreads) {
                     scan_points(cur, bc, listed, true, x, y, a, qrow);
-                    if (ng > kBatch) __syncthreads();
+                    if (b < nbat) __syncthreads();
                     listed = 0;
                 }   // else: a sparse first batch of many -- keep accumulating (the primed pass is dropped)
             }
-            for (int gi0 = kBatch; gi0 < ng; gi0 += kBatch) {
+            while (b < nbat) {
                 const Marks mk = mark(cur, iv2);
 #pragma unroll
                 for (int u = 0; u < U; ++u) ent3[u] = ent2[u];
-                if (gi0 + kBatch < ng) cull_load(cur, bc, gi0 + kBatch, iv2, ent2);      // next batch's reads fly
+                const int bnext = next_live(b + 1);
+                if (bnext < nbat) cull_load(cur, bc, bnext * kBatch, iv2, ent2);      // next live batch's reads fly
                 listed = add_batch(cur, bc, mk, ent3, listed, x, y, a, qrow);
-                if (gi0 + kBatch < ng && listed < kScatterThreads) continue;      // not yet a full pass
+                b = bnext;
+                if (b < nbat && listed < kScatterThreads) continue;      // not yet a full pass
                 scan_points(cur, bc, listed, false, x, y, a, qrow);
-                if (gi0 + kBatch < ng) __syncthreads();
+                if (b < nbat) __syncthreads();
                 listed = 0;
             }
         }
@@ -2492,6 +2558,13 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
             if (rc) return rc;
         }
     }
+    if ((phases & 1) && p.cull_points && p.bsum) {       // block summaries of the per-point records just written
+        const int64_t entries = (int64_t)p.groups * p.M * (p.LA + p.LB) * ((p.Lq + kCullBlock - 1) / kCullBlock);
+        const unsigned sb = (unsigned)((entries + 3) / 4 < 65536 ? (entries + 3) / 4 : 65536);
+        hipLaunchKernelGGL(msda_cull_summary_kernel, dim3(sb), dim3(256), 0, stream, p);
+        rc = check_launch("msda backward (culling block summaries)");
+        if (rc) return rc;
+    }
     if (!(phases & 2)) return rc;
     // LDS budget: one 1024-thread workgroup per CU with 144 KiB of 8-byte accumulators
     const int cap_bytes = env_int("MSDA_SCATTER_LDS_KB", 144) * 1024;
@@ -2594,6 +2667,7 @@ int run(int dtype, const Params &p_in, bool bwd, hipStream_t stream)
     p.dbg = env_int("MSDA_DBG", 0);
     // culling records per point when a level has <= 4 points (MSDA_BWD_CULL=2: force (min, max) intervals)
     p.cull_points = bwd && p.bbox && p.PA <= 4 && p.PB <= 4 && env_int("MSDA_BWD_CULL", 1) != 2;
+    if (!p.cull_points) p.bsum = nullptr;
     if (p.groups == 0 || p.Lq == 0) return MSDA_OK;
     bool taken = false;
     int rc = MSDA_OK;
@@ -2649,18 +2723,31 @@ int zero_grad_value(int dtype, void *grad_value, int groups, int S, int M, int D
     return MSDA_OK;
 }
 
+long long workspace_table_bytes(int batch, int num_query, int num_heads, int virtual_levels)
+{
+    return (long long)batch * num_query * num_heads * virtual_levels * 8;
+}
+
+// ticket counters + per-point culling records + their 64-query block summaries
 long long workspace_need(int batch, int num_query, int num_heads, int virtual_levels)
 {
-    return MSDA_BWD_WORKSPACE_BYTES + (long long)batch * num_query * num_heads * virtual_levels * 8;
+    const long long nblk = (num_query + kCullBlock - 1) / kCullBlock;
+    return MSDA_BWD_WORKSPACE_BYTES + workspace_table_bytes(batch, num_query, num_heads, virtual_levels) +
+           (long long)batch * num_heads * virtual_levels * nblk * 8;
 }
 
 void attach_workspace(Params &p, void *workspace, long long bytes, int batch, int num_query, int num_heads, int vl)
 {
     p.workspace = (workspace && bytes >= MSDA_BWD_WORKSPACE_BYTES) ? static_cast<unsigned *>(workspace) : nullptr;
     p.bbox = nullptr;
+    p.bsum = nullptr;
     const char *e = getenv("MSDA_BWD_CULL");        // measurement hook: 0 disables the culling structure
-    if (p.workspace && bytes >= workspace_need(batch, num_query, num_heads, vl) && !(e && e[0] == '0'))
+    if (p.workspace && bytes >= workspace_need(batch, num_query, num_heads, vl) && !(e && e[0] == '0')) {
         p.bbox = reinterpret_cast<int *>(p.workspace) + MSDA_BWD_WORKSPACE_BYTES / 4;
+        // block summaries only pay for long candidate ranges (and index (group, head, level) rows with 32 bits)
+        if (num_query >= 2048 && (long long)batch * num_heads * vl < 0x7fffffffLL && env_int("MSDA_BWD_SUMMARY", 1) != 0)
+            p.bsum = p.bbox + workspace_table_bytes(batch, num_query, num_heads, vl) / 4;
+    }
 }
 
 template <typename T, typename A>

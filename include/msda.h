@@ -111,8 +111,10 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
                   void *workspace, long long workspace_bytes, const int64_t *value_strides, void *stream);
 
 /* Bytes of `workspace` that enable every feature of msda_backward / msda_temporal_backward:
- * 64 + rows * virtual_levels * 8 with rows = batch * num_query * num_heads and virtual_levels = num_levels
- * (msda_backward) or num_levels * (1 + window) (msda_temporal_backward; batch = clips * frames). */
+ * 64 (ticket counters) + rows * virtual_levels * 8 (per-point culling records) + their summaries over blocks of 64
+ * queries (batch * num_heads * virtual_levels * ceil(num_query / 64) * 8), with rows = batch * num_query *
+ * num_heads and virtual_levels = num_levels (msda_backward) or num_levels * (1 + window)
+ * (msda_temporal_backward; batch = clips * frames). */
 long long msda_backward_workspace_bytes(int batch, int num_query, int num_heads, int virtual_levels);
 
 /*
