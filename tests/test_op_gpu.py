@@ -557,3 +557,22 @@ def test_bench_scale_batch_equals_single_clip_runs():
             bc = b[c * T:(c + 1) * T]
             scale = max(1.0, s.abs().max().item())
             assert (bc - s).abs().max().item() <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("local", [False, True])
+def test_long_candidate_range_block_summaries(local):
+    """Lq large enough (> 4 cull batches of 2048 groups) for the 64-query block summaries and the batch-skipping
+    pre-pass of the scatter: uniform locations (every batch live) and query-index-local ones (most skipped)."""
+    d = make_inputs(314, 1, 8, 32, 11000, [(40, 24), (20, 12), (10, 6)], 4, "unit", np.float32)
+    if local:
+        rng = np.random.default_rng(9)
+        q = np.arange(11000, dtype=np.float64) / 11000.0
+        y = q[None, :, None, None, None] + rng.normal(0, 0.02, size=d["loc"].shape[:-1])
+        d["loc"][..., 1] = np.clip(y, -0.1, 1.1).astype(np.float32)
+    ref = oracle_fwd_bwd(d, np.float64)
+    ref32 = oracle_fwd_bwd(d, np.float32)
+    out, gv, gl, ga = _run_op(d, torch.float32)
+    assert _maxabs(out, ref[0]) <= 1e-5
+    assert _maxabs(gv, ref32[1]) <= 1e-4 * max(1.0, np.abs(ref[1]).max())
+    assert _maxabs(gl, ref32[2]) <= 1e-4 * max(1.0, np.abs(ref32[2]).max())
+    assert _maxabs(ga, ref32[3]) <= 1e-4 * max(1.0, np.abs(ref[3]).max())
