@@ -1787,6 +1787,7 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
     struct Hit { int pix, bits; float w0, w1, w2, w3; float g[VEC]; };
     Hit pend;
     pend.bits = 0;
+    int pend_q = -1;            // query row of `pend` (its grad_out row may serve the next hit of the team)
     auto consume = [&](const Item &it, const Hit &h) {
         if (!h.bits) return;
         const int W = it.W;
@@ -1884,15 +1885,18 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
                 const int h_q = team_bcast<G, R>(qr, lane);
                 h.w0 = team_bcast<G, R>(wa0, lane); h.w1 = team_bcast<G, R>(wa1, lane);
                 h.w2 = team_bcast<G, R>(wa2, lane); h.w3 = team_bcast<G, R>(wa3, lane);
+                // The list is lane-major, so with local / clustered sampling a team's consecutive hits are often
+                // points of the SAME query: its grad_out row is then already in the previous record.
+                const bool same_row = VEC <= 4 && pend.bits != 0 && h_q == pend_q;
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) h.g[c] = 0.f;
-                if (h.bits && !(dbg & 32)) {
+                for (int c = 0; c < VEC; ++c) h.g[c] = same_row ? pend.g[c] : 0.f;
+                if (h.bits && !same_row && !(dbg & 32)) {
                     const T *go = static_cast<const T *>(p.grad_out) + (int64_t)h_q * MD + it.m * D;
 #pragma unroll
                     for (int c = 0; c < VEC; ++c) h.g[c] = Store<T>::get(go + ((c + team) % VEC) * G + sub);
                 }
                 // (8-channel lanes: no one-group-ahead pipelining, the second record does not fit the registers)
-                if constexpr (VEC > 4) { consume(it, h); } else { consume(it, pend); pend = h; }
+                if constexpr (VEC > 4) { consume(it, h); } else { consume(it, pend); pend = h; pend_q = h_q; }
             };
             if constexpr (G == 4 || G == 8) {
                 static_for<G>(sub_round);
