@@ -2122,6 +2122,363 @@ msda_zero_unowned_kernel(const Params p, int cap_slots)
 }
 
 // ------------------------------------------------------------------------------------------------
+// "resident-slab" kernels (round 2): levels 1..L-1 of one source frame live in LDS, tap records in registers
+// ------------------------------------------------------------------------------------------------
+// The slab kernels above keep 70 KiB of per-wave tap records in LDS, which leaves room for levels 2-3 only
+// (50 % of the taps); everything else crosses the L1 path at ~25 B/clk/CU.  Here the records never touch
+// LDS, so ~156 KiB of the 160 are slab (levels 1-3 of the DeVIS pyramids: 75 % of the taps):
+//   * a 1024-thread workgroup owns (clip, head, a run of up to NT*16 row tiles); its waves keep the accumulators
+//     of NT tiles in registers while the workgroup walks the clip's SOURCE FRAMES; per frame the slab
+//     value[frame, levels >= l0, head, :] is staged by LDS-DMA (once per NT*16 tiles instead of once per 16),
+//     then every wave runs, for each of its tiles, the slots of that tile that read the frame;
+//   * a row (query, head) is served by ONE QUAD: 16 rows per wave, lane c of the quad holding channels
+//     [4c, 4c+4) of both halves of the row (D = 32).  Lane c also fetches point (g0 + c) of the row and turns it
+//     into "point data" (fractions, attention weight, top-left pixel, validity bits).  In step R the quad's
+//     lanes read lane R's data through quad_perm DPP operands folded into the consuming VALU instruction
+//     (v_and/v_add/v_fmac/v_mul ..._dpp: no LDS crossbar), each lane deriving the address and weight of ITS
+//     corner (lane & 3); the four corners of the point are then read with 16-byte loads whose addresses and
+//     weights come from lanes 0..3 of the quad, again by DPP.  (Measured, scripts/ubench/valu_rate.hip: a DPP
+//     operand makes a VALU instruction half rate -- 4.3 vs 2.3 clk per wave64 instruction -- so a weight is
+//     moved once per corner with v_mov_b32_dpp and then feeds 8 plain v_fmac_f32: that is why a row is a quad
+//     with 8 channels per lane and not 8 lanes with 4.)
+//   * quads alternate which 64-byte half of a 128-byte row they read first, which halves the LDS bank conflicts
+//     of the 16-lane ds_read_b128 groups (4 quads = 4 half rows on 4 different 16-bank quarters when row
+//     parities differ);
+//   * a corner outside the map reads a zero row kept in LDS (slab levels) or an out-of-range buffer offset
+//     (other levels: buffer loads return 0 without touching memory), so a non-finite value at an unrelated
+//     pixel can never leak into a row that does not sample it.
+constexpr int kRsThreads = 1024, kRsWaves = kRsThreads / kWave;
+constexpr int kRsRows = kWave / 4;       // rows per wave tile: one quad per row
+constexpr int kRsSlack = 1024;          // bytes: the last LDS-DMA piece may overrun the slab's pixels
+constexpr int kRsMaxFrames = 32;        // frames x frames slot masks live in LDS
+constexpr int kRsRowB = 128;            // bytes of one pixel of one head: D = 32 channels x 4 bytes
+constexpr int kRsTailBytes = kRsRowB + kRsMaxFrames * kRsMaxFrames * 4 + 4 * kSlabMaxLevels * 4 + 16;   // after the slab
+
+#define MSDA_QP(s) "quad_perm:[" #s "," #s "," #s "," #s "] row_mask:0xf bank_mask:0xf"
+
+// dst = quad_lane_R(src) <op> other, R a compile-time constant
+#define MSDA_DEF_QUAD_OP(name, ctype, mnem)                                                                \
+    template <int R> __device__ __forceinline__ ctype name(ctype src, ctype other)                         \
+    {                                                                                                      \
+        ctype r;                                                                                           \
+        if constexpr (R == 0) asm(mnem " %0, %1, %2 " MSDA_QP(0) : "=v"(r) : "v"(src), "v"(other));       \
+        else if constexpr (R == 1) asm(mnem " %0, %1, %2 " MSDA_QP(1) : "=v"(r) : "v"(src), "v"(other));  \
+        else if constexpr (R == 2) asm(mnem " %0, %1, %2 " MSDA_QP(2) : "=v"(r) : "v"(src), "v"(other));  \
+        else asm(mnem " %0, %1, %2 " MSDA_QP(3) : "=v"(r) : "v"(src), "v"(other));                        \
+        return r;                                                                                          \
+    }
+MSDA_DEF_QUAD_OP(quad_and, int, "v_and_b32_dpp")
+MSDA_DEF_QUAD_OP(quad_add, int, "v_add_u32_dpp")
+MSDA_DEF_QUAD_OP(quad_mul, float, "v_mul_f32_dpp")
+#undef MSDA_DEF_QUAD_OP
+
+// acc += quad_lane_R(src) * other
+template <int R> __device__ __forceinline__ void quad_fmac(float &acc, float src, float other)
+{
+    if constexpr (R == 0) asm("v_fmac_f32_dpp %0, %1, %2 " MSDA_QP(0) : "+v"(acc) : "v"(src), "v"(other));
+    else if constexpr (R == 1) asm("v_fmac_f32_dpp %0, %1, %2 " MSDA_QP(1) : "+v"(acc) : "v"(src), "v"(other));
+    else if constexpr (R == 2) asm("v_fmac_f32_dpp %0, %1, %2 " MSDA_QP(2) : "+v"(acc) : "v"(src), "v"(other));
+    else asm("v_fmac_f32_dpp %0, %1, %2 " MSDA_QP(3) : "+v"(acc) : "v"(src), "v"(other));
+}
+
+// A VGPR written by a VALU instruction may be read through DPP only two wait states later; inline asm is
+// invisible to the compiler's hazard recogniser, so values about to be read that way pass through a fence.
+__device__ __forceinline__ void dpp_fence(float &a, float &b, float &c, int &d, int &e)
+{
+    asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+}
+
+// lanes 0..3 of the quad hold the records of corners 0..3: their addresses (+ this lane's offset) and weights
+__device__ __forceinline__ void quad_corner_records(int addr, float w, int lane_off, int (&A)[4], float (&W)[4])
+{
+    asm volatile("s_nop 1\n"
+                 "v_add_u32_dpp %0, %8, %9 " MSDA_QP(0) "\n v_add_u32_dpp %1, %8, %9 " MSDA_QP(1) "\n"
+                 "v_add_u32_dpp %2, %8, %9 " MSDA_QP(2) "\n v_add_u32_dpp %3, %8, %9 " MSDA_QP(3) "\n"
+                 "v_mov_b32_dpp %4, %10 " MSDA_QP(0) "\n v_mov_b32_dpp %5, %10 " MSDA_QP(1) "\n"
+                 "v_mov_b32_dpp %6, %10 " MSDA_QP(2) "\n v_mov_b32_dpp %7, %10 " MSDA_QP(3)
+                 : "=&v"(A[0]), "=&v"(A[1]), "=&v"(A[2]), "=&v"(A[3]), "=&v"(W[0]), "=&v"(W[1]), "=&v"(W[2]), "=&v"(W[3])
+                 : "v"(addr), "v"(lane_off), "v"(w));
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Per-lane constants of the corner a lane serves inside its quad (corner = lane & 3: bit 0 = x+1, bit 1 = y+1).
+struct RsLane {
+    int vmask, dymask, dx;                  // validity bit of the corner in Wb; (y+1 ? 0xffffff : 0); x+1
+    int off1, delta2;                       // byte offset of the lane's first 16-byte slice inside a pixel row; second = first + delta2
+    float fy0, fys, fx0, fxs;               // corner weight = (fy0 + fys * lh) * (fx0 + fxs * lw)
+};
+
+// What the lane that fetched a point shows to its quad.
+struct RsPoint { float lh, lw, a; int pbase, Wb; };     // Wb = W | validity bits << 24
+
+// levels >= l0 of source frame f (head m) -> LDS slab, 16 bytes per lane by LDS-DMA (8 lanes per pixel)
+template <typename T>
+__device__ __forceinline__ void rs_stage_slab(const Params &p, T *slab, int clip, int m, int f, int px0, int npx,
+                                              int wave, int lane)
+{
+    constexpr int GL = kRsRowB / 16, D = kRsRowB / (int)sizeof(T);
+    constexpr int PXW = kWave / GL;                 // pixels per LDS-DMA wave instruction
+    const T *src = static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head + ((int64_t)f * p.S + px0) * p.v_pix;
+    for (int pb = wave * PXW; pb < npx; pb += kRsWaves * PXW) {
+        const int px = min(pb + lane / GL, npx - 1);
+        const T *gp = src + (int64_t)px * p.v_pix + (lane % GL) * (16 / (int)sizeof(T));
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_global_load_lds(gp, (__attribute__((address_space(3))) void *)(slab + (size_t)pb * D), 16, 0, 0);
+#else
+        (void)gp;
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Point data of THIS lane's own point (x, y, a) at level `lvl` of source frame f: cuh:285-288 (pixel coords,
+// range test), cuh:38-53 (floor, fractions), cuh:56-80 (per-corner validity).  Levels of the slab are addressed
+// by their pixel index inside the slab, the others by their pixel index inside the clip.
+__device__ __forceinline__ RsPoint rs_point(float x, float y, float a, int lvl, int l0, int fS,
+                                            const int *s_H, const int *s_W, const int *s_lsi, const int *s_sst)
+{
+    const int H = s_H[lvl], W = s_W[lvl];
+    const int base = lvl >= l0 ? s_sst[lvl] : fS + s_lsi[lvl];
+    const float h_im = __fsub_rn(__fmul_rn(y, (float)H), 0.5f);
+    const float w_im = __fsub_rn(__fmul_rn(x, (float)W), 0.5f);
+    const bool rng = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;     // false for NaN
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const int yl = rng ? (int)hf : 0, xl = rng ? (int)wf : 0;
+    RsPoint r;
+    r.lh = rng ? h_im - hf : 0.f;
+    r.lw = rng ? w_im - wf : 0.f;
+    r.a = rng ? a : 0.f;
+    const int vy0 = yl >= 0, vy1 = yl + 1 <= H - 1, vx0 = xl >= 0, vx1 = xl + 1 <= W - 1;
+    const int bits = rng ? ((vy0 & vx0) | ((vy0 & vx1) << 1) | ((vy1 & vx0) << 2) | ((vy1 & vx1) << 3)) : 0;
+    r.pbase = base + yl * W + xl;
+    r.Wb = W | (bits << 24);
+    return r;
+}
+
+// The shared front of the resident-slab kernels: LDS carve, level tables, slot masks, tile geometry.
+struct RsShared {
+    int *H, *W, *lsi, *sst;         // level tables (LDS)
+    unsigned *mask;                 // [frames, frames] slot masks (LDS): bit 0 = current-frame points, bit 1 + w = slot w
+    int zero_off;                   // byte offset of the zero row
+    int l0, px0, npx;               // slab = levels [l0, L) = pixels [px0, px0 + npx) of a frame
+};
+
+__device__ __forceinline__ RsShared rs_setup(const Params &p, unsigned char *lds_raw, int slab_bytes, int elem_bytes)
+{
+    RsShared sh;
+    sh.zero_off = slab_bytes;
+    sh.mask = reinterpret_cast<unsigned *>(lds_raw + slab_bytes + kRsRowB);
+    sh.H = reinterpret_cast<int *>(sh.mask + kRsMaxFrames * kRsMaxFrames);
+    sh.W = sh.H + kSlabMaxLevels; sh.lsi = sh.W + kSlabMaxLevels; sh.sst = sh.lsi + kSlabMaxLevels;
+    int *geo = sh.sst + kSlabMaxLevels;
+    const int tid = threadIdx.x, L = p.L;
+    // mask[t * frames + f]: which slots of frame t read frame f -- built once, so that the frame loop does not
+    // chase the frame table through memory (frames <= kRsMaxFrames, window <= 31: host-checked)
+    for (int i = tid; i < p.frames * p.frames; i += kRsThreads) {
+        const int t = i / p.frames, f = i - t * p.frames;
+        unsigned mk = (t == f) ? 1u : 0u;
+        for (int w = 0; w < p.window; ++w) mk |= (p.ftab[t * p.window + w] == f) ? (2u << w) : 0u;
+        sh.mask[i] = mk;
+    }
+    if (tid == 0) {
+        const int l0 = first_slab_level(p, (slab_bytes - kRsSlack) / elem_bytes);
+        const int px0 = l0 < L ? (int)p.lsi[l0] : 0;
+        int npx = 0;
+        for (int l = 0; l < L; ++l) {
+            sh.H[l] = (int)p.shapes[2 * l]; sh.W[l] = (int)p.shapes[2 * l + 1]; sh.lsi[l] = (int)p.lsi[l];
+            sh.sst[l] = (int)p.lsi[l] - px0;
+            if (l >= l0) npx += sh.H[l] * sh.W[l];
+        }
+        geo[0] = l0; geo[1] = px0; geo[2] = npx;
+    }
+    if (tid < kRsRowB / 4) reinterpret_cast<float *>(lds_raw + sh.zero_off)[tid] = 0.f;
+    __syncthreads();
+    sh.l0 = geo[0]; sh.px0 = geo[1]; sh.npx = geo[2];
+    return sh;
+}
+
+template <typename T, int NT>
+__global__ void __launch_bounds__(kRsThreads)
+msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
+{
+    static_assert(sizeof(T) == 4, "resident-slab forward: 4-byte storage types");
+    constexpr int RPW = kRsRows, D = 32;
+    extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];       // (no static LDS: the slab starts at 0)
+    const int tid = threadIdx.x, lane = tid % kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int L = p.L;
+    T *slab = reinterpret_cast<T *>(lds_raw);
+    const RsShared sh = rs_setup(p, lds_raw, slab_bytes, (int)sizeof(T));
+    const int l0 = sh.l0;
+
+    // workgroup -> (clip, head, part of the clip's tiles); wave -> up to NT tiles, 16 apart.  Blocks are dealt
+    // round-robin to the 8 XCDs; each XCD takes a CONTIGUOUS run of (clip, head, part) triples, i.e. whole clips:
+    // the parts of one (clip, head) share their slab and gathers in one L2, and -- unlike a head-per-XCD
+    // mapping -- every XCD touches all heads, so the 1 KiB head pitch of the dense layout does not pin address
+    // bits 7..9 and starve the L2 channels (speed only; results do not depend on placement)
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u;
+    const unsigned lin = xcd * (nwg / 8u) + min(xcd, nwg % 8u) + blockIdx.x / 8u;
+    const int part = (int)(lin % (unsigned)parts), m = (int)((lin / (unsigned)parts) % (unsigned)p.M);
+    const int clip = (int)(lin / ((unsigned)parts * (unsigned)p.M));
+    const int tiles_per_group = (p.Lq + RPW - 1) / RPW, tiles_per_clip = p.frames * tiles_per_group;
+    const int tpw = (tiles_per_clip + parts - 1) / parts;
+    const int tile_lo = part * tpw + wave, tile_hi = min((part + 1) * tpw, tiles_per_clip);
+    const int my_tiles = tile_lo < tile_hi ? (tile_hi - tile_lo + kRsWaves - 1) / kRsWaves : 0;      // <= NT (host)
+    // tile k of this wave -> (frame t, first query q0); the tile loop is a RUNTIME loop (one copy of the body):
+    // the NT accumulator sets are swapped in and out of a working set through uniform branches
+    auto tile_of = [&](int k, int &t, int &q0) {
+        const int ct = tile_lo + k * kRsWaves;
+        t = ct / tiles_per_group;
+        q0 = (ct - t * tiles_per_group) * RPW;
+    };
+
+    const int j = lane / 4, cor = lane & 3, hsw = j & 1;
+    RsLane ln;
+    ln.vmask = 1 << (24 + cor); ln.dymask = (cor & 2) ? 0xffffff : 0; ln.dx = cor & 1;
+    ln.off1 = cor * 16 + hsw * 64; ln.delta2 = hsw ? -64 : 64;
+    ln.fy0 = (cor & 2) ? 0.f : 1.f; ln.fys = (cor & 2) ? 1.f : -1.f;
+    ln.fx0 = (cor & 1) ? 0.f : 1.f; ln.fxs = (cor & 1) ? 1.f : -1.f;
+    const int pixB = p.v_pix * (int)sizeof(T);
+    // buffer resource over value[clip, :, m, :] (stride 0 = raw, num_records in bytes): out-of-range -> 0
+    const char *vbase = reinterpret_cast<const char *>(static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head);
+    const unsigned vbytes = (unsigned)(((int64_t)p.frames * p.S - 1) * pixB + kRsRowB);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(vbase), 0, (int)vbytes, 0x00020000);
+#endif
+
+    float acc[NT][8];
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[k][c] = 0.f;
+
+    for (int f = 0; f < p.frames; ++f) {
+        __syncthreads();                                   // every wave is done with the previous slab
+        if (l0 < L) rs_stage_slab<T>(p, slab, clip, m, f, sh.px0, sh.npx, wave, lane);
+        __syncthreads();
+        const int fS = f * p.S;
+#pragma unroll 1
+        for (int k = 0; k < my_tiles; ++k) {
+            int t, q0;
+            tile_of(k, t, q0);
+            unsigned todo = __builtin_amdgcn_readfirstlane(sh.mask[t * p.frames + f]);
+            if (!todo) continue;
+            const bool live = j < min(RPW, p.Lq - q0);
+            const int64_t row = (((int64_t)clip * p.frames + t) * p.Lq + q0 + j) * p.M + m;
+            float wacc[8];                                     // working accumulators = set k
+            static_for<NT>([&](auto Kc) {
+                constexpr int K = decltype(Kc)::value;
+                if (k == K) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) wacc[c] = acc[K][c];
+                }
+            });
+#pragma unroll 1
+            while (todo) {                                     // sl = -1: the tile's current-frame points
+                const int sl = (int)__builtin_ctz(todo) - 1;
+                todo &= todo - 1;
+                const T *loc = static_cast<const T *>(sl < 0 ? p.locA : p.locB);
+                const T *aw = static_cast<const T *>(sl < 0 ? p.awA : p.awB);
+                const int P = sl < 0 ? p.PA : p.PB;
+                const int LP = (sl < 0 ? p.LA : p.LB) * P;
+                const int npts = (sl < 0 ? p.LA : L) * P;
+                const int64_t idx0 = row * LP + (sl < 0 ? 0 : sl * L * P);
+                const unsigned invP = (65536u + (unsigned)P - 1u) / (unsigned)P;      // kk / P for kk * P < 2^16
+                const int first_slab_pt = l0 * P;              // points of levels >= l0 read the slab
+#pragma unroll 1
+                for (int g0 = 0; g0 < npts; g0 += 4) {
+                    const int kk = g0 + cor;
+                    float x = -10.f, y = -10.f, a = 0.f;       // far outside every map
+                    if (live && kk < npts) {
+                        const float2 xy = *reinterpret_cast<const float2 *>(loc + 2 * (idx0 + kk));
+                        x = xy.x; y = xy.y;
+                        a = aw[idx0 + kk];
+                    }
+                    const int lvl = min((int)(((unsigned)kk * invP) >> 16), L - 1);
+                    RsPoint pt = rs_point(x, y, a, lvl, l0, fS, sh.H, sh.W, sh.lsi, sh.sst);
+                    dpp_fence(pt.lh, pt.lw, pt.a, pt.pbase, pt.Wb);
+                    // one step = one point of the 16 rows: this lane's corner record, then the four corners
+                    auto step = [&](auto Rc, auto Sc) {
+                        constexpr int R = decltype(Rc)::value;
+                        constexpr bool SLAB = decltype(Sc)::value;
+                        const int vb = quad_and<R>(pt.Wb, ln.vmask);
+                        const int tw = quad_and<R>(pt.Wb, ln.dymask);
+                        const int pix = quad_add<R>(pt.pbase, ln.dx) + tw;
+                        int addr = SLAB ? (pix << 7) : (int)((unsigned)pix * (unsigned)pixB);
+                        addr = vb ? addr : (SLAB ? sh.zero_off : (int)0x80000000u);
+                        float wy = ln.fy0, wx = ln.fx0;
+                        quad_fmac<R>(wy, pt.lh, ln.fys);
+                        quad_fmac<R>(wx, pt.lw, ln.fxs);
+                        const float w = quad_mul<R>(pt.a, wy * wx);
+                        int A[4];
+                        float W[4];
+                        quad_corner_records(addr, w, ln.off1, A, W);
+                        float v1[4][4], v2[4][4];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            if constexpr (SLAB) {
+                                const float4 q1 = *reinterpret_cast<const float4 *>(lds_raw + A[s]);
+                                const float4 q2 = *reinterpret_cast<const float4 *>(lds_raw + (A[s] ^ 64));
+                                v1[s][0] = q1.x; v1[s][1] = q1.y; v1[s][2] = q1.z; v1[s][3] = q1.w;
+                                v2[s][0] = q2.x; v2[s][1] = q2.y; v2[s][2] = q2.z; v2[s][3] = q2.w;
+                            } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+                                const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, A[s], 0, 0);
+                                const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, A[s] + ln.delta2, 0, 0);
+                                v1[s][0] = __uint_as_float(q1.x); v1[s][1] = __uint_as_float(q1.y);
+                                v1[s][2] = __uint_as_float(q1.z); v1[s][3] = __uint_as_float(q1.w);
+                                v2[s][0] = __uint_as_float(q2.x); v2[s][1] = __uint_as_float(q2.y);
+                                v2[s][2] = __uint_as_float(q2.z); v2[s][3] = __uint_as_float(q2.w);
+#endif
+                            }
+                        }
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                wacc[c] = fmaf(W[s], v1[s][c], wacc[c]);
+                                wacc[4 + c] = fmaf(W[s], v2[s][c], wacc[4 + c]);
+                            }
+                    };
+                    if (g0 >= first_slab_pt) {                 // the whole group reads the slab (uniform)
+                        static_for<4>([&](auto Rc) { if (g0 + decltype(Rc)::value < npts) step(Rc, std::true_type{}); });
+                    } else if (g0 + 3 < first_slab_pt) {       // the whole group reads memory
+                        static_for<4>([&](auto Rc) { if (g0 + decltype(Rc)::value < npts) step(Rc, std::false_type{}); });
+                    } else {
+                        static_for<4>([&](auto Rc) {
+                            constexpr int R = decltype(Rc)::value;
+                            if (g0 + R >= npts) return;
+                            if (g0 + R >= first_slab_pt) step(Rc, std::true_type{}); else step(Rc, std::false_type{});
+                        });
+                    }
+                }
+            }
+            static_for<NT>([&](auto Kc) {
+                constexpr int K = decltype(Kc)::value;
+                if (k == K) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[K][c] = wacc[c];
+                }
+            });
+        }
+    }
+    static_for<NT>([&](auto Kc) {
+        constexpr int K = decltype(Kc)::value;
+        if (K >= my_tiles) return;
+        int t, q0;
+        tile_of(K, t, q0);
+        if (j < min(RPW, p.Lq - q0)) {
+            const int64_t row = (((int64_t)clip * p.frames + t) * p.Lq + q0 + j) * p.M + m;
+            T *o = static_cast<T *>(p.out) + row * D;
+            const float a1[4] = {acc[K][0], acc[K][1], acc[K][2], acc[K][3]}, a2[4] = {acc[K][4], acc[K][5], acc[K][6], acc[K][7]};
+            Store<T>::store(o + ln.off1 / 4, a1);
+            Store<T>::store(o + (ln.off1 + ln.delta2) / 4, a2);
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
 // generic kernels: any D / M / L / P, any dtype (fp64 included).  Correctness path for shapes the
 // tile kernels do not take (D not a power-of-two multiple of the 16-B lane vector, fp64 gradcheck).
 // ------------------------------------------------------------------------------------------------
@@ -2482,6 +2839,36 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     // the slab kernels run 4 channels per lane for every dtype (SlabStore): twice the lanes per row for 16-bit types
     constexpr int GSL = SlabStore<T>::VEC == Store<T>::VEC ? G : 2 * G;
     constexpr int RPWS = kWave / (GSL <= kWave ? GSL : kWave);
+    if constexpr (sizeof(T) == 4 && G == 8) if (!bwd && p.LA == p.L && p.L <= kSlabMaxLevels) {
+        // resident-slab forward (D = 32, 4-byte types): up to NT * 16 tiles of 16 rows per workgroup, so that the
+        // per-frame slab staging is amortised
+        const int mode = env_int("MSDA_FWD_RS", 0);                    // -1 auto, 0 off (default while it is tuned), 1 force
+        const int tiles_per_clip = p.frames * ((p.Lq + kRsRows - 1) / kRsRows);
+        const int64_t clips = p.groups / p.frames;
+        const int64_t pixB = (int64_t)p.v_pix * (int64_t)sizeof(T);
+        const bool fits = (int64_t)p.frames * p.S < (1 << 24) && pixB < (1 << 24) &&
+                          (int64_t)p.frames * p.S * pixB < 0x7fffffffLL && p.frames <= kRsMaxFrames && p.window <= 31;
+        int nt = 0, parts = 0;
+        for (int cand : {4, 2}) {
+            const int c = (tiles_per_clip + kRsWaves * cand - 1) / (kRsWaves * cand);
+            if (mode == 1 || clips * p.M * c >= device_cus()) { nt = cand; parts = c; break; }
+        }
+        const int force_nt = env_int("MSDA_FWD_RS_NT", 0);
+        if (force_nt == 2 || force_nt == 4) { nt = force_nt; parts = (tiles_per_clip + kRsWaves * nt - 1) / (kRsWaves * nt); }
+        if (mode != 0 && fits && nt && clips * p.M * parts <= 0x7fffffffLL) {
+            const int slab_bytes = ((160 * 1024 - 256 - kRsTailBytes) / 128) * 128;
+            const size_t total = (size_t)slab_bytes + kRsTailBytes;
+            const unsigned grid = (unsigned)(clips * p.M * parts);
+            auto launch = [&](auto kern) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)total) != hipSuccess)
+                    return fail(MSDA_ERR_HIP, "msda forward: cannot reserve the LDS budget of the resident-slab kernel%s");
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(kRsThreads), total, stream, p, slab_bytes, parts);
+                return check_launch("msda forward (resident-slab kernel)");
+            };
+            return nt == 4 ? launch(&msda_fwd_rs_kernel<T, 4>) : launch(&msda_fwd_rs_kernel<T, 2>);
+        }
+    }
     if constexpr (GSL >= 4 && GSL <= kWave) if (!bwd && p.LA == p.L && p.L <= kSlabMaxLevels) {   // (1- and 2-lane rows spill)
         // slab forward: 16 waves per workgroup share the small levels in LDS; needs enough workgroups.
         // Picked automatically for 4-byte types only: for the 16-bit types the 16-byte-lane tile kernel (half

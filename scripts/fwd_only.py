@@ -9,6 +9,9 @@ dt = bench.DTYPES[os.environ.get("DT","f32")]
 dev = torch.device("cuda:0")
 b = bench.make_clip_batch(a, dev, dt, 1)
 T,q,M,D,L,P,W,S = b["dims"]
+if os.environ.get("LAYOUT") == "padded":
+    buf = torch.zeros((b["value"].shape[0], S, M + 1, D), dtype=dt, device=dev)
+    buf[:, :, :M] = b["value"]; b["value"] = buf[:, :, :M]
 out = torch.empty((a.clips*T, q, M*D), dtype=dt, device=dev)
 for _ in range(3):
     _native.temporal_forward(b["value"], b["shapes"], b["lsi"], b["ftab"], b["loc_c"], b["aw_c"], b["loc_t"], b["aw_t"], a.clips, out)
