@@ -286,11 +286,18 @@ def main():
             _native.temporal_backward(
                 dv[0], b["shapes"], b["lsi"], b["ftab"], dv[1], dv[2], dv[3], dv[4], b["grad_out"], args.clips,
                 gv, gl_c, ga_c, gl_t, ga_t, workspace=ws)
+        # (a measurement hook: honoured only with MSDA_ENABLE_HOOKS=1 and re-read on request; it is switched on
+        # here, AFTER the timed region, and off again below)
+        os.environ["MSDA_ENABLE_HOOKS"] = "1"
         os.environ["MSDA_BWD_PHASES"] = "1"
+        _native.reload_knobs()
         gat_ms, gat_med = time_kernel(bwd, 20)
         os.environ["MSDA_BWD_PHASES"] = "2"
+        _native.reload_knobs()
         sca_ms, sca_med = time_kernel(bwd, 20)
         os.environ.pop("MSDA_BWD_PHASES")
+        os.environ.pop("MSDA_ENABLE_HOOKS")
+        _native.reload_knobs()
         e = b["value"].element_size()
         ab = algorithmic_bytes(args, e)
         # the library runs the slab forward when there are >= 2 workgroups of 16 tiles per CU, else the tile forward

@@ -11,7 +11,7 @@ import torch
 
 from . import build as _build
 
-MSDA_ABI_VERSION = 7
+MSDA_ABI_VERSION = 8
 BWD_WORKSPACE_BYTES = 64
 _DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.float16: 3}
 
@@ -19,7 +19,7 @@ _DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.floa
 EXPORTED_SYMBOLS = (
     "msda_version", "msda_last_error", "msda_forward", "msda_backward",
     "msda_temporal_forward", "msda_temporal_backward", "msda_backward_workspace_bytes",
-    "msda_prep_forward", "msda_prep_backward",
+    "msda_prep_forward", "msda_prep_backward", "msda_reload_knobs",
 )
 
 _lib = None
@@ -36,7 +36,7 @@ def load():
         if _lib is not None:
             return _lib
         path = _build.lib_path()
-        if not os.path.exists(path):
+        if not os.path.exists(path) or (_build.is_stale() and _build.have_compiler()):     # an edited .hip is never silently ignored
             try:
                 _build.build()
             except Exception as e:  # no hipcc on this box and no prebuilt library
@@ -53,21 +53,28 @@ def load():
             raise RuntimeError("devis_amd: ABI version mismatch (library %d, binding %d); rebuild with "
                                "python -m devis_amd.build --force" % (lib.msda_version(), MSDA_ABI_VERSION))
         lib.msda_forward.restype = _ci
-        lib.msda_forward.argtypes = [_ci] + [_vp] * 5 + [_ci] * 7 + [_vp, _vp, _vp]
+        lib.msda_forward.argtypes = [_ci] + [_vp] * 5 + [_ci] * 7 + [_vp, _vp, _vp, _vp]
         lib.msda_backward.restype = _ci
-        lib.msda_backward.argtypes = [_ci] + [_vp] * 6 + [_ci] * 7 + [_vp] * 4 + [ctypes.c_longlong, _vp, _vp]
+        lib.msda_backward.argtypes = [_ci] + [_vp] * 6 + [_ci] * 7 + [_vp] * 4 + [ctypes.c_longlong, _vp, _vp, _vp]
         lib.msda_backward_workspace_bytes.restype = ctypes.c_longlong
         lib.msda_backward_workspace_bytes.argtypes = [_ci] * 4
         lib.msda_temporal_forward.restype = _ci
-        lib.msda_temporal_forward.argtypes = [_ci] + [_vp] * 8 + [_ci] * 10 + [_vp, _vp, _vp]
+        lib.msda_temporal_forward.argtypes = [_ci] + [_vp] * 8 + [_ci] * 10 + [_vp, _vp, _vp, _vp]
         lib.msda_temporal_backward.restype = _ci
-        lib.msda_temporal_backward.argtypes = [_ci] + [_vp] * 9 + [_ci] * 10 + [_vp] * 6 + [ctypes.c_longlong, _vp, _vp]
+        lib.msda_temporal_backward.argtypes = [_ci] + [_vp] * 9 + [_ci] * 10 + [_vp] * 6 + [ctypes.c_longlong, _vp, _vp, _vp]
         lib.msda_prep_forward.restype = _ci
         lib.msda_prep_forward.argtypes = [_ci] + [_vp] * 7 + [ctypes.c_longlong] + [_ci] * 6 + [ctypes.c_longlong] + [_vp] * 5
+        lib.msda_reload_knobs.restype = None
+        lib.msda_reload_knobs.argtypes = []
         lib.msda_prep_backward.restype = _ci
         lib.msda_prep_backward.argtypes = [_ci] + [_vp] * 9 + [ctypes.c_longlong] + [_ci] * 6 + [ctypes.c_longlong] + [_vp] * 5
         _lib = lib
     return _lib
+
+
+def reload_knobs():
+    """Re-read the MSDA_* test / measurement knobs (honoured only with MSDA_ENABLE_HOOKS=1; include/msda.h)."""
+    load().msda_reload_knobs()
 
 
 def dtype_code(dtype):
@@ -117,12 +124,31 @@ def head_major(value):
     return value.permute(2, 0, 1, 3).contiguous().permute(1, 2, 0, 3)
 
 
+_shape_hints = {}       # (data_ptr, _version, device) -> (tensor kept alive, ctypes int64 array): host copies of spatial_shapes
+
+
+def shapes_hint(shapes):
+    """include/msda.h `spatial_shapes_host`: a host copy of the device tensor `spatial_shapes`, for kernel selection
+    only.  Cached per tensor (the transformer hands the same tensor to every layer of every
+    step), so the device-to-host copy -- the only synchronisation -- happens once per distinct tensor."""
+    key = (shapes.data_ptr(), shapes._version, shapes.device)
+    hit = _shape_hints.get(key)
+    if hit is not None and hit[0] is shapes:
+        return hit[1]
+    host = shapes.detach().to("cpu", torch.int64).reshape(-1).tolist()
+    arr = (ctypes.c_int64 * len(host))(*host)
+    if len(_shape_hints) > 64:
+        _shape_hints.clear()
+    _shape_hints[key] = (shapes, arr)
+    return arr
+
+
 def forward(value, shapes, lsi, loc, aw, out):
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = loc.shape
     with torch.cuda.device(value.device):
         rc = load().msda_forward(dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(aw),
-                                 N, S, M, D, L, Lq, P, _p(out), value_strides(value), _stream(value))
+                                 N, S, M, D, L, Lq, P, _p(out), value_strides(value), shapes_hint(shapes), _stream(value))
     _check(rc, "msda_forward")
 
 
@@ -143,7 +169,7 @@ def backward(value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_a
         rc = load().msda_backward(dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(aw),
                                   _p(grad_out), N, S, M, D, L, Lq, P,
                                   _p(grad_value), _p(grad_loc), _p(grad_aw), _p(ws), ws.numel() * 4,
-                                  value_strides(value), _stream(value))
+                                  value_strides(value), shapes_hint(shapes), _stream(value))
     _check(rc, "msda_backward")
 
 
@@ -157,7 +183,7 @@ def temporal_forward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, clips, 
         rc = load().msda_temporal_forward(
             dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(ftab), _p(loc_c), _p(aw_c),
             _p(loc_t), _p(aw_t), clips, frames, window, S, M, D, L, Lq, Pc, Pt, _p(out),
-            value_strides(value, frames), _stream(value))
+            value_strides(value, frames), shapes_hint(shapes), _stream(value))
     _check(rc, "msda_temporal_forward")
 
 
@@ -174,7 +200,7 @@ def temporal_backward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, grad_o
             dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(ftab), _p(loc_c), _p(aw_c),
             _p(loc_t), _p(aw_t), _p(grad_out), clips, frames, window, S, M, D, L, Lq, Pc, Pt,
             _p(grad_value), _p(gloc_c), _p(gaw_c), _p(gloc_t), _p(gaw_t), _p(ws), ws.numel() * 4,
-            value_strides(value, frames), _stream(value))
+            value_strides(value, frames), shapes_hint(shapes), _stream(value))
     _check(rc, "msda_temporal_backward")
 
 

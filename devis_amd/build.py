@@ -5,6 +5,7 @@ sits IN-TREE next to this file (git-ignored, but shipped to the GPU box with the
 
     python -m devis_amd.build [--force]
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -15,6 +16,7 @@ ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "msda_hip.hip")
 INC = os.path.join(ROOT, "include")
 LIB = os.path.join(HERE, "libmsda_hip.so")
+HASH = os.path.join(HERE, "libmsda_hip.srchash")
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -29,11 +31,27 @@ def lib_path():
     return LIB
 
 
+def _source_hash():
+    h = hashlib.sha256()
+    for path in (SRC, os.path.join(INC, "msda.h")):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
 def is_stale():
-    if not os.path.exists(LIB):
+    """True when the library is missing or was built from other sources / flags than the ones in the tree.
+    Compared by content hash (a sidecar file written at build time), not by mtime: the repository snapshot that
+    travels to the GPU box does not promise to keep timestamps."""
+    if not os.path.exists(LIB) or not os.path.exists(HASH):
         return True
-    deps = [SRC, os.path.join(INC, "msda.h"), os.path.abspath(__file__)]
-    return os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps if os.path.exists(d))
+    with open(HASH) as f:
+        return f.read().strip() != _source_hash()
+
+
+def have_compiler():
+    return bool(shutil.which("hipcc")) or os.path.exists("/opt/rocm/bin/hipcc")
 
 
 def build(force=False, verbose=False):
@@ -49,6 +67,8 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(tmp, LIB)
+    with open(HASH, "w") as f:
+        f.write(_source_hash() + "\n")
     return LIB
 
 

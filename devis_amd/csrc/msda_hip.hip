@@ -214,6 +214,7 @@ struct Params {
     int v_pix;                  // ... and between consecutive pixels (standard [S, M, D]: frames*S*M*D, D, M*D)
     int *bsum;                  // bwd: [groups, M, LA+LB, ceil(Lq/64), 2] (min, max) top tap row over blocks of 64 queries
                                 // (built from the per-point records; lets long candidate ranges skip dead blocks) or null
+    const int64_t *shapes_host; // HOST copy of `shapes` or null: kernel selection only (never dereferenced on the device)
     int cull_points;            // bbox entries are 4 x int16 top tap rows, one per POINT (PA, PB <= 4), not (min, max)
     int dbg;                    // measurement hooks (MSDA_DBG env), 0 in production
 };
@@ -2791,23 +2792,112 @@ size_t tile_lds_bytes(int rpw, int nvl, bool bwd, bool intervals = false)
            (intervals ? (size_t)rpw * nvl * 8 : 0);     // + the per-(row, level) tap-row intervals
 }
 
+// ---- test / measurement knobs -------------------------------------------------------------------------------
+// All of them are environment variables that are read ONCE (first call into the library, or msda_reload_knobs())
+// and only when MSDA_ENABLE_HOOKS=1: a production process cannot have its results or speed changed by a stray
+// variable, and the launch path does not call getenv.  tests/ and bench.py set MSDA_ENABLE_HOOKS=1 and call
+// msda_reload_knobs() after changing a knob.
+struct Knobs {
+    int fwd_rs = -1, fwd_rs_nt = 0;     // resident-slab forward: -1 auto, 0 off, 1 force; tiles per wave (0 = auto)
+    int fwd_slab = -1, bwd_slab = -1;   // slab kernels: -1 auto, 0 off, 1 force
+    int fwd_nb = 4;                     // tile forward: points in flight
+    int bwd_atomic = 0;                 // MSDA_BWD_MODE=atomic: one-kernel backward with global atomics
+    int bwd_phases = 3;                 // 1 = gather pass only, 2 = scatter pass only, 3 = both
+    int bwd_cull = 1;                   // 0: no culling structure, 2: (min, max) intervals instead of per-point records
+    int bwd_summary = 1;                // 64-query block summaries for long candidate ranges
+    int scatter_lds_kb = 144, scatter_wg_per_cu = 1, scatter_dbg = 0;
+    int force_generic = 0;
+    int dbg = 0;
+};
+Knobs g_knobs;
+int g_knobs_loaded = 0;
+
 int env_int(const char *name, int dflt)
 {
     const char *e = getenv(name);
     return (e && e[0]) ? atoi(e) : dflt;
 }
 
+void load_knobs()
+{
+    Knobs k;
+    if (env_int("MSDA_ENABLE_HOOKS", 0) == 1) {
+        k.fwd_rs = env_int("MSDA_FWD_RS", k.fwd_rs); k.fwd_rs_nt = env_int("MSDA_FWD_RS_NT", k.fwd_rs_nt);
+        k.fwd_slab = env_int("MSDA_FWD_SLAB", k.fwd_slab); k.bwd_slab = env_int("MSDA_BWD_SLAB", k.bwd_slab);
+        k.fwd_nb = env_int("MSDA_FWD_NB", k.fwd_nb);
+        const char *mode = getenv("MSDA_BWD_MODE");
+        k.bwd_atomic = (mode && !strcmp(mode, "atomic")) ? 1 : 0;
+        k.bwd_phases = env_int("MSDA_BWD_PHASES", k.bwd_phases);
+        k.bwd_cull = env_int("MSDA_BWD_CULL", k.bwd_cull);
+        k.bwd_summary = env_int("MSDA_BWD_SUMMARY", k.bwd_summary);
+        k.scatter_lds_kb = env_int("MSDA_SCATTER_LDS_KB", k.scatter_lds_kb);
+        k.scatter_wg_per_cu = env_int("MSDA_SCATTER_WG_PER_CU", k.scatter_wg_per_cu);
+        k.scatter_dbg = env_int("MSDA_SCATTER_DBG", k.scatter_dbg);
+        k.force_generic = env_int("MSDA_FORCE_GENERIC", 0) == 1;
+        k.dbg = env_int("MSDA_DBG", 0);
+    }
+    g_knobs = k;
+    __atomic_store_n(&g_knobs_loaded, 1, __ATOMIC_RELEASE);
+}
+
+inline const Knobs &knobs()
+{
+    if (!__atomic_load_n(&g_knobs_loaded, __ATOMIC_ACQUIRE)) load_knobs();      // benign race: every thread reads the same environment
+    return g_knobs;
+}
+
+// ---- per-device caches --------------------------------------------------------------------------------------
+constexpr int kMaxDevices = 64;
+
+int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    return dev;
+}
+
 int device_cus()
 {
-    static int cus = 0;     // benign race: every thread computes the same value
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        cus = n;
+    static int cus[kMaxDevices];        // 0 = not asked yet; benign race: every thread computes the same value
+    const int dev = current_device();
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
     }
-    return cus;
+    return cus[dev];
+}
+
+// Dynamic LDS above 64 KiB must be opted into per kernel function AND per device; `granted` is the caller's
+// per-instantiation table of what each device has been given so far.
+struct LdsGrant { size_t bytes[kMaxDevices]; };
+int grant_lds(const void *kernel, size_t bytes, LdsGrant &granted, const char *what)
+{
+    const int dev = current_device();
+    if (bytes <= granted.bytes[dev]) return MSDA_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return fail(MSDA_ERR_HIP, "msda: cannot reserve the LDS budget of %s", what);
+    granted.bytes[dev] = bytes;
+    return MSDA_OK;
+}
+
+// How many of the LAST pyramid levels fit `cap_pixels` pixels of LDS slab (the device-side rule of first_slab_level,
+// evaluated on the host copy of spatial_shapes when the caller passed one; otherwise guessed from the pixel count:
+// with the usual stride-2 pyramids level 0 holds ~3/4 of the S pixels).  Returns the first slab level l0.
+int host_first_slab_level(const Params &p, long long cap_pixels)
+{
+    if (p.shapes_host) {
+        int l0 = p.L;
+        long long acc = 0;
+        for (int l = p.L - 1; l >= 0; --l) {
+            acc += (long long)p.shapes_host[2 * l] * p.shapes_host[2 * l + 1];
+            if (acc > cap_pixels) break;
+            l0 = l;
+        }
+        return l0;
+    }
+    if (p.L == 1) return (long long)p.S <= cap_pixels ? 0 : 1;
+    return (long long)p.S <= cap_pixels ? 0 : ((double)p.S * 0.2551 <= (double)cap_pixels ? 1 : 2);
 }
 
 // Can grad_value go through the LDS scatter kernel?  MSDA_BWD_MODE=atomic forces the one-kernel
@@ -2819,8 +2909,7 @@ bool standard_value_layout(const Params &p)
 
 bool scatter_applicable(const Params &p)
 {
-    const char *mode = getenv("MSDA_BWD_MODE");
-    if (mode && !strcmp(mode, "atomic")) return false;
+    if (knobs().bwd_atomic) return false;
     if (p.L > kScatterMaxLevels || (p.D % 4) != 0) return false;
     if (1 + p.frames * p.window > kScatterMaxSources || p.Lq >= (1 << 24)) return false;   // survivor-list entry fields
     if (p.window == 0 && p.LA != p.L) return false;
@@ -2842,31 +2931,40 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     if constexpr (sizeof(T) == 4 && G == 8) if (!bwd && p.LA == p.L && p.L <= kSlabMaxLevels) {
         // resident-slab forward (D = 32, 4-byte types): up to NT * 16 tiles of 16 rows per workgroup, so that the
         // per-frame slab staging is amortised
-        const int mode = env_int("MSDA_FWD_RS", 0);                    // -1 auto, 0 off (default while it is tuned), 1 force
+        const int mode = knobs().fwd_rs;                               // -1 auto, 0 off, 1 force
         const int tiles_per_clip = p.frames * ((p.Lq + kRsRows - 1) / kRsRows);
         const int64_t clips = p.groups / p.frames;
         const int64_t pixB = (int64_t)p.v_pix * (int64_t)sizeof(T);
-        const bool fits = (int64_t)p.frames * p.S < (1 << 24) && pixB < (1 << 24) &&
+        const bool fits = (int64_t)p.frames * p.S < (1 << 24) && pixB < (1 << 24) && p.D == 32 &&
                           (int64_t)p.frames * p.S * pixB < 0x7fffffffLL && p.frames <= kRsMaxFrames && p.window <= 31;
+        // Tiles per wave (NT) and workgroups per (clip, head) (parts).  Measured (16 clips of the DeVIS decoder
+        // shape): the kernel is bound by the L2 misses of the level-0 gathers -- every workgroup of a (clip,
+        // head) pair gathers from the same 460 KiB map, and an XCD's 4 MiB L2 holds the maps of ~8 pairs -- so
+        // MORE, smaller workgroups per pair (parts = 4: 8 pairs in flight per XCD) beat fewer, larger ones
+        // (parts = 2: 16 pairs, 0.55 vs 0.47 ms) although each stages its own copy of the slab.  NT = 1 only
+        // when that is what it takes to fill the chip.
         int nt = 0, parts = 0;
-        for (int cand : {4, 2}) {
+        for (int cand : {2, 1}) {
             const int c = (tiles_per_clip + kRsWaves * cand - 1) / (kRsWaves * cand);
             if (mode == 1 || clips * p.M * c >= device_cus()) { nt = cand; parts = c; break; }
         }
-        const int force_nt = env_int("MSDA_FWD_RS_NT", 0);
-        if (force_nt == 2 || force_nt == 4) { nt = force_nt; parts = (tiles_per_clip + kRsWaves * nt - 1) / (kRsWaves * nt); }
+        // the slab must be worth staging: every level but the first has to fit (75 % of the taps of a DeVIS call)
+        const int slab_bytes = ((160 * 1024 - 256 - kRsTailBytes) / 128) * 128;
+        if (mode != 1 && host_first_slab_level(p, (slab_bytes - kRsSlack) / kRsRowB) > 1) nt = 0;
+        const int force_nt = knobs().fwd_rs_nt;
+        if (force_nt == 1 || force_nt == 2 || force_nt == 4) { nt = force_nt; parts = (tiles_per_clip + kRsWaves * nt - 1) / (kRsWaves * nt); }
         if (mode != 0 && fits && nt && clips * p.M * parts <= 0x7fffffffLL) {
-            const int slab_bytes = ((160 * 1024 - 256 - kRsTailBytes) / 128) * 128;
             const size_t total = (size_t)slab_bytes + kRsTailBytes;
             const unsigned grid = (unsigned)(clips * p.M * parts);
-            auto launch = [&](auto kern) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)total) != hipSuccess)
-                    return fail(MSDA_ERR_HIP, "msda forward: cannot reserve the LDS budget of the resident-slab kernel%s");
+            auto launch = [&](auto kern, LdsGrant &granted) {
+                const int rc = grant_lds(reinterpret_cast<const void *>(kern), total, granted, "the resident-slab forward kernel");
+                if (rc) return rc;
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(kRsThreads), total, stream, p, slab_bytes, parts);
                 return check_launch("msda forward (resident-slab kernel)");
             };
-            return nt == 4 ? launch(&msda_fwd_rs_kernel<T, 4>) : launch(&msda_fwd_rs_kernel<T, 2>);
+            static LdsGrant g4, g2, g1;
+            return nt == 4 ? launch(&msda_fwd_rs_kernel<T, 4>, g4) : nt == 2 ? launch(&msda_fwd_rs_kernel<T, 2>, g2)
+                                                                              : launch(&msda_fwd_rs_kernel<T, 1>, g1);
         }
     }
     if constexpr (GSL >= 4 && GSL <= kWave) if (!bwd && p.LA == p.L && p.L <= kSlabMaxLevels) {   // (1- and 2-lane rows spill)
@@ -2877,26 +2975,22 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
         const int tiles_per_clip = p.frames * ((p.Lq + RPWS - 1) / RPWS);
         const int blocks_per_clip = (tiles_per_clip + kSlabWaves - 1) / kSlabWaves;
         const int64_t slab_blocks = (int64_t)(p.groups / p.frames) * blocks_per_clip * p.M;
-        const int mode = env_int("MSDA_FWD_SLAB", -1);                 // -1 auto, 0 off, 1 force
+        const int mode = knobs().fwd_slab;                             // -1 auto, 0 off, 1 force
         const size_t per_wave = (size_t)RPWS * kRowSlots * 32 + (size_t)(p.LA + p.LB) * sizeof(Level);
         const long long slab_bytes = ((160 * 1024 - 1024 - (long long)kSlabWaves * (long long)per_wave) / 1024) * 1024;
         if (mode != 0 && slab_bytes >= 16 * 1024 && (mode == 1 || (slab_blocks >= 2 * device_cus() && sizeof(T) == 4)) &&
             slab_blocks <= 0x7fffffffLL) {
             const size_t total = (size_t)slab_bytes + kSlabWaves * per_wave;
-            static size_t limit_set = 0;
-            if (total > limit_set) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_slab_kernel<T, GSL, 4>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)total) != hipSuccess)
-                    return fail(MSDA_ERR_HIP, "msda forward: cannot reserve the LDS budget of the slab kernel%s");
-                limit_set = total;
-            }
+            static LdsGrant granted;
+            if (const int rc = grant_lds(reinterpret_cast<const void *>(&msda_fwd_slab_kernel<T, GSL, 4>), total, granted,
+                                         "the slab forward kernel")) return rc;
             hipLaunchKernelGGL((msda_fwd_slab_kernel<T, GSL, 4>), dim3((unsigned)slab_blocks), dim3(kSlabThreads),
                                total, stream, p, (int)(slab_bytes / (long long)sizeof(T)));
             return check_launch("msda forward (slab kernel)");
         }
     }
     if (!bwd) {
-        const int nb = env_int("MSDA_FWD_NB", 4);
+        const int nb = knobs().fwd_nb;
         if (nb == 1)
             hipLaunchKernelGGL((msda_fwd_tile_kernel<T, G, 1>), dim3((unsigned)blocks), dim3(kWave), lds, stream, p);
         else if (nb == 2)
@@ -2913,7 +3007,7 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     }
     // MSDA_BWD_PHASES (measurement hook for bench.py): 1 = gather pass only, 2 = scatter pass only
     // (needs the workspace a previous gather pass filled), 3 = both (default)
-    const int phases = env_int("MSDA_BWD_PHASES", 3);
+    const int phases = knobs().bwd_phases;
     int rc = MSDA_OK;
     if (phases & 1) {
         bool done = false;
@@ -2921,7 +3015,7 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
             const int tiles_per_clip = p.frames * ((p.Lq + RPWS - 1) / RPWS);
             const int blocks_per_clip = (tiles_per_clip + kSlabWaves - 1) / kSlabWaves;
             const int64_t slab_blocks = (int64_t)(p.groups / p.frames) * blocks_per_clip * p.M;
-            const int mode = env_int("MSDA_BWD_SLAB", -1);              // -1 auto, 0 off, 1 force
+            const int mode = knobs().bwd_slab;                          // -1 auto, 0 off, 1 force
             const size_t per_wave = (size_t)RPWS * kRowSlots * 48 + (size_t)(p.LA + p.LB) * sizeof(Level) +
                                     (p.bbox ? (size_t)RPWS * p.L * 8 : 0);
             const long long slab_bytes =
@@ -2929,13 +3023,9 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
             if (mode != 0 && slab_bytes >= 16 * 1024 && (mode == 1 || slab_blocks >= 2 * device_cus()) &&
                 slab_blocks <= 0x7fffffffLL) {
                 const size_t total = (size_t)slab_bytes + kSlabWaves * per_wave;
-                static size_t limit_set = 0;
-                if (total > limit_set) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_slab_kernel<T, GSL>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)total) != hipSuccess)
-                        return fail(MSDA_ERR_HIP, "msda backward: cannot reserve the LDS budget of the slab kernel%s");
-                    limit_set = total;
-                }
+                static LdsGrant granted;
+                if (const int grc = grant_lds(reinterpret_cast<const void *>(&msda_bwd_slab_kernel<T, GSL>), total, granted,
+                                              "the slab gather-pass kernel")) return grc;
                 hipLaunchKernelGGL((msda_bwd_slab_kernel<T, GSL>), dim3((unsigned)slab_blocks), dim3(kSlabThreads),
                                    total, stream, p, (int)(slab_bytes / (long long)sizeof(T)), (int)per_wave);
                 rc = check_launch("msda backward (slab kernel, grad_loc/grad_attn)");
@@ -2958,16 +3048,14 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     }
     if (!(phases & 2)) return rc;
     // LDS budget: one 1024-thread workgroup per CU with 144 KiB of 8-byte accumulators
-    const int cap_bytes = env_int("MSDA_SCATTER_LDS_KB", 144) * 1024;
-    const int per_cu = env_int("MSDA_SCATTER_WG_PER_CU", 1);
+    const int cap_bytes = knobs().scatter_lds_kb * 1024;
+    const int per_cu = knobs().scatter_wg_per_cu;
     unsigned grid = (unsigned)(device_cus() * per_cu);
     grid -= grid % 8;                                   // multiple of the XCD count: item % M stays put
-    static int lds_limit_set = 0;      // per instantiation; dynamic LDS above 64 KiB must be opted into
-    if (cap_bytes > lds_limit_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_value_lds_kernel<T, G>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, cap_bytes) != hipSuccess)
-            return fail(MSDA_ERR_HIP, "msda backward: cannot reserve the requested LDS budget%s");
-        lds_limit_set = cap_bytes;
+    {
+        static LdsGrant granted;       // per instantiation and device
+        if (const int grc = grant_lds(reinterpret_cast<const void *>(&msda_bwd_value_lds_kernel<T, G>), (size_t)cap_bytes,
+                                      granted, "the LDS scatter kernel")) return grc;
     }
     {
         // pixels the scatter will not overwrite (normally none) are zero-filled first
@@ -2979,20 +3067,16 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
         if (rc) return rc;
     }
     if (p.cull_points) {
-        static int lds_limit_points = 0;
+        static LdsGrant granted_points;
         const int cap_pts = cap_bytes < kPointsCapBytes ? cap_bytes : kPointsCapBytes;   // its static tables need ~17 KiB
-        if (cap_pts > lds_limit_points) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_value_points_kernel<T, G>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, cap_pts) != hipSuccess)
-                return fail(MSDA_ERR_HIP, "msda backward: cannot reserve the LDS budget of the scatter kernel%s");
-            lds_limit_points = cap_pts;
-        }
+        if (const int grc = grant_lds(reinterpret_cast<const void *>(&msda_bwd_value_points_kernel<T, G>), (size_t)cap_pts,
+                                      granted_points, "the per-point LDS scatter kernel")) return grc;
         hipLaunchKernelGGL((msda_bwd_value_points_kernel<T, G>), dim3(grid), dim3(kScatterThreads),
-                           (size_t)cap_pts, stream, p, cap_pts / 8, env_int("MSDA_SCATTER_DBG", 0));
+                           (size_t)cap_pts, stream, p, cap_pts / 8, knobs().scatter_dbg);
         return check_launch("msda backward (LDS scatter kernel, per-point culling)");
     }
     hipLaunchKernelGGL((msda_bwd_value_lds_kernel<T, G>), dim3(grid), dim3(kScatterThreads),
-                       (size_t)cap_bytes, stream, p, cap_bytes / 8, env_int("MSDA_SCATTER_DBG", 0));
+                       (size_t)cap_bytes, stream, p, cap_bytes / 8, knobs().scatter_dbg);
     return check_launch("msda backward (LDS scatter kernel)");
 }
 
@@ -3046,23 +3130,17 @@ int launch_generic(const Params &p, bool bwd, hipStream_t stream)
     return check_launch("msda forward (generic kernel)");
 }
 
-int env_force_generic()
-{
-    const char *e = getenv("MSDA_FORCE_GENERIC");   // test hook: exercise the generic kernels
-    return e && e[0] == '1';
-}
-
 int run(int dtype, const Params &p_in, bool bwd, hipStream_t stream)
 {
     Params p = p_in;
-    p.dbg = env_int("MSDA_DBG", 0);
+    p.dbg = knobs().dbg;
     // culling records per point when a level has <= 4 points (MSDA_BWD_CULL=2: force (min, max) intervals)
-    p.cull_points = bwd && p.bbox && p.PA <= 4 && p.PB <= 4 && env_int("MSDA_BWD_CULL", 1) != 2;
+    p.cull_points = bwd && p.bbox && p.PA <= 4 && p.PB <= 4 && knobs().bwd_cull != 2;
     if (!p.cull_points) p.bsum = nullptr;
     if (p.groups == 0 || p.Lq == 0) return MSDA_OK;
     bool taken = false;
     int rc = MSDA_OK;
-    const bool force_generic = env_force_generic();
+    const bool force_generic = knobs().force_generic != 0;
     switch (dtype) {
         case MSDA_F32:
             if (!force_generic) rc = dispatch_tile<float>(p, bwd, stream, taken);
@@ -3132,11 +3210,10 @@ void attach_workspace(Params &p, void *workspace, long long bytes, int batch, in
     p.workspace = (workspace && bytes >= MSDA_BWD_WORKSPACE_BYTES) ? static_cast<unsigned *>(workspace) : nullptr;
     p.bbox = nullptr;
     p.bsum = nullptr;
-    const char *e = getenv("MSDA_BWD_CULL");        // measurement hook: 0 disables the culling structure
-    if (p.workspace && bytes >= workspace_need(batch, num_query, num_heads, vl) && !(e && e[0] == '0')) {
+    if (p.workspace && bytes >= workspace_need(batch, num_query, num_heads, vl) && knobs().bwd_cull != 0) {
         p.bbox = reinterpret_cast<int *>(p.workspace) + MSDA_BWD_WORKSPACE_BYTES / 4;
         // block summaries only pay for long candidate ranges (and index (group, head, level) rows with 32 bits)
-        if (num_query >= 2048 && (long long)batch * num_heads * vl < 0x7fffffffLL && env_int("MSDA_BWD_SUMMARY", 1) != 0)
+        if (num_query >= 2048 && (long long)batch * num_heads * vl < 0x7fffffffLL && knobs().bwd_summary != 0)
             p.bsum = p.bbox + workspace_table_bytes(batch, num_query, num_heads, vl) / 4;
     }
 }
@@ -3174,6 +3251,8 @@ extern "C" {
 
 int msda_version(void) { return MSDA_ABI_VERSION; }
 
+void msda_reload_knobs(void) { load_knobs(); }
+
 long long msda_backward_workspace_bytes(int batch, int num_query, int num_heads, int virtual_levels)
 {
     return workspace_need(batch, num_query, num_heads, virtual_levels);
@@ -3184,7 +3263,8 @@ const char *msda_last_error(void) { return g_err; }
 int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,
                  const int64_t *level_start_index, const void *sampling_loc, const void *attn_weight,
                  int batch, int spatial_size, int num_heads, int channels, int num_levels,
-                 int num_query, int num_point, void *out, const int64_t *value_strides, void *stream)
+                 int num_query, int num_point, void *out, const int64_t *value_strides,
+                 const int64_t *spatial_shapes_host, void *stream)
 {
     g_err[0] = 0;
     int rc = check_common(value, spatial_shapes, level_start_index, batch, spatial_size, num_heads,
@@ -3200,6 +3280,7 @@ int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,
     p.groups = batch; p.frames = 1; p.window = 0;
     p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
     p.LA = num_levels; p.PA = num_point; p.LB = 0; p.PB = 1;
+    p.shapes_host = spatial_shapes_host;
     rc = set_value_strides(p, value_strides);
     if (rc) return rc;
     return run(dtype, p, false, static_cast<hipStream_t>(stream));
@@ -3211,7 +3292,8 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
                   int batch, int spatial_size, int num_heads, int channels, int num_levels,
                   int num_query, int num_point,
                   void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
-                  void *workspace, long long workspace_bytes, const int64_t *value_strides, void *stream)
+                  void *workspace, long long workspace_bytes, const int64_t *value_strides,
+                  const int64_t *spatial_shapes_host, void *stream)
 {
     g_err[0] = 0;
     int rc = check_common(value, spatial_shapes, level_start_index, batch, spatial_size, num_heads,
@@ -3231,6 +3313,7 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
     p.groups = batch; p.frames = 1; p.window = 0;
     p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
     p.LA = num_levels; p.PA = num_point; p.LB = 0; p.PB = 1;
+    p.shapes_host = spatial_shapes_host;
     rc = set_value_strides(p, value_strides);
     if (rc) return rc;
     return run(dtype, p, true, static_cast<hipStream_t>(stream));
@@ -3243,7 +3326,7 @@ int msda_temporal_forward(int dtype, const void *value, const int64_t *spatial_s
                           int clips, int frames, int window, int spatial_size, int num_heads,
                           int channels, int num_levels, int num_query,
                           int num_curr_point, int num_temp_point, void *out, const int64_t *value_strides,
-                          void *stream)
+                          const int64_t *spatial_shapes_host, void *stream)
 {
     g_err[0] = 0;
     int rc = check_common(value, spatial_shapes, level_start_index, clips, spatial_size, num_heads,
@@ -3262,6 +3345,7 @@ int msda_temporal_forward(int dtype, const void *value, const int64_t *spatial_s
     p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
     p.LA = num_levels; p.PA = num_curr_point;
     p.LB = window * num_levels; p.PB = window > 0 ? num_temp_point : 1;
+    p.shapes_host = spatial_shapes_host;
     rc = set_value_strides(p, value_strides);
     if (rc) return rc;
     return run(dtype, p, false, static_cast<hipStream_t>(stream));
@@ -3276,7 +3360,7 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
                            int num_curr_point, int num_temp_point,
                            void *grad_value, void *grad_loc_curr, void *grad_aw_curr,
                            void *grad_loc_temp, void *grad_aw_temp, void *workspace, long long workspace_bytes,
-                           const int64_t *value_strides, void *stream)
+                           const int64_t *value_strides, const int64_t *spatial_shapes_host, void *stream)
 {
     g_err[0] = 0;
     int rc = check_common(value, spatial_shapes, level_start_index, clips, spatial_size, num_heads,
@@ -3301,6 +3385,7 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
     p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
     p.LA = num_levels; p.PA = num_curr_point;
     p.LB = window * num_levels; p.PB = window > 0 ? num_temp_point : 1;
+    p.shapes_host = spatial_shapes_host;
     rc = set_value_strides(p, value_strides);
     if (rc) return rc;
     return run(dtype, p, true, static_cast<hipStream_t>(stream));

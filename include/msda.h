@@ -13,8 +13,12 @@
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer (HBM) unless stated;
  *   - tensors are dense row-major ("contiguous") in the layouts named below;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue work,
- *     they never allocate, never synchronise and keep no global state, so they are re-entrant
- *     (forward on the Python thread, backward on an autograd worker -- as in the reference);
+ *     they never allocate and never synchronise, and are re-entrant (forward on the Python thread,
+ *     backward on an autograd worker -- as in the reference).  The only process-wide state is caches
+ *     keyed by HIP device id (compute-unit count, per-kernel LDS opt-in) and the test knobs below;
+ *   - test / measurement knobs are environment variables (MSDA_FWD_SLAB, MSDA_BWD_MODE, ...; listed in
+ *     devis_amd/csrc/msda_hip.hip at `struct Knobs`).  They are IGNORED unless MSDA_ENABLE_HOOKS=1, and
+ *     are read once -- at the first call or when msda_reload_knobs() is called -- never on the launch path;
  *   - return value: MSDA_OK (0) or a negative msda_status; on failure msda_last_error() returns a
  *     thread-local message.  Unlike the reference (errors only printf'd,
  *     ms_deform_im2col_cuda.cuh:948-952,1321-1325) launch failures ARE reported;
@@ -34,6 +38,11 @@
  *     on an XCD and only a fraction of its L2 channels is used.  grad_value is
  *     always dense [N, S, M, D].
  *
+ *   - `spatial_shapes_host` (HOST pointer to [L, 2] int64, or NULL; ABI v8): a host copy of `spatial_shapes`,
+ *     used ONLY to choose between kernels (which pyramid levels fit the LDS slab).  Results never depend on
+ *     it; NULL makes the library guess from `spatial_size`.  The device tensor stays the one the kernels read
+ *     (no host synchronisation inside the library, as in the reference).
+ *
  * Symbols:  N batch, S = sum_l H_l*W_l, M heads, D channels per head, Lq queries, L levels,
  *           P points;  spatial_shapes[l] = (H_l, W_l);  sampling_loc[..., 0] = x (width), 1 = y.
  */
@@ -46,7 +55,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 7
+#define MSDA_ABI_VERSION 8
 #define MSDA_BWD_WORKSPACE_BYTES 64   /* minimum device scratch of the backward entry points (ticket counters) */
 
 enum msda_dtype { MSDA_F32 = 0, MSDA_F64 = 1, MSDA_BF16 = 2, MSDA_F16 = 3 };
@@ -63,6 +72,9 @@ int msda_version(void);
 
 /* Thread-local description of the last failure on this thread ("" if none). */
 const char *msda_last_error(void);
+
+/* Re-read the test / measurement knobs from the environment (see Conventions).  Not for production use. */
+void msda_reload_knobs(void);
 
 /*
  * Forward of one MSDeformAttnFunction call.
@@ -83,7 +95,8 @@ const char *msda_last_error(void);
 int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,
                  const int64_t *level_start_index, const void *sampling_loc, const void *attn_weight,
                  int batch, int spatial_size, int num_heads, int channels, int num_levels,
-                 int num_query, int num_point, void *out, const int64_t *value_strides, void *stream);
+                 int num_query, int num_point, void *out, const int64_t *value_strides,
+                 const int64_t *spatial_shapes_host, void *stream);
 
 /*
  * Backward of one MSDeformAttnFunction call.
@@ -108,7 +121,8 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
                   int batch, int spatial_size, int num_heads, int channels, int num_levels,
                   int num_query, int num_point,
                   void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
-                  void *workspace, long long workspace_bytes, const int64_t *value_strides, void *stream);
+                  void *workspace, long long workspace_bytes, const int64_t *value_strides,
+                  const int64_t *spatial_shapes_host, void *stream);
 
 /* Bytes of `workspace` that enable every feature of msda_backward / msda_temporal_backward:
  * 64 (ticket counters) + rows * virtual_levels * 8 (per-point culling records) + their summaries over blocks of 64
@@ -144,7 +158,7 @@ int msda_temporal_forward(int dtype, const void *value, const int64_t *spatial_s
                           int clips, int frames, int window, int spatial_size, int num_heads,
                           int channels, int num_levels, int num_query,
                           int num_curr_point, int num_temp_point, void *out, const int64_t *value_strides,
-                          void *stream);
+                          const int64_t *spatial_shapes_host, void *stream);
 
 /*
  * Fused temporal backward.  grad_value [clips*frames, S, M, D] (float / double, fully overwritten, need
@@ -162,7 +176,7 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
                            int num_curr_point, int num_temp_point,
                            void *grad_value, void *grad_loc_curr, void *grad_aw_curr,
                            void *grad_loc_temp, void *grad_aw_temp, void *workspace, long long workspace_bytes,
-                           const int64_t *value_strides, void *stream);
+                           const int64_t *value_strides, const int64_t *spatial_shapes_host, void *stream);
 
 /*
  * Pre-op fusion: everything the modules do between their Linears and the operator

@@ -1,5 +1,6 @@
 """GPU probe: a few fused backward launches only (for rocprofv3 --pmc passes)."""
 import os, sys
+os.environ.setdefault("MSDA_ENABLE_HOOKS", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from devis_amd import _native

@@ -1,6 +1,7 @@
 """GPU probe: resident-slab forward (MSDA_FWD_RS=1) against the previous kernels (MSDA_FWD_RS=0) on bench-shaped
 inputs: max abs difference and HIP-event timings."""
 import os, sys
+os.environ.setdefault("MSDA_ENABLE_HOOKS", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from devis_amd import _native
@@ -18,6 +19,7 @@ def run(clips, pyr="A", locs="uniform", queries=300, dt="f32", layout="dense", r
     outs, times = {}, {}
     for mode in ("0", "1"):
         os.environ["MSDA_FWD_RS"] = mode
+        _native.reload_knobs()
         out = torch.full((clips * T, q, M * D), float("nan"), dtype=dtype, device=dev)
         fn = lambda: _native.temporal_forward(b["value"], b["shapes"], b["lsi"], b["ftab"], b["loc_c"], b["aw_c"],
                                               b["loc_t"], b["aw_t"], clips, out)
@@ -30,11 +32,14 @@ def run(clips, pyr="A", locs="uniform", queries=300, dt="f32", layout="dense", r
         times[mode] = sum(s.elapsed_time(e) for s, e in ev) / reps
         outs[mode] = out.float().clone()
     os.environ.pop("MSDA_FWD_RS")
+    _native.reload_knobs()
     diff = (outs["0"] - outs["1"]).abs().max().item()
     nan = int(torch.isnan(outs["1"]).sum())
     print("clips %3d pyr %s locs %-9s q %5d %s %-6s  old %.4f ms  rs %.4f ms  max|diff| %.3e  nan %d  scale %.3f"
           % (clips, pyr, locs, queries, dt, layout, times["0"], times["1"], diff, nan, outs["0"].abs().max().item()), flush=True)
 
 if __name__ == "__main__":
-    run(16); run(16, layout="padded"); run(16, locs="clustered"); run(8); run(32); run(3, queries=37); run(8, pyr="B")
-    os.environ["MSDA_FWD_RS_NT"] = "2"; print("NT=2"); run(16); os.environ.pop("MSDA_FWD_RS_NT")
+    for nt in ("2", "1"):
+        os.environ["MSDA_FWD_RS_NT"] = nt; print("NT=" + nt)
+        run(16); run(16, layout="padded"); run(8); run(32)
+    os.environ.pop("MSDA_FWD_RS_NT")

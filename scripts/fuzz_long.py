@@ -8,6 +8,8 @@ from helpers import make_inputs, make_temporal_inputs, oracle_fwd_bwd, round_to,
 from devis_amd import _native
 from devis_amd.functions import MSDeformAttnFunction, MSDeformAttnTemporalFunction
 DEV = "cuda:0"
+os.environ["MSDA_ENABLE_HOOKS"] = "1"
+from devis_amd import _native as _native_mod
 ROUTES = [{}, {"MSDA_SCATTER_DBG": "16"}, {"MSDA_FWD_SLAB": "1", "MSDA_BWD_SLAB": "1"}, {"MSDA_BWD_CULL": "2"},
           {"MSDA_BWD_CULL": "0"}, {"MSDA_SCATTER_LDS_KB": "6"}, {"MSDA_SCATTER_DBG": "16", "MSDA_FWD_SLAB": "1", "MSDA_BWD_SLAB": "1"},
           {"MSDA_FWD_SLAB": "0", "MSDA_BWD_SLAB": "0"}]
@@ -30,6 +32,7 @@ for seed in range(first, first + count):
     for k in KEYS: os.environ.pop(k, None)
     route = ROUTES[int(rng.integers(0, len(ROUTES)))]
     os.environ.update(route)
+    _native_mod.reload_knobs()
     lay = int(rng.integers(0, 3))
     big = rng.random() < 0.25
     if seed % 2 == 0:

@@ -10,6 +10,42 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The library's MSDA_* test knobs (route forcing, measurement hooks) are honoured only with MSDA_ENABLE_HOOKS=1 and
+# are read once (include/msda.h): tests switch them with monkeypatch.setenv, which is wrapped here to re-read them,
+# and an autouse fixture re-reads them again once monkeypatch has restored the environment.
+os.environ["MSDA_ENABLE_HOOKS"] = "1"
+
+
+def _reload_knobs():
+    from devis_amd import _native
+    _native.reload_knobs()
+
+
+_orig_setenv, _orig_delenv = pytest.MonkeyPatch.setenv, pytest.MonkeyPatch.delenv
+
+
+def _setenv(self, name, value, prepend=None):
+    _orig_setenv(self, name, value, prepend)
+    if name.startswith("MSDA_"):
+        _reload_knobs()
+
+
+def _delenv(self, name, raising=True):
+    _orig_delenv(self, name, raising)
+    if name.startswith("MSDA_"):
+        _reload_knobs()
+
+
+pytest.MonkeyPatch.setenv, pytest.MonkeyPatch.delenv = _setenv, _delenv
+
+
+@pytest.fixture(autouse=True)
+def _knobs_follow_environment():
+    """Set up before (hence torn down after) monkeypatch: the knobs are re-read once the environment is restored."""
+    yield
+    if any(k.startswith("MSDA_") for k in os.environ) or True:
+        _reload_knobs()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

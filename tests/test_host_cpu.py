@@ -36,14 +36,14 @@ def test_abi_argument_errors_without_gpu():
     from devis_amd import _native
     lib = _native.load()
     # null pointers / bad sizes are rejected before any HIP call
-    rc = lib.msda_forward(0, None, None, None, None, None, 1, 30, 2, 2, 2, 2, 2, None, None, None)
+    rc = lib.msda_forward(0, None, None, None, None, None, 1, 30, 2, 2, 2, 2, 2, None, None, None, None)
     assert rc == -1 and b"null pointer" in lib.msda_last_error()
     buf = ctypes.create_string_buffer(64)
     p = ctypes.cast(buf, ctypes.c_void_p)
-    rc = lib.msda_forward(0, p, p, p, p, p, 1, 30, 0, 2, 2, 2, 2, p, None, None)
+    rc = lib.msda_forward(0, p, p, p, p, p, 1, 30, 0, 2, 2, 2, 2, p, None, None, None)
     assert rc == -1 and b"positive" in lib.msda_last_error()
-    assert lib.msda_forward(0, p, p, p, p, p, 0, 30, 2, 2, 2, 2, 2, p, None, None) == 0      # empty batch: no-op
-    rc = lib.msda_temporal_forward(0, p, p, p, p, p, p, p, p, 1, 0, 1, 30, 2, 2, 2, 2, 2, 2, p, None, None)
+    assert lib.msda_forward(0, p, p, p, p, p, 0, 30, 2, 2, 2, 2, 2, p, None, None, None) == 0      # empty batch: no-op
+    rc = lib.msda_temporal_forward(0, p, p, p, p, p, p, p, p, 1, 0, 1, 30, 2, 2, 2, 2, 2, 2, p, None, None, None)
     assert rc == -1
 
 

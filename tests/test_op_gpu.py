@@ -292,7 +292,7 @@ def test_backward_without_workspace_static_schedule():
     lib = _native.load()
     rc = lib.msda_backward(0, t["value"].data_ptr(), t["shapes"].data_ptr(), t["lsi"].data_ptr(), t["loc"].data_ptr(),
                            t["aw"].data_ptr(), t["grad_out"].float().contiguous().data_ptr(), N, S, M, D, L, Lq, P,
-                           gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), None, 0, None,
+                           gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), None, 0, None, None,
                            torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     torch.cuda.synchronize()
@@ -460,7 +460,7 @@ def test_grad_value_is_overwritten(route, monkeypatch):
         _, Lq, _, L, P, _ = loc.shape
         rc = _native.load().msda_backward(0, v.data_ptr(), t["shapes"].data_ptr(), t["lsi"].data_ptr(), loc.data_ptr(),
                                           aw.data_ptr(), go.data_ptr(), N, S, M, D, L, Lq, P, gv.data_ptr(),
-                                          gl.data_ptr(), ga.data_ptr(), None, 0, None,
+                                          gl.data_ptr(), ga.data_ptr(), None, 0, None, None,
                                           torch.cuda.current_stream().cuda_stream)
         assert rc == 0
     else:
