@@ -2101,6 +2101,333 @@ msda_bwd_value_points_kernel(const Params p, int cap_slots, int dbg)
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// grad_value by OWNER-COMPUTES scatter (round 2): no floating-point atomics at all
+// ------------------------------------------------------------------------------------------------
+// The LDS scatter above is bound by the fp64 LDS atomic unit: 2 KiB of read-modify-write per hit, 9.1 clk per
+// ds_add_f64 wave instruction, a floor of 0.65 ms on the DeVIS decoder workload.  Here every pixel of a band
+// has an OWNER -- one quad of the workgroup, lane c holding channels [4c, 4c+4) of both halves of the pixel in
+// registers -- and a hit only (1) has its grad_out row staged in LDS once (LDS-DMA, 128 B) and (2) links one
+// 8-byte entry {weight, next} per owned corner into that pixel's list (ds_wrxchg_rtn_b32 on the list head: an
+// integer exchange, not a float atomic).  The owners then walk their lists with plain LDS reads
+// (8 B entry + 2 x 16 B of the row per lane) and accumulate in fp32 registers: ~650 B of plain LDS traffic
+// per hit instead of 2 KiB of atomics.  Same items (clip, source frame, head, band of pixel rows of one
+// level), same per-point culling records from the gather pass, same survivor list as
+// msda_bwd_value_points_kernel; bands are sized by the owners' registers (kOwnPix pixels) instead of by LDS.
+// The sum of a pixel's terms is an fp32 sum in list order (the reference's atomicAdd order is arbitrary too,
+// cuh:125-152); terms are the products (w_corner * attn) * grad_out[c].
+constexpr int kOwnThreads = 1024;
+constexpr int kOwnQuads = kOwnThreads / 4;
+constexpr int kOwnSlots = 4;                        // pixels per owner quad
+constexpr int kOwnPix = kOwnQuads * kOwnSlots;      // pixels per band
+constexpr int kOwnChunk = 768;                      // hits per chunk: their grad_out rows live in LDS (96 KiB)
+constexpr int kOwnList = kOwnChunk + 4 * kOwnThreads;   // survivor list: a chunk's worth + one cull batch, worst case
+constexpr unsigned kOwnNil = 0xffffffffu;
+constexpr int kOwnLdsBytes = kOwnChunk * 128 + 4 * kOwnChunk * 8 + kOwnPix * 4 + kOwnList * 4;
+
+template <typename T, int VARIANT>       // VARIANT bit 1: the next chunk's hits are fetched before the walk (bit 0: unused)
+__global__ void __launch_bounds__(kOwnThreads)
+msda_bwd_value_own_kernel(const Params p, int dbg)
+{
+    static_assert(sizeof(T) == 4, "owner-computes scatter: 4-byte storage types");
+    constexpr int D = 32;
+    extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];
+    unsigned char *rows = lds_raw;                                              // [kOwnChunk][128 B]
+    uint2 *ents = reinterpret_cast<uint2 *>(lds_raw + kOwnChunk * 128);         // [4 * kOwnChunk] {weight bits, next}
+    unsigned *head = reinterpret_cast<unsigned *>(ents + 4 * kOwnChunk);        // [kOwnPix]
+    unsigned *list = head + kOwnPix;                                            // [kOwnList] (k:6 | pt:2 | q:24)
+    __shared__ int s_H[kScatterMaxLevels], s_W[kScatterMaxLevels], s_R[kScatterMaxLevels],
+        s_first[kScatterMaxLevels + 1], s_lsi[kScatterMaxLevels];
+    __shared__ int s_nsrc, s_cnt[3];     // survivor counters rotate: slot j is reset two barriers before it is used again
+    __shared__ long long s_src_tab[kScatterMaxSources], s_src_loc[kScatterMaxSources];
+    __shared__ int s_src_q0[kScatterMaxSources];
+    __shared__ long long s_item;
+
+    const int tid = threadIdx.x, lane = tid % kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int MD = p.M * D, L = p.L, VL = p.LA + p.LB;
+    if (tid == 0) {
+        int first = 0;
+        for (int l = 0; l < L; ++l) {
+            const int H = (int)p.shapes[2 * l], W = (int)p.shapes[2 * l + 1];
+            const int R = min(H, kOwnPix / max(1, W));          // rows per band; 0 = "direct" level (row wider than a band)
+            s_H[l] = H; s_W[l] = W; s_R[l] = R; s_lsi[l] = (int)p.lsi[l];
+            s_first[l] = first;
+            first += (R > 0) ? (H + R - 1) / R : 1;
+        }
+        s_first[L] = first;
+        s_cnt[0] = s_cnt[1] = s_cnt[2] = 0;
+    }
+    int ci = 0;                             // counter of the current cull batch
+    for (int i = tid; i < kOwnPix; i += kOwnThreads) head[i] = kOwnNil;
+    __syncthreads();
+    const int NB = s_first[L];
+    const int clips = p.groups / p.frames;
+    const int64_t n_items = (int64_t)clips * p.frames * p.M * NB;
+    const bool dynamic = p.workspace != nullptr && (dbg & 16) == 0 && n_items < (int64_t)16 * gridDim.x;
+    const int lane8 = blockIdx.x % 8;
+    const int strideA = p.M * p.LA * p.PA, strideB = p.M * p.LB * p.PB;      // loc/attn elements per query
+    // owner side: quad Q owns pixels s * kOwnQuads + Q of the band; lane c of the quad the channels [4c, 4c+4) of
+    // both 64-byte halves of the pixel (odd quads read the second half first: LDS banks, as in the forward)
+    const int Q = tid / 4, cq = tid & 3, hsw = Q & 1;
+    const int off1 = cq * 16 + hsw * 64;
+
+    for (int64_t it = blockIdx.x;; it += gridDim.x) {
+        int64_t item = it;
+        if (dynamic) {
+            if (tid == 0) s_item = (long long)atomicAdd(p.workspace + lane8, 1u) * 8 + lane8;
+            __syncthreads();
+            item = s_item;
+        }
+        if (item >= n_items) break;
+        int l, part, m, f, clip;
+        if (dynamic) {      // heaviest first: levels from the last to the first (see msda_bwd_value_lds_kernel)
+            const int64_t ctm = (int64_t)clips * p.frames * p.M;
+            l = L - 1;
+            int64_t local = item;
+            while (l > 0 && local >= ctm * (s_first[l + 1] - s_first[l])) {
+                local -= ctm * (s_first[l + 1] - s_first[l]);
+                --l;
+            }
+            const int nb_l = s_first[l + 1] - s_first[l];
+            m = (int)(local % p.M);
+            int64_t rest = local / p.M;
+            part = s_first[l] + (int)(rest % nb_l); rest /= nb_l;
+            f = (int)(rest % p.frames);
+            clip = (int)(rest / p.frames);
+        } else {
+            m = (int)(item % p.M);
+            int64_t rest = item / p.M;
+            part = (int)(rest % NB); rest /= NB;
+            f = (int)(rest % p.frames);
+            clip = (int)(rest / p.frames);
+            l = 0;
+            while (l + 1 < L && s_first[l + 1] <= part) ++l;
+        }
+        const int H = s_H[l], W = s_W[l], R = s_R[l];
+        const bool direct = (R == 0);
+        const int r0 = direct ? 0 : (part - s_first[l]) * R;
+        const int r1 = direct ? H - 1 : min(H, r0 + R) - 1;
+        const int npix = direct ? 0 : (r1 - r0 + 1) * W;
+        float *gmap = static_cast<float *>(p.grad_value) +
+                      (((int64_t)clip * p.frames + f) * p.S + s_lsi[l]) * MD + m * D;     // pixel (0, 0) of the level, head m
+
+        // sources that read frame f: the current-frame points of frame f, then every temporal slot (t, w) with
+        // frame_table[t, w] == f; per source the first culling-table entry, first loc/attn element, first query row
+        if (wave == 0) {
+            const int n_tw = p.frames * p.window;
+            const bool hit = lane < n_tw && p.ftab[lane] == f;
+            const u64 bal = __ballot(hit);
+            if (lane == 0) {
+                const int64_t g = (int64_t)clip * p.frames + f;
+                s_src_tab[0] = ((g * p.M + m) * VL + l) * p.Lq;
+                s_src_loc[0] = (g * p.Lq * p.M + m) * ((int64_t)p.LA * p.PA) + l * p.PA;
+                s_src_q0[0] = (int)(g * p.Lq);
+                s_nsrc = 1 + (int)__popcll(bal);
+            }
+            if (hit) {
+                const int n = 1 + (int)__popcll(bal & ((1ull << lane) - 1ull)), t = lane / p.window;
+                const int vl = (lane - t * p.window) * L + l;
+                const int64_t g = (int64_t)clip * p.frames + t;
+                s_src_tab[n] = ((g * p.M + m) * VL + p.LA + vl) * p.Lq;
+                s_src_loc[n] = (g * p.Lq * p.M + m) * ((int64_t)p.LB * p.PB) + vl * p.PB;
+                s_src_q0[n] = (int)(g * p.Lq);
+            }
+        }
+        __syncthreads();
+        const int ng = s_nsrc * p.Lq;              // candidate groups: (source, query) pairs, <= 4 points each
+
+        float acc[kOwnSlots][8];
+#pragma unroll
+        for (int s = 0; s < kOwnSlots; ++s)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[s][c] = 0.f;
+
+        // Stage A of a chunk: the hit of this thread -- survivor entry -> (x, y, attention weight) loads in flight.
+        auto fetch_hit = [&](int base, int n, float &x, float &y, float &a, int &qrow) {
+            x = y = -10.f; a = 0.f; qrow = 0;
+            if (tid < n) {
+                const unsigned e = list[base + tid];
+                const int k = (int)(e >> 26), q = (int)(e & 0xffffffu);
+                const bool curf = (k == 0);
+                const int64_t idx = s_src_loc[k] + (int64_t)q * (curf ? strideA : strideB) + (int)((e >> 24) & 3u);
+                const T *loc = static_cast<const T *>(curf ? p.locA : p.locB);
+                const T *aw = static_cast<const T *>(curf ? p.awA : p.awB);
+                const float2 xy = *reinterpret_cast<const float2 *>(loc + 2 * idx);
+                x = xy.x; y = xy.y;
+                a = aw[idx];
+                qrow = s_src_q0[k] + q;
+            }
+        };
+        // One chunk of n hits (already fetched into x, y, a, qrow): rows staged, entries linked, lists walked by
+        // the owners; the NEXT chunk's hits (list[nbase, nbase + nn)) are fetched before the walk, so their memory
+        // latency hides behind it.
+        auto process_chunk = [&](int n, float &x, float &y, float &a, int &qrow, int nbase, int nn) {
+            // ---- grad_out rows -> LDS: 8 lanes x 16 B per hit, 8 hits per LDS-DMA wave instruction
+            if (!direct && !(dbg & 4)) {
+                const T *go = static_cast<const T *>(p.grad_out) + m * D + (lane & 7) * 4;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int src_lane = 8 * i + (lane >> 3);
+                    const int qr = __shfl(qrow, src_lane, kWave);
+                    const int h = wave * kWave + src_lane;
+                    if (wave * kWave + 8 * i < n) {                     // uniform: this instruction has at least one live hit
+                        const T *gp = go + (int64_t)(h < n ? qr : 0) * MD;
+#if defined(__HIP_DEVICE_COMPILE__)
+                        __builtin_amdgcn_global_load_lds(gp, (__attribute__((address_space(3))) void *)(rows + (wave * kWave + 8 * i) * 128), 16, 0, 0);
+#else
+                        (void)gp;
+#endif
+                    }
+                }
+            }
+            // ---- taps (cuh:285-288, 38-80) and the entries of the corners this band owns
+            {
+                const float h_im = __fsub_rn(__fmul_rn(y, (float)H), 0.5f);
+                const float w_im = __fsub_rn(__fmul_rn(x, (float)W), 0.5f);
+                if (tid < n && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                    const float hf = floorf(h_im), wf = floorf(w_im);
+                    const int h_low = (int)hf, w_low = (int)wf;
+                    const bool top = h_low >= max(r0, 0) && h_low <= r1;          // rows this band owns
+                    const bool bot = h_low + 1 >= r0 && h_low + 1 <= min(r1, H - 1);
+                    const bool x0 = w_low >= 0, x1 = w_low + 1 <= W - 1;
+                    const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+                    const float wgt[4] = {hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a};
+                    const bool own[4] = {top && x0, top && x1, bot && x0, bot && x1};
+                    const int pix00 = (h_low - r0) * W + w_low;
+                    const int dpix[4] = {0, 1, W, W + 1};
+                    if (direct) {
+                        // a level whose single row does not fit a band: float atomics straight to memory
+                        const float *gr = reinterpret_cast<const float *>(static_cast<const T *>(p.grad_out) + (int64_t)qrow * MD + m * D);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (own[c]) {
+                                float *dst = gmap + (int64_t)(pix00 + dpix[c]) * MD;
+                                for (int ch = 0; ch < D; ++ch) atomic_accumulate(dst + ch, wgt[c] * gr[ch]);
+                            }
+                    } else if (!(dbg & 2)) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (own[c]) {
+                                const unsigned ei = 4u * (unsigned)tid + (unsigned)c;
+                                const unsigned prev = atomicExch(&head[pix00 + dpix[c]], ei);
+                                ents[ei] = make_uint2(__float_as_uint(wgt[c]), prev);
+                            }
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's rows have landed
+            __syncthreads();
+            if constexpr (VARIANT & 2) fetch_hit(nbase, nn, x, y, a, qrow);      // (nn = 0: nothing)
+            // ---- owners walk their pixels' lists
+            if (!direct && !(dbg & 1)) {
+#pragma unroll
+                for (int s = 0; s < kOwnSlots; ++s) {
+                    const int pix = s * kOwnQuads + Q;
+                    unsigned e = kOwnNil;
+                    if (pix < npix) { e = head[pix]; if (e != kOwnNil) head[pix] = kOwnNil; }
+                    while (e != kOwnNil) {
+                        const uint2 en = ents[e];
+                        const float w = __uint_as_float(en.x);
+                        const unsigned char *r = rows + (e >> 2) * 128;
+                        const float4 v1 = *reinterpret_cast<const float4 *>(r + off1);
+                        const float4 v2 = *reinterpret_cast<const float4 *>(r + (off1 ^ 64));
+                        acc[s][0] = fmaf(w, v1.x, acc[s][0]); acc[s][1] = fmaf(w, v1.y, acc[s][1]);
+                        acc[s][2] = fmaf(w, v1.z, acc[s][2]); acc[s][3] = fmaf(w, v1.w, acc[s][3]);
+                        acc[s][4] = fmaf(w, v2.x, acc[s][4]); acc[s][5] = fmaf(w, v2.y, acc[s][5]);
+                        acc[s][6] = fmaf(w, v2.z, acc[s][6]); acc[s][7] = fmaf(w, v2.w, acc[s][7]);
+                        e = en.y;
+                    }
+                }
+            }
+            __syncthreads();
+        };
+
+        // ---- cull the candidate groups in batches of one per thread against the band; chunks are cut from the END
+        // of the survivor list, so nothing has to move
+        int listed = 0;
+        const int lo = min(r0 - 1, 32767), hi = min(r1, 32767);
+        auto load_records = [&](int gi0, int2 &iv, unsigned &ent, bool &live) {
+            const int gi = gi0 + tid;
+            live = gi < ng;
+            iv = make_int2((int)0x80008000u, (int)0x80008000u);
+            ent = 0u;
+            if (live) {
+                const int k = gi / p.Lq, q = gi - k * p.Lq;
+                ent = ((unsigned)k << 26) | (unsigned)q;
+                if (p.bbox) iv = *reinterpret_cast<const int2 *>(p.bbox + (s_src_tab[k] + q) * 2);
+            }
+        };
+        int2 iv;
+        unsigned ent;
+        bool live;
+        load_records(0, iv, ent, live);
+        for (int gi0 = 0; gi0 < ng || gi0 == 0; gi0 += kOwnThreads) {
+            unsigned pm = 0u;
+            if (live) {
+                if (p.bbox) {
+                    const int hr[4] = {(int)(short)(iv.x & 0xffff), iv.x >> 16, (int)(short)(iv.y & 0xffff), iv.y >> 16};
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp) pm |= (hr[jp] >= lo && hr[jp] <= hi) ? (1u << jp) : 0u;
+                } else {
+                    pm = (1u << ((ent >> 26) == 0u ? p.PA : p.PB)) - 1u;       // no culling table: every point is a candidate
+                }
+            }
+            const unsigned ent_now = ent;
+            const bool last = gi0 + kOwnThreads >= ng;
+            if (!last) load_records(gi0 + kOwnThreads, iv, ent, live);        // the next batch's records fly meanwhile
+            // wave-wide exclusive scan of the per-lane survivor counts (DPP), one LDS atomic per wave
+            const int cnt = __popc(pm);
+            int v = cnt;
+            v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+            const int total = __builtin_amdgcn_readlane(v, kWave - 1);
+            int wbase = 0;
+            if (tid == 0) s_cnt[(ci + 1) % 3] = 0;      // last read before the previous barrier, next used after the next one
+            if (lane == 0 && total) wbase = atomicAdd(&s_cnt[ci], total);
+            wbase = __shfl(wbase, 0, kWave);
+            int pos = listed + wbase + v - cnt;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if ((pm >> b) & 1u) { list[pos] = ent_now | ((unsigned)b << 24); ++pos; }
+            __syncthreads();
+            listed += s_cnt[ci];
+            ci = (ci + 1) % 3;
+            float x, y, a;
+            int qrow;
+            bool primed = false;
+            if (dbg & 8) listed = 0;                    // measurement: cull only
+            while (listed >= kOwnChunk || (last && listed > 0)) {
+                const int n = min(kOwnChunk, listed);
+                if (!primed || !(VARIANT & 2)) fetch_hit(listed - n, n, x, y, a, qrow);
+                listed -= n;
+                const bool more = listed >= kOwnChunk || (last && listed > 0);
+                const int nn = more ? min(kOwnChunk, listed) : 0;
+                process_chunk(n, x, y, a, qrow, listed - nn, nn);
+                primed = more;
+            }
+        }
+        // ---- owners store their pixels: grad_value is overwritten, every pixel of the band exactly once
+        if (!direct) {
+            float *gband = gmap + (int64_t)r0 * W * MD;
+#pragma unroll
+            for (int s = 0; s < kOwnSlots; ++s) {
+                const int pix = s * kOwnQuads + Q;
+                if (pix < npix) {
+                    float *o = gband + (int64_t)pix * MD;
+                    *reinterpret_cast<float4 *>(o + off1 / 4) = make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
+                    *reinterpret_cast<float4 *>(o + (off1 ^ 64) / 4) = make_float4(acc[s][4], acc[s][5], acc[s][6], acc[s][7]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // The LDS scatter kernels OVERWRITE every pixel of a level whose row fits the band budget.  Pixels they
 // do not own -- levels that take the float-atomic branch, or rows of `value` outside every level when
 // spatial_shapes does not tile [0, S) -- are zero-filled here, so that callers need not memset grad_value.
@@ -2806,6 +3133,7 @@ struct Knobs {
     int bwd_cull = 1;                   // 0: no culling structure, 2: (min, max) intervals instead of per-point records
     int bwd_summary = 1;                // 64-query block summaries for long candidate ranges
     int scatter_lds_kb = 144, scatter_wg_per_cu = 1, scatter_dbg = 0;
+    int scatter_own = -1;               // owner-computes scatter: -1 auto, 0 off, 1 force (where it applies)
     int force_generic = 0;
     int dbg = 0;
 };
@@ -2833,6 +3161,7 @@ void load_knobs()
         k.scatter_lds_kb = env_int("MSDA_SCATTER_LDS_KB", k.scatter_lds_kb);
         k.scatter_wg_per_cu = env_int("MSDA_SCATTER_WG_PER_CU", k.scatter_wg_per_cu);
         k.scatter_dbg = env_int("MSDA_SCATTER_DBG", k.scatter_dbg);
+        k.scatter_own = env_int("MSDA_SCATTER_OWN", k.scatter_own);
         k.force_generic = env_int("MSDA_FORCE_GENERIC", 0) == 1;
         k.dbg = env_int("MSDA_DBG", 0);
     }
@@ -3047,6 +3376,29 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
         if (rc) return rc;
     }
     if (!(phases & 2)) return rc;
+    if constexpr (sizeof(T) == 4 && G == 8) {
+        // owner-computes scatter (D = 32, 4-byte types, <= 4 points per level): no float atomics
+        const int own = knobs().scatter_own;
+        if (own != 0 && p.PA <= 4 && p.PB <= 4 && (p.cull_points || !p.bbox) && knobs().scatter_lds_kb == 144 &&
+            knobs().scatter_wg_per_cu == 1) {
+            unsigned grid = (unsigned)device_cus();
+            grid -= grid % 8;
+            static LdsGrant granted_own[4];
+            const int variant = (knobs().scatter_dbg & 256) ? 0 : 2;       // (measurement: 256 = no cross-chunk prefetch)
+            auto own_launch = [&](auto kern) {
+                if (const int grc = grant_lds(reinterpret_cast<const void *>(kern), (size_t)kOwnLdsBytes, granted_own[variant],
+                                              "the owner-computes scatter kernel")) return grc;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(kOwnThreads), (size_t)kOwnLdsBytes, stream, p, knobs().scatter_dbg);
+                return check_launch("msda backward (owner-computes scatter kernel)");
+            };
+            const int64_t rows = (int64_t)p.groups * p.S;
+            const unsigned zb = (unsigned)((rows + 255) / 256 < 16384 ? (rows + 255) / 256 : 16384);
+            hipLaunchKernelGGL(msda_zero_unowned_kernel, dim3(zb), dim3(256), 0, stream, p, kOwnPix * p.D);
+            rc = check_launch("msda backward (zero-fill of pixels outside the bands)");
+            if (rc) return rc;
+            return variant == 0 ? own_launch(&msda_bwd_value_own_kernel<T, 0>) : own_launch(&msda_bwd_value_own_kernel<T, 2>);
+        }
+    }
     // LDS budget: one 1024-thread workgroup per CU with 144 KiB of 8-byte accumulators
     const int cap_bytes = knobs().scatter_lds_kb * 1024;
     const int per_cu = knobs().scatter_wg_per_cu;
