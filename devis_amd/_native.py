@@ -153,12 +153,13 @@ def forward(value, shapes, lsi, loc, aw, out):
 
 
 def bwd_workspace(device, batch, num_query, num_heads, virtual_levels):
-    """Device scratch for one backward call (include/msda.h): full size, first 64 bytes (the scatter
-    pass's ticket counters) zeroed; the rest is written by the gather pass before it is read."""
+    """Device scratch for one backward call (include/msda.h), uninitialised: the library zeroes the ticket counters
+    at its head and writes the culling records before it reads them (ABI v8 -- no memset launch here).  It is
+    drawn from torch's caching allocator per call rather than kept in a table of our own: the allocator IS a
+    per-(device, stream, size) cache, and unlike a private one it stays correct when two backward passes run on
+    different streams."""
     n = load().msda_backward_workspace_bytes(batch, num_query, num_heads, virtual_levels)
-    ws = torch.empty((n + 3) // 4, dtype=torch.int32, device=device)
-    ws[:BWD_WORKSPACE_BYTES // 4].zero_()
-    return ws
+    return torch.empty((n + 3) // 4, dtype=torch.int32, device=device)
 
 
 def backward(value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_aw):

@@ -773,6 +773,9 @@ msda_bwd_slab_kernel(const Params p, int slab_elems, int per_wave_bytes)
 
     const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
     const int nvl = p.LA + p.LB, L = p.L;
+    // the scatter pass that follows on the stream draws its work tickets from the head of the workspace: zeroed here
+    // (ABI v8), so that the caller does not have to launch a memset for 64 bytes
+    if (blockIdx.x == 0 && tid < MSDA_BWD_WORKSPACE_BYTES / 4 && p.workspace) p.workspace[tid] = 0u;
     T *slab = reinterpret_cast<T *>(lds_raw);
     unsigned char *mine = lds_raw + (size_t)slab_elems * sizeof(T) + (size_t)wave * per_wave_bytes;
     int4 *s_off = reinterpret_cast<int4 *>(mine);
@@ -977,6 +980,7 @@ msda_bwd_tile_kernel(const Params p)
     Level *s_lvl = reinterpret_cast<Level *>(s_e + RPW * kRowSlots);
 
     const int lane = threadIdx.x;
+    if (blockIdx.x == 0 && lane < MSDA_BWD_WORKSPACE_BYTES / 4 && p.workspace) p.workspace[lane] = 0u;     // (see msda_bwd_slab_kernel)
     int m, group, q0;
     tile_coords<RPW>(p, m, group, q0);
     const int clip = group / p.frames, t = group - clip * p.frames;

@@ -255,6 +255,29 @@ def project_value(x, linear, n_heads, padding_mask=None, pad_heads=1):
     return _PaddedValueProj.apply(x, linear.weight, linear.bias, n_heads, pad_heads, padding_mask)
 
 
+def _check_prep_inputs(y, named_refs, shapes):
+    """Preconditions of the fused pre-op pass.  msda_prep_* reads the reference points AS THE DTYPE OF ``y`` and
+    ``spatial_shapes`` as int64 device memory through raw pointers, so a mismatch would not fail, it would
+    reinterpret memory: reference points follow ``y`` (cast here when they differ -- DeVIS's
+    ``get_reference_points`` builds them in fp32 whatever the model's dtype), everything must sit on ``y``'s GPU."""
+    if not y.is_cuda:
+        raise RuntimeError("Not implemented on the CPU (the fused pre-op pass needs GPU tensors)")
+    _native.dtype_code(y.dtype)
+    _require(isinstance(shapes, torch.Tensor) and shapes.dtype == torch.int64 and shapes.device == y.device and
+             shapes.dim() == 2 and shapes.shape[1] == 2 and shapes.is_contiguous(),
+             "spatial_shapes must be a contiguous int64 [L, 2] tensor on the device of the query")
+    out = []
+    for name, ref in named_refs:
+        if ref is None:
+            out.append(None)
+            continue
+        _require(isinstance(ref, torch.Tensor) and ref.is_floating_point(), "%s must be a floating-point tensor" % name)
+        _require(ref.device == y.device, "%s must be on the same device as the query" % name)
+        _require(ref.shape[-1] in (2, 4), "Last dim of reference_points must be 2 or 4, but get %d instead." % ref.shape[-1])
+        out.append(ref.to(y.dtype).contiguous())
+    return out
+
+
 class MSDeformPrepFunction(Function):
     """Joint softmax + sampling-location arithmetic of the (temporal) modules as one fused pass each way
     (include/msda.h msda_prep_forward/backward).
@@ -269,9 +292,17 @@ class MSDeformPrepFunction(Function):
         R, M, L, Pc, _ = off_c.shape
         W = 0 if off_t is None else off_t.shape[2] // L
         Pt = 1 if off_t is None else off_t.shape[3]
-        off_c, logit_c, ref_c = off_c.contiguous(), logit_c.contiguous(), ref_c.contiguous()
+        ctx.ref_dtypes = (ref_c.dtype if isinstance(ref_c, torch.Tensor) else None,
+                          ref_t.dtype if isinstance(ref_t, torch.Tensor) else None)
+        ref_c, ref_t = _check_prep_inputs(off_c, (("reference_points", ref_c), ("temporal reference_points", ref_t if W else None)), shapes)
+        _require(logit_c.dtype == off_c.dtype and logit_c.device == off_c.device, "offsets / logits must share dtype and device")
+        off_c, logit_c = off_c.contiguous(), logit_c.contiguous()
+        _require(tuple(ref_c.shape) == (R, L, ref_c.shape[-1]), "reference_points must be [rows, L, 2|4]")
         if W:
-            off_t, logit_t, ref_t = off_t.contiguous(), logit_t.contiguous(), ref_t.contiguous()
+            _require(off_t.dtype == off_c.dtype and logit_t.dtype == off_c.dtype, "offsets / logits must share one dtype")
+            _require(tuple(ref_t.shape) == (R, W * L, ref_t.shape[-1]) and ref_t.shape[-1] == ref_c.shape[-1],
+                     "temporal reference_points must be [rows, window*L, 2|4]")
+            off_t, logit_t = off_t.contiguous(), logit_t.contiguous()
         loc_c, aw_c = torch.empty_like(off_c), torch.empty((R, M, L, Pc), dtype=off_c.dtype, device=off_c.device)
         loc_t = torch.empty_like(off_t) if W else None
         aw_t = torch.empty((R, M, W * L, Pt), dtype=off_c.dtype, device=off_c.device) if W else None
@@ -305,8 +336,8 @@ class MSDeformPrepFunction(Function):
                 return g
             return torch.cat((g, (gloc * (off / P * 0.5)).sum((1, 3))), -1)
 
-        gref_c = ref_grad(gloc_c, off_c, ref_c, Pc) if ctx.needs_input_grad[4] else None
-        gref_t = ref_grad(gloc_t, off_t, ref_t, Pt) if (W and ctx.needs_input_grad[5]) else None
+        gref_c = ref_grad(gloc_c, off_c, ref_c, Pc).to(ctx.ref_dtypes[0]) if ctx.needs_input_grad[4] else None
+        gref_t = ref_grad(gloc_t, off_t, ref_t, Pt).to(ctx.ref_dtypes[1]) if (W and ctx.needs_input_grad[5]) else None
         return goff_c, goff_t, glogit_c, glogit_t, gref_c, gref_t, None
 
 
@@ -331,8 +362,13 @@ class MSDeformPrepFusedFunction(Function):
         cols = MSDeformPrepFusedFunction._cols(M, L, W, Pc, Pt)
         assert y.shape[1] == cols[3][1]
         v = [y[:, a:b] for a, b in cols]
-        ref_c = ref_c.contiguous()
-        ref_t = ref_t.contiguous() if W else None
+        ctx.ref_dtypes = (ref_c.dtype if isinstance(ref_c, torch.Tensor) else None,
+                          ref_t.dtype if isinstance(ref_t, torch.Tensor) else None)
+        ref_c, ref_t = _check_prep_inputs(y, (("reference_points", ref_c), ("temporal reference_points", ref_t if W else None)), shapes)
+        _require(tuple(ref_c.shape) == (R, L, ref_c.shape[-1]), "reference_points must be [rows, L, 2|4]")
+        if W:
+            _require(tuple(ref_t.shape) == (R, W * L, ref_t.shape[-1]) and ref_t.shape[-1] == ref_c.shape[-1],
+                     "temporal reference_points must be [rows, window*L, 2|4]")
         loc_c = torch.empty((R, M, L, Pc, 2), dtype=y.dtype, device=y.device)
         aw_c = torch.empty((R, M, L, Pc), dtype=y.dtype, device=y.device)
         loc_t = torch.empty((R, M, W * L, Pt, 2), dtype=y.dtype, device=y.device) if W else None
@@ -366,6 +402,6 @@ class MSDeformPrepFusedFunction(Function):
             off = off2d.reshape(gloc.shape)
             return torch.cat((gsum, (gloc * (off / P * 0.5)).sum((1, 3))), -1)
 
-        gref_c = ref_grad(gloc_c, y[:, cols[0][0]:cols[0][1]], ref_c, Pc) if ctx.needs_input_grad[1] else None
-        gref_t = ref_grad(gloc_t, y[:, cols[1][0]:cols[1][1]], ref_t, Pt) if (W and ctx.needs_input_grad[2]) else None
+        gref_c = ref_grad(gloc_c, y[:, cols[0][0]:cols[0][1]], ref_c, Pc).to(ctx.ref_dtypes[0]) if ctx.needs_input_grad[1] else None
+        gref_t = ref_grad(gloc_t, y[:, cols[1][0]:cols[1][1]], ref_t, Pt).to(ctx.ref_dtypes[1]) if (W and ctx.needs_input_grad[2]) else None
         return gy, gref_c, gref_t, None, None, None, None, None, None

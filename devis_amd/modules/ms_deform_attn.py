@@ -206,7 +206,7 @@ class TemporalMSDeformAttnBase(nn.Module):
         T, Len_q, _ = query.shape
         M, L, W = self.n_heads, self.n_levels, self.t_window
         Pc, Pt = self.n_curr_points, self.n_temporal_points
-        value = project_value(input_flatten, self.value_proj, M, None, self.value_pad_heads)     # [T,S,M,D], padded rows
+        value = project_value(input_flatten, self.value_proj, M, None, self._pad_heads(T))     # [T,S,M,D], padded rows
         temporal_offsets = self.temporal_sampling_offsets(query).view(T, Len_q, M, W * L, Pt, 2)
         logits = torch.cat([self.attention_weights(query).view(T, Len_q, M, L * Pc),
                             self.temporal_attention_weights(query).view(T, Len_q, M, W * L * Pt)], 3)
@@ -233,7 +233,7 @@ class TemporalMSDeformAttnBase(nn.Module):
             loc_temp = _locations(ref_temp[:, :, None, :, None, :], off_temp, normalizer.repeat(W, 1), Pt)
             return value, loc_curr, loc_temp, w_curr, w_temp
         R = T * Len_q
-        value = project_value(input_flatten, self.value_proj, M, None, self.value_pad_heads)
+        value = project_value(input_flatten, self.value_proj, M, None, self._pad_heads(T))
         # the four query-side Linears as ONE GEMM (same parameters, concatenated on the fly); the fused pass reads
         # its output as column slices and returns one gradient matrix, so their backward is one dgrad + one wgrad
         lins = (self.sampling_offsets, self.temporal_sampling_offsets, self.attention_weights,
@@ -244,6 +244,12 @@ class TemporalMSDeformAttnBase(nn.Module):
             M, L, W, Pc, Pt)
         return (value, loc_c.view(T, Len_q, M, L, Pc, 2), loc_t.view(T, Len_q, M, W * L, Pt, 2),
                 w_c.view(T, Len_q, M, L, Pc), w_t.view(T, Len_q, M, W * L, Pt))
+
+    def _pad_heads(self, n_frames):
+        """Spare head slots of the padded `value` layout.  With 1 + frames*window >= 64 sources (e.g. a connect-all
+        decoder over >= 9 frames) the scatter kernels do not apply and the one-kernel atomic backward only takes the
+        reference's dense layout: padding would push the backward onto the slow generic kernel."""
+        return 0 if 1 + n_frames * self.t_window > 63 else self.value_pad_heads
 
     _table_cache = None     # (offset tensors, n_frames, device, table): shared by all layers of a transformer
 
@@ -260,6 +266,12 @@ class TemporalMSDeformAttnBase(nn.Module):
             return cached[3]
         table = torch.stack([o.to(device) for o in temporal_offsets]) \
             + torch.arange(n_frames, device=device)[:, None]
+        # The reference indexes value[temporal_offsets[t] + t] (ref :339, :445) with Python semantics: a negative
+        # index wraps once, anything else out of range raises.  The kernels take absolute frame ids in [0, T), so the
+        # table is normalised and checked here -- once per list of offset tensors (the result is cached).
+        table = torch.where(table < 0, table + n_frames, table)
+        if bool(((table < 0) | (table >= n_frames)).any()):
+            raise IndexError("temporal_offsets point outside the clip's %d frames" % n_frames)
         table = table.to(torch.int32).contiguous()
         TemporalMSDeformAttnBase._table_cache = ([(o, o._version) for o in temporal_offsets], n_frames, device, table)
         return table

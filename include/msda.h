@@ -107,9 +107,11 @@ int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,
  *   grad_value        [N, S, M, D]         float (double for MSDA_F64); fully overwritten (need not be zeroed)
  *   grad_sampling_loc [N, Lq, M, L, P, 2]  dtype, fully overwritten (skipped points get 0)
  *   grad_attn_weight  [N, Lq, M, L, P]     dtype, fully overwritten
- *   workspace         device scratch private to this call until it completes, `workspace_bytes` long, whose
- *                     FIRST MSDA_BWD_WORKSPACE_BYTES are zero-filled by the caller (work-ticket counters of
- *                     the scatter pass: dynamic scheduling).  With at least msda_backward_workspace_bytes()
+ *   workspace         device scratch private to this call until it completes, `workspace_bytes` long.  Its
+ *                     first MSDA_BWD_WORKSPACE_BYTES hold the work-ticket counters of the scatter pass (dynamic
+ *                     scheduling); since ABI v8 the library zeroes them itself (in the gather pass that
+ *                     precedes the scatter on the stream), the caller passes uninitialised memory.
+ *                     With at least msda_backward_workspace_bytes()
  *                     bytes the gather pass also leaves, per (row, level), the interval of pixel rows its
  *                     taps touch, and the scatter pass culls the rows that cannot reach its band -- a large
  *                     win whenever sampling is local (encoder) or clustered (decoder).  NULL / 0 is allowed

@@ -168,3 +168,33 @@ def test_project_value_padded_equals_dense_linear():
         for a, b in zip(res[0], other):
             torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-13)
     assert (res[1][0][mask] == 0).all()
+
+
+def test_cached_argument_builders_match_the_reference_formulas():
+    """level tables, encoder reference points and temporal tables, cached per pyramid, equal the
+    reference's inline code (deformable_transformer.py:69-94,185-198; devis_transformer.py:94-118,147-158) bit for
+    bit, and repeated calls hand back the same objects."""
+    from devis_amd import argument_builders as ab
+    shapes = [(12, 20), (6, 10), (3, 5)]
+    dev = torch.device("cpu")
+    ss, lsi = ab.level_tables(shapes, dev)
+    ref_ss = torch.as_tensor(shapes, dtype=torch.long)
+    assert torch.equal(ss, ref_ss) and torch.equal(lsi, torch.cat((ref_ss.new_zeros((1,)), ref_ss.prod(1).cumsum(0)[:-1])))
+    assert ab.level_tables(shapes, dev)[0] is ss
+    vr = torch.rand(2, 3, 2, generator=torch.Generator().manual_seed(5)) * 0.5 + 0.5
+    lst = []
+    for lvl, (H_, W_) in enumerate(shapes):           # the reference's get_reference_points, restated
+        ry, rx = torch.meshgrid(torch.linspace(0.5, H_ - 0.5, H_), torch.linspace(0.5, W_ - 0.5, W_), indexing='ij')
+        ry = ry.reshape(-1)[None] / (vr[:, None, lvl, 1] * H_)
+        rx = rx.reshape(-1)[None] / (vr[:, None, lvl, 0] * W_)
+        lst.append(torch.stack((rx, ry), -1))
+    want = torch.cat(lst, 1)[:, :, None] * vr[:, None]
+    assert torch.equal(ab.reference_points(shapes, vr, dev), want)
+    T = 5
+    offs, rep, start = ab.temporal_tables(ss, T, dev)
+    for t in range(T):
+        assert offs[t].tolist() == [u for u in range(-t, T - t) if u != 0]
+    assert torch.equal(rep, ss.repeat(T - 1, 1)) and torch.equal(start, torch.cat((rep.new_zeros((1,)), rep.prod(1).cumsum(0)[:-1])))
+    assert ab.temporal_tables(ss, T, dev)[0][2] is offs[2]
+    offs_w, rep_w, _ = ab.temporal_tables(ss, T, dev, t_window=2)
+    assert [o.tolist() for o in offs_w] == [[1, 1], [-1, 1], [-1, 1], [-1, 1], [-1, -1]] and rep_w.shape[0] == 2 * len(shapes)
