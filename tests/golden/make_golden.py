@@ -290,10 +290,29 @@ def make_module_fixtures(Mo):
     torch.set_default_dtype(torch.float32)
 
 
+def make_config_sized_fixtures(Mo):
+    """SURVEY 8c harness row: one config-sized case per temporal module (DeVIS cfg3 dimensions: C=256, M=8, L=4, T=6,
+    300 queries per frame / Lq = S, pyramid of the 360x640 test size), run through the REFERENCE modules in fp64 on the
+    CPU.  Parameters and inputs come from seeds (tests/module_cases.py::cfg_build, shared with the test), the fixture
+    stores statistics and a strided subsample of every output and gradient: a few hundred KB."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import module_cases
+    for kind, cls in (("dec", Mo.TemporalMSDeformAttnDecoder), ("enc", Mo.TemporalMSDeformAttnEncoder)):
+        got = module_cases.cfg_run(kind, cls)
+        d = {}
+        for k, v in got.items():
+            smp = module_cases.cfg_sample(v)
+            d[k + "/sample"], d[k + "/stats"] = smp["sample"], smp["stats"]
+        np.savez_compressed(os.path.join(HERE, "cfg_%s.npz" % kind), **d)
+        print("wrote cfg_%s: %d arrays, |out| max %.3e" % (kind, len(got), np.abs(got["out"]).max()))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF_OPS):
         sys.exit("reference not present: golden vectors can only be regenerated in the build container")
     F, Mo = import_reference()
-    make_op_fixtures(F)
-    make_module_fixtures(Mo)
+    if "--config-sized-only" not in sys.argv:
+        make_op_fixtures(F)
+        make_module_fixtures(Mo)
+    make_config_sized_fixtures(Mo)
     os.system("du -sh %s" % HERE)

@@ -77,3 +77,72 @@ def compare(got, g, rtol, atol):
         scale = max(1.0, float(np.abs(exp).max()))
         err = float(np.abs(a - exp).max())
         assert err <= atol * scale + rtol * scale, (k, err, scale)
+
+
+# ---- config-sized cases (DeVIS cfg3 dimensions): parameters and inputs are regenerated from seeds on the CPU, the
+# fixture (tests/golden/cfg_*.npz, made from the REFERENCE modules by make_golden.py) holds statistics and a strided
+# subsample of every output and gradient.
+CFG = dict(C=256, M=8, L=4, T=6, q=300, Pc=4, Pt=4, pyramid=[(45, 80), (23, 40), (12, 20), (6, 10)])
+
+
+def cfg_sample(a):
+    """Strided subsample + statistics of one array (what the fixture stores)."""
+    a = np.asarray(a, dtype=np.float64)
+    flat = a.reshape(-1)
+    step = max(1, flat.size // 4096)
+    return {"sample": flat[::step][:4096].copy(), "stats": np.array([flat.sum(), np.abs(flat).sum(), np.square(flat).sum(),
+                                                                      flat.min(), flat.max()])}
+
+
+def cfg_build(kind, module_cls, dtype=torch.float64):
+    """(module, args, names of the args that get gradients) for kind in {'dec', 'enc'}; `module_cls` is the reference's
+    or our TemporalMSDeformAttn{Decoder,Encoder}.  Everything is drawn on the CPU in float64 from fixed seeds."""
+    c = CFG
+    T, C, L, M, q = c["T"], c["C"], c["L"], c["M"], c["q"]
+    g = torch.Generator().manual_seed(7000 + (0 if kind == "dec" else 1))
+    mod = module_cls(T, C, L, T - 1, M, c["Pc"], c["Pt"]) if kind == "enc" else \
+        module_cls(T, C, L, T - 1, M, c["Pc"], c["Pt"], dec_instance_aware_att=True)
+    mod = mod.double()
+    with torch.no_grad():
+        for k, p in sorted(mod.named_parameters()):
+            # offsets in the pixel range a trained model uses; small logits; O(1/sqrt(C)) projections
+            scale = 0.02 if "sampling_offsets.weight" in k else 0.5 if "sampling_offsets.bias" in k else 0.05
+            p.copy_(torch.randn(p.shape, generator=g, dtype=torch.float64) * scale)
+    shapes = torch.as_tensor(c["pyramid"], dtype=torch.long)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    t_shapes = shapes.repeat(T - 1, 1)
+    t_lsi = torch.cat((t_shapes.new_zeros((1,)), t_shapes.prod(1).cumsum(0)[:-1]))
+    offsets = [torch.tensor([t for t in range(-f, T - f) if t != 0]) for f in range(T)]
+    src = torch.randn(T, S, C, generator=g, dtype=torch.float64)
+    if kind == "dec":
+        query = torch.randn(1, T * q, C, generator=g, dtype=torch.float64)
+        ref = torch.rand(1, T * q, L, 2, generator=g, dtype=torch.float64) * 0.8 + 0.1
+    else:
+        query = torch.randn(T, S, C, generator=g, dtype=torch.float64)
+        centres = torch.cat([torch.stack(torch.meshgrid((torch.arange(h, dtype=torch.float64) + 0.5) / h,
+                                                         (torch.arange(w, dtype=torch.float64) + 0.5) / w, indexing="ij"), -1)
+                             .reshape(-1, 2).flip(-1) for h, w in c["pyramid"]], 0)
+        ref = centres[None, :, None, :].expand(T, S, L, 2).contiguous()
+    loss_w = torch.randn(query.shape[0] if kind == "enc" else 1, query.shape[1], C, generator=g, dtype=torch.float64)
+    args = [query.to(dtype), ref.to(dtype), src.to(dtype), (shapes, t_shapes), (lsi, t_lsi), offsets]
+    return mod.to(dtype), args, loss_w.to(dtype)
+
+
+def cfg_run(kind, module_cls, device="cpu", dtype=torch.float64):
+    mod, args, loss_w = cfg_build(kind, module_cls, dtype)
+    mod = mod.to(device)
+    mv = lambda x: x.to(device) if isinstance(x, torch.Tensor) else type(x)(y.to(device) for y in x)
+    args = [mv(a) for a in args]
+    args[0].requires_grad_(True); args[2].requires_grad_(True)
+    ret = mod(*args)
+    out = ret[0]
+    params = [p for _, p in sorted(mod.named_parameters())]
+    grads = torch.autograd.grad((out * loss_w.to(device)).sum(), [args[0], args[2]] + params)
+    got = {"out": out, "grad/query": grads[0], "grad/input_flatten": grads[1]}
+    for (k, _), gr in zip(sorted(mod.named_parameters()), grads[2:]):
+        got["grad/" + k] = gr
+    if kind == "dec":
+        got["aux/curr_loc/3"], got["aux/temp_loc/3"] = ret[1][3], ret[2][3]
+        got["aux/aw_curr"], got["aux/aw_temp"] = ret[3], ret[4]
+    return {k: v.detach().double().cpu().numpy() for k, v in got.items()}

@@ -183,3 +183,35 @@ def test_frame_table_wraps_negative_offsets_and_rejects_out_of_range():
     bad = [torch.tensor([1, 2], device=DEV) for _ in range(T)]      # frame T-1 + 1 = T: out of range
     with pytest.raises(IndexError):
         TemporalMSDeformAttnBase._frame_table(bad, T, torch.device(DEV))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 1e-4)], ids=["f64", "f32"])
+@pytest.mark.parametrize("kind", ["dec", "enc"])
+def test_config_sized_modules_vs_reference_fixture(kind, dtype, tol):
+    """SURVEY 8c harness row: the temporal decoder / encoder at DeVIS's real size (C=256, M=8, L=4, T=6, 300 queries
+    per frame resp. Lq = S = 4820, 360x640 pyramid) against the fixture captured from the REFERENCE modules
+    (tests/golden/cfg_*.npz: statistics + a strided subsample of every output and gradient; parameters and inputs
+    are regenerated from the same seeds).  fp64 pins the arithmetic, fp32 the BASELINE bar of 1e-4."""
+    from conftest import golden
+    from devis_amd.modules import TemporalMSDeformAttnDecoder, TemporalMSDeformAttnEncoder
+    g = golden("cfg_" + kind)
+    cls = TemporalMSDeformAttnDecoder if kind == "dec" else TemporalMSDeformAttnEncoder
+    got = module_cases.cfg_run(kind, cls, device=DEV, dtype=dtype)
+    assert sorted(k + "/sample" for k in got) == sorted(k for k in g if k.endswith("/sample"))
+    for k, v in got.items():
+        mine = module_cases.cfg_sample(v)
+        want_s, want_t = g[k + "/sample"], g[k + "/stats"]
+        scale = max(1.0, float(np.abs(want_s).max()), abs(float(want_t[3])), abs(float(want_t[4])))
+        assert mine["sample"].shape == want_s.shape, k
+        if dtype == torch.float32 and k.startswith("grad/"):
+            # fp32 gradients: a location within rounding distance of a cell border takes the neighbouring cell's
+            # (piecewise constant) derivative -- isolated terms differ at 1e-3: a norm-wise bound
+            err = np.abs(mine["sample"] - want_s)
+            assert float(np.linalg.norm(err) / max(1e-12, np.linalg.norm(want_s))) <= 5e-3, k
+            continue
+        assert float(np.abs(mine["sample"] - want_s).max()) <= tol * scale, (k, float(np.abs(mine["sample"] - want_s).max()), scale)
+        # sums over the WHOLE tensor: catches an error anywhere, not only at the sampled positions
+        n = v.size
+        assert abs(mine["stats"][0] - want_t[0]) <= tol * scale * n ** 0.5 * 4 + tol * abs(want_t[0]), (k, "sum")
+        assert abs(mine["stats"][1] - want_t[1]) <= tol * (want_t[1] + scale), (k, "abs-sum")
+        assert abs(mine["stats"][2] - want_t[2]) <= 4 * tol * (want_t[2] + scale), (k, "square-sum")
