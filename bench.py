@@ -67,6 +67,7 @@ def parse_args():
                     help="dense = the reference's [N,S,M,D]; padded = one spare head slot per pixel row, what "
                          "devis_amd's modules feed the op (functions.project_value; DESIGN.md section 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the extra keys for the other BASELINE configs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -109,6 +110,29 @@ def make_clip_batch(args, device, dtype, seed):
                 grad_out=dev(grad_out), dims=(T, q, M, D, L, P, W, S))
 
 
+ROUTE_KERNELS = [   # msda_last_route() phrase -> kernel symbol
+    ("resident-slab kernel", "msda_fwd_rs_kernel"), ("forward (slab kernel)", "msda_fwd_slab_kernel"),
+    ("forward (tile kernel)", "msda_fwd_tile_kernel"), ("forward (generic kernel)", "msda_fwd_generic_kernel"),
+    ("slab kernel, grad_loc/grad_attn", "msda_bwd_slab_kernel"), ("tile kernel, grad_loc/grad_attn", "msda_bwd_tile_kernel"),
+    ("owner-computes scatter", "msda_bwd_value_own_kernel"), ("per-point culling", "msda_bwd_value_points_kernel"),
+    ("LDS scatter kernel)", "msda_bwd_value_lds_kernel"), ("global atomics", "msda_bwd_tile_kernel<atomics>"),
+    ("backward (generic kernel)", "msda_bwd_generic_kernel"),
+]
+
+
+def kernel_name(route, what):
+    """Kernel symbol of the forward / gather pass / scatter in a msda_last_route() string."""
+    parts = [x.strip() for x in route.split(";")]
+    pick = {"forward": [x for x in parts if "forward" in x],
+            "gather": [x for x in parts if "grad_loc/grad_attn" in x or "global atomics" in x or "generic" in x],
+            "scatter": [x for x in parts if "scatter" in x]}[what]
+    for x in pick:
+        for phrase, name in ROUTE_KERNELS:
+            if phrase in x:
+                return name
+    return "msda_%s(%s)" % (what, route)
+
+
 def algorithmic_bytes(args, e):
     """Per launch over ONE clip (DESIGN.md 'algorithmic bytes'): every tensor a kernel
     must touch counted once -- value read once (not once per gathered corner), (x, y, weight) per
@@ -124,6 +148,151 @@ def algorithmic_bytes(args, e):
     return {"fwd": T * S * C * e + points * 3 * e + T * q * C * e,
             "bwd_gather": T * S * C * e + T * q * C * e + points * 3 * e + points * 3 * e,
             "bwd_scatter": points * 3 * e + T * q * C * e + T * S * C * 4}
+
+
+def _event_ms(fn, reps, warm=3):
+    """Average duration of fn() in ms: HIP events on torch's current stream (the stream the library launches on)."""
+    st = torch.cuda.current_stream()
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for s0, e0 in ev:
+        s0.record(st)
+        fn()
+        e0.record(st)
+    torch.cuda.synchronize()
+    return sum(s0.elapsed_time(e0) for s0, e0 in ev) / reps
+
+
+def _plain_op_case(device, dtype, shapes, N, Lq, locs, seed, M=8, D=32, P=4):
+    """Synthetic inputs of one plain MSDeformAttnFunction call.  locs: 'uniform' or 'local' (query i sits on pixel i of
+    the pyramid, Lq = S, and samples N(0, (2 px)^2) around it: what an encoder layer does)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    sh = torch.tensor(shapes, dtype=torch.int64)
+    L, S = sh.shape[0], int(sh.prod(1).sum())
+    value = torch.rand(N, S, M, D, generator=g) * 2 - 1
+    if locs == "local":
+        assert Lq == S
+        centres = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w,
+                                                         indexing="ij"), -1).reshape(-1, 2).flip(-1) for h, w in shapes], 0)
+        wh = torch.stack([sh[:, 1], sh[:, 0]], -1).float()
+        loc = centres[None, :, None, None, None, :] + torch.randn(N, Lq, M, L, P, 2, generator=g) * 2.0 / wh[None, None, None, :, None, :]
+    else:
+        loc = torch.rand(N, Lq, M, L, P, 2, generator=g)
+    aw = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).reshape(N, Lq, M, L, P)
+    go = torch.randn(N, Lq, M * D, generator=g)
+    dev = lambda x: x.to(device=device, dtype=dtype).contiguous()
+    return dict(value=dev(value), shapes=sh.to(device), lsi=torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1])).to(device),
+                loc=dev(loc), aw=dev(aw), grad_out=dev(go), S=S, L=L)
+
+
+def other_configs(args, device):
+    """The BASELINE.json configurations beside the headline, as extra keys of the one JSON line (a few steps each;
+    never part of `value`): the single-clip latency of the headline call (what DeVIS issues: 1 clip per GPU,
+    main.py:85), clustered sampling locations, configs[1] (single-frame encoder attention, 800x1333, bf16) and
+    configs[4] (SwinL 480x768 pyramid, fp16, im2col_step 1 vs 64; 3-level mask-head-like call)."""
+    from devis_amd import _native
+    from devis_amd.functions import MSDeformAttnFunction, MSDeformAttnTemporalFunction
+    res = {}
+
+    def fused_case(clips, locs, dtype):
+        class A:
+            pass
+        a = A()
+        a.clips, a.frames, a.queries, a.pyramid, a.locs = clips, args.frames, args.queries, args.pyramid, locs
+        b = make_clip_batch(a, device, dtype, seed=4321)
+        leaves = [b[k].requires_grad_(True) for k in ("value", "loc_c", "aw_c", "loc_t", "aw_t")]
+
+        def step():
+            out = MSDeformAttnTemporalFunction.apply(b["value"], b["shapes"], b["lsi"], b["ftab"], b["loc_c"], b["aw_c"],
+                                                     b["loc_t"], b["aw_t"], clips)
+            torch.autograd.grad(out, leaves, b["grad_out"])
+
+        def fwd():
+            with torch.no_grad():
+                MSDeformAttnTemporalFunction.apply(b["value"], b["shapes"], b["lsi"], b["ftab"], b["loc_c"], b["aw_c"],
+                                                   b["loc_t"], b["aw_t"], clips)
+        return step, fwd, clips * args.frames * args.queries
+
+    # (i) one clip: the call DeVIS makes per decoder layer
+    step, fwd, rows = fused_case(1, "uniform", torch.float32)
+    ms, fms = _event_ms(step, 30, 10), _event_ms(fwd, 30, 10)
+    res["single_clip_latency"] = {"workload": "cfg3, ONE clip (T=%d x %d queries), fused call, f32" % (args.frames, args.queries),
+                                  "fwd_bwd_ms": round(ms, 4), "fwd_ms": round(fms, 4), "M_queries_per_s": round(rows / ms / 1e3, 3)}
+    # (ii) the headline batch with clustered locations (what a trained decoder produces)
+    step, fwd, rows = fused_case(args.clips, "clustered", torch.float32)
+    ms = _event_ms(step, 10)
+    res["clustered_locations"] = {"workload": "headline batch, reference point + N(0, (3 px)^2) offsets", "fwd_bwd_ms": round(ms, 4),
+                                  "M_queries_per_s": round(rows / ms / 1e3, 3)}
+    del step, fwd
+
+    def plain(name, dtype, shapes, N, Lq, locs, steps, reps=6, per_kernel=False):
+        c = _plain_op_case(device, dtype, shapes, N, Lq, locs, seed=99)
+        leaves = [c[k].requires_grad_(True) for k in ("value", "loc", "aw")]
+        out_rows = N * Lq
+        entry = {"workload": name}
+        for st in steps:
+            def step():
+                out = MSDeformAttnFunction.apply(c["value"], c["shapes"], c["lsi"], c["loc"], c["aw"], st)
+                torch.autograd.grad(out, leaves, c["grad_out"])
+
+            def fwd():
+                with torch.no_grad():
+                    MSDeformAttnFunction.apply(c["value"], c["shapes"], c["lsi"], c["loc"], c["aw"], st)
+            ms, fms = _event_ms(step, reps), _event_ms(fwd, reps)
+            entry["im2col_step_%d" % st] = {"fwd_ms": round(fms, 4), "fwd_bwd_ms": round(ms, 4),
+                                            "fwd_M_queries_per_s": round(out_rows / fms / 1e3, 2),
+                                            "fwd_bwd_M_queries_per_s": round(out_rows / ms / 1e3, 2)}
+        if per_kernel:      # per-kernel durations and algorithmic-byte fractions of the un-chunked call
+            e = c["value"].element_size()
+            M, D, P, L, S = 8, 32, 4, c["L"], c["S"]
+            pts = N * Lq * M * L * P
+            alg = {"fwd": N * S * M * D * e + pts * 3 * e + N * Lq * M * D * e,
+                   "gather": N * S * M * D * e + N * Lq * M * D * e + pts * 6 * e,
+                   "scatter": pts * 3 * e + N * Lq * M * D * e + N * S * M * D * 4}
+            dv = [x.detach() for x in leaves]
+            out = torch.empty((N, Lq, M * D), dtype=dtype, device=device)
+            gv = torch.empty(c["value"].shape, dtype=_native.acc_dtype(dtype), device=device)
+            gl, ga = torch.empty_like(c["loc"]), torch.empty_like(c["aw"])
+            ws = _native.bwd_workspace(device, N, Lq, M, L)
+            t = {"fwd": _event_ms(lambda: _native.forward(dv[0], c["shapes"], c["lsi"], dv[1], dv[2], out), reps)}
+            names = {"fwd": kernel_name(_native.last_route(), "forward")}
+            os.environ["MSDA_ENABLE_HOOKS"] = "1"
+            for ph, key, what in (("1", "gather", "gather"), ("2", "scatter", "scatter")):
+                os.environ["MSDA_BWD_PHASES"] = ph
+                _native.reload_knobs()
+
+                def bwd():
+                    ws[:16].zero_()
+                    load = _native.load()
+                    rc = load.msda_backward(_native.dtype_code(dtype), dv[0].data_ptr(), c["shapes"].data_ptr(), c["lsi"].data_ptr(),
+                                            dv[1].data_ptr(), dv[2].data_ptr(), c["grad_out"].data_ptr(), N, S, M, D, L, Lq, P,
+                                            gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), ws.numel() * 4, None,
+                                            _native.shapes_hint(c["shapes"]), torch.cuda.current_stream().cuda_stream)
+                    assert rc == 0, load.msda_last_error()
+                t[key] = _event_ms(bwd, reps)
+                names[key] = kernel_name(_native.last_route(), what)
+            os.environ.pop("MSDA_BWD_PHASES")
+            os.environ.pop("MSDA_ENABLE_HOOKS")
+            _native.reload_knobs()
+            entry["kernels"] = {names[k]: {"avg_ms": round(t[k], 4), "algorithmic_GBps": round(alg[k] / t[k] / 1e6, 1),
+                                           "frac_of_hbm_peak": round(alg[k] / t[k] / 1e6 / HBM_PEAK_GBS, 4)} for k in t}
+        res_key = name.split(":")[0]
+        res[res_key] = entry
+        del c, leaves
+        torch.cuda.empty_cache()
+
+    plain("cfg1_encoder_800x1333_bf16: single-frame encoder attention, N=8 images, Lq = S = 22223, L=4, K=4, M=8xD=32, bf16, "
+          "encoder-like local sampling", torch.bfloat16, PYRAMIDS["B"], 8, 22223, "local", (64,), per_kernel=True)
+    swin = [(60, 96), (30, 48), (15, 24), (8, 12)]            # SwinL training size 480x768 (src/datasets/vis.py:228-231)
+    plain("cfg4_swinl_fp16_decoder_like: plain MSDeformAttn, N = T = 6 frames as the batch, 300 queries, SwinL 480x768 pyramid, "
+          "fp16, im2col_step 1 vs 64", torch.float16, swin, 6, 300, "uniform", (1, 64))
+    plain("cfg4_swinl_fp16_encoder_like: same pyramid, Lq = S = 7656 (local sampling), fp16, im2col_step 1 vs 64",
+          torch.float16, swin, 6, 7656, "local", (1, 64))
+    plain("cfg4_mask_head_like_fp16: 3 levels (/8, /16, /32), Lq = 10 instances x 6 frames, N=1 (the reference mask head "
+          "itself holds no MSDeformAttn: deformable_segmentation.py:265 is torchvision deform_conv2d)",
+          torch.float16, swin[:3], 1, 60, "uniform", (64,))
+    return res
 
 
 def main():
@@ -279,6 +448,7 @@ def main():
 
         fwd_ms, fwd_med = time_kernel(lambda: _native.temporal_forward(
             dv[0], b["shapes"], b["lsi"], b["ftab"], dv[1], dv[2], dv[3], dv[4], args.clips, out), 20)
+        fwd_name = kernel_name(_native.last_route(), "forward")     # the kernels the library actually launched
         # the backward entry point launches two kernels; MSDA_BWD_PHASES lets each be timed alone
         ws = _native.bwd_workspace(device, args.clips * T, q, M, L * (1 + W))
         def bwd():
@@ -292,23 +462,16 @@ def main():
         os.environ["MSDA_BWD_PHASES"] = "1"
         _native.reload_knobs()
         gat_ms, gat_med = time_kernel(bwd, 20)
+        gat_name = kernel_name(_native.last_route(), "gather")
         os.environ["MSDA_BWD_PHASES"] = "2"
         _native.reload_knobs()
         sca_ms, sca_med = time_kernel(bwd, 20)
+        sca_name = kernel_name(_native.last_route(), "scatter")
         os.environ.pop("MSDA_BWD_PHASES")
         os.environ.pop("MSDA_ENABLE_HOOKS")
         _native.reload_knobs()
         e = b["value"].element_size()
         ab = algorithmic_bytes(args, e)
-        # the library runs the slab forward when there are >= 2 workgroups of 16 tiles per CU, else the tile forward
-        n_cu = torch.cuda.get_device_properties(device).multi_processor_count
-        slab_blocks = args.clips * ((T * ((q + 7) // 8) + 15) // 16) * M
-        use_slab = slab_blocks >= 2 * n_cu
-        fwd_name = "msda_fwd_slab_kernel" if (use_slab and dtype == torch.float32) else "msda_fwd_tile_kernel"
-        gat_name = "msda_bwd_slab_kernel" if use_slab else "msda_bwd_tile_kernel"
-        # <= 4 points per level: the gather pass leaves per-point culling records and the pipelined scatter runs
-        pts = max(int(b["loc_c"].shape[4]), int(b["loc_t"].shape[4]))
-        sca_name = "msda_bwd_value_points_kernel" if pts <= 4 else "msda_bwd_value_lds_kernel"
         kernels = {
             fwd_name: (fwd_ms, fwd_med, ab["fwd"]),
             gat_name + " (grad_loc/grad_attn gather pass)": (gat_ms, gat_med, ab["bwd_gather"]),
@@ -319,20 +482,22 @@ def main():
         ach = d_bytes * args.clips / (d_ms * 1e-3) / 1e9
         # HBM traffic cannot be counted from inside this process; when the run is the profiled
         # configuration, quote the committed rocprofv3 PMC result (profiles/hbm_traffic.json), else null
-        traffic = None
+        traffic, traffic_src = None, None
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
             w = prof["workload"]
             if (w["clips"], w["frames"], w["queries"], w["pyramid"], w["dtype"], w["locs"], w["pattern"]) == \
                     (args.clips, args.frames, args.queries, args.pyramid, args.dtype, args.locs, args.pattern) \
                     and args.value_layout == "dense":
-                k = prof["kernels"][dom]
+                k = prof["kernels"][dom.split(" ")[0]]
                 traffic = k["fetch_bytes"] + k["write_bytes"]
+                traffic_src = prof.get("source", "profiles/hbm_traffic.json")
         except (OSError, KeyError, ValueError):
             traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": d_bytes * args.clips, "avg_launch_ms": round(d_ms, 4)}
+                    "algorithmic_bytes_per_launch": d_bytes * args.clips, "avg_launch_ms": round(d_ms, 4),
+                    "traffic_source": traffic_src}
         extra = {"kernels": {k: {"avg_ms": round(v[0], 4), "median_ms": round(v[1], 4),
                                  "algorithmic_GBps": round(v[2] * args.clips / (v[0] * 1e-3) / 1e9, 1),
                                  "frac_of_hbm_peak": round(v[2] * args.clips / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
@@ -371,6 +536,19 @@ def main():
                          "oracle.grid_sample_forward in the reference's call pattern, %.1f s, %d torch threads"
                          % (n, q, args.pyramid, dt, cores)}
 
+    # every rank contributes a one: the SCALE record can check that RCCL really saw N ranks
+    ranks_seen = 1
+    if world > 1:
+        import torch.distributed as dist
+        ones = torch.ones(1, device=device, dtype=torch.int32)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(ones.item())
+    others = None
+    if rank == 0 and world == 1 and not args.no_other_configs and args.mode == "clip-parallel":
+        del b, leaves
+        torch.cuda.empty_cache()
+        others = other_configs(args, device)
+
     if rank == 0:
         line = {
             "metric": "MSDeformAttn fwd+bwd M-queries/s at T=6,L=4,K=4,C=256", "value": round(value, 3),
@@ -385,9 +563,11 @@ def main():
                        "clips_per_gpu": args.clips, "query_rows_per_step": rows_per_step,
                        "parallelism": ("clip-parallel x%d (no data-path collective)" % world) if args.mode == "clip-parallel"
                        else "one clip sharded x%d (all-gather value / reduce-scatter grad_value over RCCL)" % world},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "ranks_seen": ranks_seen,
         }
         line.update(extra)
+        if others is not None:
+            line["other_configs"] = others
         if padded_line is not None:
             line["padded_value_layout"] = padded_line
         print(json.dumps(line), flush=True)

@@ -19,7 +19,7 @@ _DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.floa
 EXPORTED_SYMBOLS = (
     "msda_version", "msda_last_error", "msda_forward", "msda_backward",
     "msda_temporal_forward", "msda_temporal_backward", "msda_backward_workspace_bytes",
-    "msda_prep_forward", "msda_prep_backward", "msda_reload_knobs",
+    "msda_prep_forward", "msda_prep_backward", "msda_reload_knobs", "msda_last_route",
 )
 
 _lib = None
@@ -64,6 +64,7 @@ def load():
         lib.msda_temporal_backward.argtypes = [_ci] + [_vp] * 9 + [_ci] * 10 + [_vp] * 6 + [ctypes.c_longlong, _vp, _vp, _vp]
         lib.msda_prep_forward.restype = _ci
         lib.msda_prep_forward.argtypes = [_ci] + [_vp] * 7 + [ctypes.c_longlong] + [_ci] * 6 + [ctypes.c_longlong] + [_vp] * 5
+        lib.msda_last_route.restype = ctypes.c_char_p
         lib.msda_reload_knobs.restype = None
         lib.msda_reload_knobs.argtypes = []
         lib.msda_prep_backward.restype = _ci
@@ -75,6 +76,11 @@ def load():
 def reload_knobs():
     """Re-read the MSDA_* test / measurement knobs (honoured only with MSDA_ENABLE_HOOKS=1; include/msda.h)."""
     load().msda_reload_knobs()
+
+
+def last_route():
+    """Kernels launched by the last library call of this thread (include/msda.h msda_last_route)."""
+    return load().msda_last_route().decode("utf-8", "replace")
 
 
 def dtype_code(dtype):

@@ -3105,8 +3105,12 @@ int fail(int code, const char *fmt, const char *detail = "")
     return code;
 }
 
+thread_local char g_route[512] = "";     // kernels launched by the last entry-point call of this thread (msda_last_route)
+
 int check_launch(const char *what)
 {
+    const size_t used = strlen(g_route);
+    if (used + 3 < sizeof(g_route)) snprintf(g_route + used, sizeof(g_route) - used, "%s%s", used ? "; " : "", what);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
@@ -3609,6 +3613,8 @@ int msda_version(void) { return MSDA_ABI_VERSION; }
 
 void msda_reload_knobs(void) { load_knobs(); }
 
+const char *msda_last_route(void) { return g_route; }
+
 long long msda_backward_workspace_bytes(int batch, int num_query, int num_heads, int virtual_levels)
 {
     return workspace_need(batch, num_query, num_heads, virtual_levels);
@@ -3622,7 +3628,7 @@ int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,
                  int num_query, int num_point, void *out, const int64_t *value_strides,
                  const int64_t *spatial_shapes_host, void *stream)
 {
-    g_err[0] = 0;
+    g_err[0] = 0; g_route[0] = 0;
     int rc = check_common(value, spatial_shapes, level_start_index, batch, spatial_size, num_heads,
                           channels, num_levels, num_query);
     if (rc) return rc;
@@ -3651,7 +3657,7 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
                   void *workspace, long long workspace_bytes, const int64_t *value_strides,
                   const int64_t *spatial_shapes_host, void *stream)
 {
-    g_err[0] = 0;
+    g_err[0] = 0; g_route[0] = 0;
     int rc = check_common(value, spatial_shapes, level_start_index, batch, spatial_size, num_heads,
                           channels, num_levels, num_query);
     if (rc) return rc;
@@ -3684,7 +3690,7 @@ int msda_temporal_forward(int dtype, const void *value, const int64_t *spatial_s
                           int num_curr_point, int num_temp_point, void *out, const int64_t *value_strides,
                           const int64_t *spatial_shapes_host, void *stream)
 {
-    g_err[0] = 0;
+    g_err[0] = 0; g_route[0] = 0;
     int rc = check_common(value, spatial_shapes, level_start_index, clips, spatial_size, num_heads,
                           channels, num_levels, num_query);
     if (rc) return rc;
@@ -3718,7 +3724,7 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
                            void *grad_loc_temp, void *grad_aw_temp, void *workspace, long long workspace_bytes,
                            const int64_t *value_strides, const int64_t *spatial_shapes_host, void *stream)
 {
-    g_err[0] = 0;
+    g_err[0] = 0; g_route[0] = 0;
     int rc = check_common(value, spatial_shapes, level_start_index, clips, spatial_size, num_heads,
                           channels, num_levels, num_query);
     if (rc) return rc;
@@ -3753,7 +3759,7 @@ int msda_prep_forward(int dtype, const void *offsets_curr, const void *offsets_t
                       int num_curr_point, int num_temp_point, int ref_dim, long long raw_row_stride,
                       void *loc_curr, void *loc_temp, void *aw_curr, void *aw_temp, void *stream)
 {
-    g_err[0] = 0;
+    g_err[0] = 0; g_route[0] = 0;
     PrepParams p;
     memset(&p, 0, sizeof(p));
     p.off_c = offsets_curr; p.off_t = offsets_temp; p.logit_c = logits_curr; p.logit_t = logits_temp;
@@ -3774,7 +3780,7 @@ int msda_prep_backward(int dtype, const void *grad_loc_curr, const void *grad_lo
                        long long raw_row_stride, void *grad_offsets_curr, void *grad_offsets_temp,
                        void *grad_logits_curr, void *grad_logits_temp, void *stream)
 {
-    g_err[0] = 0;
+    g_err[0] = 0; g_route[0] = 0;
     PrepParams p;
     memset(&p, 0, sizeof(p));
     p.gloc_c = grad_loc_curr; p.gloc_t = grad_loc_temp; p.gaw_c = grad_aw_curr; p.gaw_t = grad_aw_temp;

@@ -76,6 +76,10 @@ const char *msda_last_error(void);
 /* Re-read the test / measurement knobs from the environment (see Conventions).  Not for production use. */
 void msda_reload_knobs(void);
 
+/* Thread-local, human-readable list of the kernels the last entry-point call of this thread launched
+ * ("msda forward (resident-slab kernel); ...").  For tests, benchmarks and bug reports. */
+const char *msda_last_route(void);
+
 /*
  * Forward of one MSDeformAttnFunction call.
  * Replaces ms_deform_attn_forward (vision.cpp:14 -> ms_deform_attn_cuda.cu:20-80 ->

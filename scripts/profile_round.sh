@@ -1,0 +1,20 @@
+#!/bin/bash
+# One profiling round on the GPU box: bench line, rocprofv3 kernel-trace stats of the same command, and the HBM-traffic
+# PMC passes (FETCH_SIZE / WRITE_SIZE / L2 hit-miss, separate passes, never combined with a trace).
+# usage: scripts/profile_round.sh <tag>     -> gpurun_out/<tag>/{bench.json,kernel_stats.csv,pmc_hbm.txt}
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/$1
+mkdir -p "$O"
+cd "$R"
+python3 bench.py > "$O/bench.json" 2> "$O/bench.err"
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs > "$O/kt.log" 2>&1
+f=$(find "$O/kt" -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && cp "$f" "$O/kernel_stats.csv"
+rm -rf "$O/kt"
+cd "$R"
+bash scripts/pmc_passes.sh "$O/pmc" scripts/step_only.py scripts/pmc_groups_hbm.txt
+cp "$O/pmc/summary.txt" "$O/pmc_hbm.txt" 2>/dev/null
+rm -rf "$O/pmc"
+tail -c 400 "$O/bench.json"; echo; head -12 "$O/kernel_stats.csv"; cat "$O/pmc_hbm.txt"
