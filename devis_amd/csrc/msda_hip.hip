@@ -2124,22 +2124,45 @@ constexpr int kOwnThreads = 1024;
 constexpr int kOwnQuads = kOwnThreads / 4;
 constexpr int kOwnSlots = 4;                        // pixels per owner quad
 constexpr int kOwnPix = kOwnQuads * kOwnSlots;      // pixels per band
-constexpr int kOwnChunk = 768;                      // hits per chunk: their grad_out rows live in LDS (96 KiB)
-constexpr int kOwnList = kOwnChunk + 4 * kOwnThreads;   // survivor list: a chunk's worth + one cull batch, worst case
+// hits per chunk: their grad_out rows live in LDS (128 B per fp32 row: 768 hits = 96 KiB; 64 B per 16-bit row: one hit
+// per thread = 64 KiB)
+template <typename T> constexpr int own_chunk() { return sizeof(T) == 4 ? 768 : kOwnThreads; }
+template <typename T> constexpr int own_list() { return own_chunk<T>() + 4 * kOwnThreads; }   // a chunk's worth + one cull batch, worst case
 constexpr unsigned kOwnNil = 0xffffffffu;
-constexpr int kOwnLdsBytes = kOwnChunk * 128 + 4 * kOwnChunk * 8 + kOwnPix * 4 + kOwnList * 4;
+template <typename T> constexpr int own_lds_bytes()
+{
+    return own_chunk<T>() * 32 * (int)sizeof(T) + 4 * own_chunk<T>() * 8 + kOwnPix * 4 + own_list<T>() * 4;
+}
+
+// (x, y) of one sampling point: one 8- / 4-byte load
+__device__ __forceinline__ void load_xy(const float *loc2, float &x, float &y)
+{
+    const float2 v = *reinterpret_cast<const float2 *>(loc2);
+    x = v.x; y = v.y;
+}
+__device__ __forceinline__ void load_xy(const bf16_t *loc2, float &x, float &y)
+{
+    const unsigned v = *reinterpret_cast<const unsigned *>(loc2);
+    x = __uint_as_float(v << 16); y = __uint_as_float(v & 0xffff0000u);
+}
+__device__ __forceinline__ void load_xy(const f16_t *loc2, float &x, float &y)
+{
+    const float2 v = __half22float2(*reinterpret_cast<const __half2 *>(loc2));
+    x = v.x; y = v.y;
+}
 
 template <typename T, int VARIANT>       // VARIANT bit 1: the next chunk's hits are fetched before the walk (bit 0: unused)
 __global__ void __launch_bounds__(kOwnThreads)
 msda_bwd_value_own_kernel(const Params p, int dbg)
 {
-    static_assert(sizeof(T) == 4, "owner-computes scatter: 4-byte storage types");
-    constexpr int D = 32;
+    constexpr int D = 32, kRowB = D * (int)sizeof(T);          // bytes of one staged grad_out row
+    constexpr int kOwnChunk = own_chunk<T>();
+    constexpr bool kHalf = sizeof(T) == 2;
     extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];
-    unsigned char *rows = lds_raw;                                              // [kOwnChunk][128 B]
-    uint2 *ents = reinterpret_cast<uint2 *>(lds_raw + kOwnChunk * 128);         // [4 * kOwnChunk] {weight bits, next}
+    unsigned char *rows = lds_raw;                                              // [kOwnChunk][kRowB]
+    uint2 *ents = reinterpret_cast<uint2 *>(lds_raw + kOwnChunk * kRowB);       // [4 * kOwnChunk] {weight bits, next}
     unsigned *head = reinterpret_cast<unsigned *>(ents + 4 * kOwnChunk);        // [kOwnPix]
-    unsigned *list = head + kOwnPix;                                            // [kOwnList] (k:6 | pt:2 | q:24)
+    unsigned *list = head + kOwnPix;                                            // [own_list<T>()] (k:6 | pt:2 | q:24)
     __shared__ int s_H[kScatterMaxLevels], s_W[kScatterMaxLevels], s_R[kScatterMaxLevels],
         s_first[kScatterMaxLevels + 1], s_lsi[kScatterMaxLevels];
     __shared__ int s_nsrc, s_cnt[3];     // survivor counters rotate: slot j is reset two barriers before it is used again
@@ -2171,10 +2194,12 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
     const bool dynamic = p.workspace != nullptr && (dbg & 16) == 0 && n_items < (int64_t)16 * gridDim.x;
     const int lane8 = blockIdx.x % 8;
     const int strideA = p.M * p.LA * p.PA, strideB = p.M * p.LB * p.PB;      // loc/attn elements per query
-    // owner side: quad Q owns pixels s * kOwnQuads + Q of the band; lane c of the quad the channels [4c, 4c+4) of
-    // both 64-byte halves of the pixel (odd quads read the second half first: LDS banks, as in the forward)
+    // owner side: quad Q owns pixels s * kOwnQuads + Q of the band.  4-byte types: lane c of the quad holds the
+    // channels [4c, 4c+4) of both 64-byte halves of the row (odd quads read the second half first: LDS banks, as
+    // in the forward); 2-byte types: the 8 channels [8c, 8c+8) = one 16-byte slice of the 64-byte row.
     const int Q = tid / 4, cq = tid & 3, hsw = Q & 1;
-    const int off1 = cq * 16 + hsw * 64;
+    const int off1 = kHalf ? cq * 16 : cq * 16 + hsw * 64;
+    const int ch1 = kHalf ? cq * 8 : off1 / 4, ch2 = kHalf ? cq * 8 + 4 : (off1 ^ 64) / 4;     // channels of acc[0..3] / acc[4..7]
 
     for (int64_t it = blockIdx.x;; it += gridDim.x) {
         int64_t item = it;
@@ -2257,9 +2282,8 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
                 const int64_t idx = s_src_loc[k] + (int64_t)q * (curf ? strideA : strideB) + (int)((e >> 24) & 3u);
                 const T *loc = static_cast<const T *>(curf ? p.locA : p.locB);
                 const T *aw = static_cast<const T *>(curf ? p.awA : p.awB);
-                const float2 xy = *reinterpret_cast<const float2 *>(loc + 2 * idx);
-                x = xy.x; y = xy.y;
-                a = aw[idx];
+                load_xy(loc + 2 * idx, x, y);
+                a = Store<T>::get(aw + idx);
                 qrow = s_src_q0[k] + q;
             }
         };
@@ -2267,18 +2291,19 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
         // the owners; the NEXT chunk's hits (list[nbase, nbase + nn)) are fetched before the walk, so their memory
         // latency hides behind it.
         auto process_chunk = [&](int n, float &x, float &y, float &a, int &qrow, int nbase, int nn) {
-            // ---- grad_out rows -> LDS: 8 lanes x 16 B per hit, 8 hits per LDS-DMA wave instruction
+            // ---- grad_out rows -> LDS: kRowB / 16 lanes x 16 B per hit, 8 (16) hits per LDS-DMA wave instruction
             if (!direct && !(dbg & 4)) {
-                const T *go = static_cast<const T *>(p.grad_out) + m * D + (lane & 7) * 4;
+                constexpr int LPR = kRowB / 16, HPI = kWave / LPR;      // lanes per row, hits per instruction
+                const T *go = static_cast<const T *>(p.grad_out) + m * D + (lane % LPR) * (16 / (int)sizeof(T));
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int src_lane = 8 * i + (lane >> 3);
+                for (int i = 0; i < kWave / HPI; ++i) {
+                    const int src_lane = HPI * i + lane / LPR;
                     const int qr = __shfl(qrow, src_lane, kWave);
                     const int h = wave * kWave + src_lane;
-                    if (wave * kWave + 8 * i < n) {                     // uniform: this instruction has at least one live hit
+                    if (wave * kWave + HPI * i < n) {                   // uniform: this instruction has at least one live hit
                         const T *gp = go + (int64_t)(h < n ? qr : 0) * MD;
 #if defined(__HIP_DEVICE_COMPILE__)
-                        __builtin_amdgcn_global_load_lds(gp, (__attribute__((address_space(3))) void *)(rows + (wave * kWave + 8 * i) * 128), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds(gp, (__attribute__((address_space(3))) void *)(rows + (wave * kWave + HPI * i) * kRowB), 16, 0, 0);
 #else
                         (void)gp;
 #endif
@@ -2302,12 +2327,12 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
                     const int dpix[4] = {0, 1, W, W + 1};
                     if (direct) {
                         // a level whose single row does not fit a band: float atomics straight to memory
-                        const float *gr = reinterpret_cast<const float *>(static_cast<const T *>(p.grad_out) + (int64_t)qrow * MD + m * D);
+                        const T *gr = static_cast<const T *>(p.grad_out) + (int64_t)qrow * MD + m * D;
 #pragma unroll
                         for (int c = 0; c < 4; ++c)
                             if (own[c]) {
                                 float *dst = gmap + (int64_t)(pix00 + dpix[c]) * MD;
-                                for (int ch = 0; ch < D; ++ch) atomic_accumulate(dst + ch, wgt[c] * gr[ch]);
+                                for (int ch = 0; ch < D; ++ch) atomic_accumulate(dst + ch, wgt[c] * Store<T>::get(gr + ch));
                             }
                     } else if (!(dbg & 2)) {
 #pragma unroll
@@ -2333,13 +2358,17 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
                     while (e != kOwnNil) {
                         const uint2 en = ents[e];
                         const float w = __uint_as_float(en.x);
-                        const unsigned char *r = rows + (e >> 2) * 128;
-                        const float4 v1 = *reinterpret_cast<const float4 *>(r + off1);
-                        const float4 v2 = *reinterpret_cast<const float4 *>(r + (off1 ^ 64));
-                        acc[s][0] = fmaf(w, v1.x, acc[s][0]); acc[s][1] = fmaf(w, v1.y, acc[s][1]);
-                        acc[s][2] = fmaf(w, v1.z, acc[s][2]); acc[s][3] = fmaf(w, v1.w, acc[s][3]);
-                        acc[s][4] = fmaf(w, v2.x, acc[s][4]); acc[s][5] = fmaf(w, v2.y, acc[s][5]);
-                        acc[s][6] = fmaf(w, v2.z, acc[s][6]); acc[s][7] = fmaf(w, v2.w, acc[s][7]);
+                        const unsigned char *r = rows + (e >> 2) * kRowB;
+                        float v[8];
+                        if constexpr (kHalf) {
+                            Store<T>::load(reinterpret_cast<const T *>(r + off1), v);
+                        } else {
+                            const float4 v1 = *reinterpret_cast<const float4 *>(r + off1);
+                            const float4 v2 = *reinterpret_cast<const float4 *>(r + (off1 ^ 64));
+                            v[0] = v1.x; v[1] = v1.y; v[2] = v1.z; v[3] = v1.w; v[4] = v2.x; v[5] = v2.y; v[6] = v2.z; v[7] = v2.w;
+                        }
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) acc[s][c] = fmaf(w, v[c], acc[s][c]);
                         e = en.y;
                     }
                 }
@@ -2423,8 +2452,8 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
                 const int pix = s * kOwnQuads + Q;
                 if (pix < npix) {
                     float *o = gband + (int64_t)pix * MD;
-                    *reinterpret_cast<float4 *>(o + off1 / 4) = make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
-                    *reinterpret_cast<float4 *>(o + (off1 ^ 64) / 4) = make_float4(acc[s][4], acc[s][5], acc[s][6], acc[s][7]);
+                    *reinterpret_cast<float4 *>(o + ch1) = make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
+                    *reinterpret_cast<float4 *>(o + ch2) = make_float4(acc[s][4], acc[s][5], acc[s][6], acc[s][7]);
                 }
             }
         }
@@ -3384,8 +3413,8 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
         if (rc) return rc;
     }
     if (!(phases & 2)) return rc;
-    if constexpr (sizeof(T) == 4 && G == 8) {
-        // owner-computes scatter (D = 32, 4-byte types, <= 4 points per level): no float atomics
+    if constexpr (G * Store<T>::VEC == 32) {
+        // owner-computes scatter (D = 32, <= 4 points per level): no float atomics
         const int own = knobs().scatter_own;
         if (own != 0 && p.PA <= 4 && p.PB <= 4 && (p.cull_points || !p.bbox) && knobs().scatter_lds_kb == 144 &&
             knobs().scatter_wg_per_cu == 1) {
@@ -3394,9 +3423,9 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
             static LdsGrant granted_own[4];
             const int variant = (knobs().scatter_dbg & 256) ? 0 : 2;       // (measurement: 256 = no cross-chunk prefetch)
             auto own_launch = [&](auto kern) {
-                if (const int grc = grant_lds(reinterpret_cast<const void *>(kern), (size_t)kOwnLdsBytes, granted_own[variant],
+                if (const int grc = grant_lds(reinterpret_cast<const void *>(kern), (size_t)own_lds_bytes<T>(), granted_own[variant],
                                               "the owner-computes scatter kernel")) return grc;
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(kOwnThreads), (size_t)kOwnLdsBytes, stream, p, knobs().scatter_dbg);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(kOwnThreads), (size_t)own_lds_bytes<T>(), stream, p, knobs().scatter_dbg);
                 return check_launch("msda backward (owner-computes scatter kernel)");
             };
             const int64_t rows = (int64_t)p.groups * p.S;
