@@ -2775,32 +2775,32 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                         int A[4];
                         float W[4];
                         quad_corner_records(addr, w, ln.off1, A, W);
-                        float v1[4][4], v2[4][4];
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
+                            float v1[4], v2[4];
                             if constexpr (SLAB) {
                                 const float4 q1 = *reinterpret_cast<const float4 *>(lds_raw + A[s]);
                                 const float4 q2 = *reinterpret_cast<const float4 *>(lds_raw + (A[s] ^ 64));
-                                v1[s][0] = q1.x; v1[s][1] = q1.y; v1[s][2] = q1.z; v1[s][3] = q1.w;
-                                v2[s][0] = q2.x; v2[s][1] = q2.y; v2[s][2] = q2.z; v2[s][3] = q2.w;
+                                v1[0] = q1.x; v1[1] = q1.y; v1[2] = q1.z; v1[3] = q1.w;
+                                v2[0] = q2.x; v2[1] = q2.y; v2[2] = q2.z; v2[3] = q2.w;
                             } else {
 #if defined(__HIP_DEVICE_COMPILE__)
                                 const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, A[s], 0, 0);
                                 const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, A[s] + ln.delta2, 0, 0);
-                                v1[s][0] = __uint_as_float(q1.x); v1[s][1] = __uint_as_float(q1.y);
-                                v1[s][2] = __uint_as_float(q1.z); v1[s][3] = __uint_as_float(q1.w);
-                                v2[s][0] = __uint_as_float(q2.x); v2[s][1] = __uint_as_float(q2.y);
-                                v2[s][2] = __uint_as_float(q2.z); v2[s][3] = __uint_as_float(q2.w);
+                                v1[0] = __uint_as_float(q1.x); v1[1] = __uint_as_float(q1.y);
+                                v1[2] = __uint_as_float(q1.z); v1[3] = __uint_as_float(q1.w);
+                                v2[0] = __uint_as_float(q2.x); v2[1] = __uint_as_float(q2.y);
+                                v2[2] = __uint_as_float(q2.z); v2[3] = __uint_as_float(q2.w);
 #endif
                             }
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) wacc[c] = fmaf(W[s], v1[c], wacc[c]);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) wacc[4 + c] = fmaf(W[s], v2[c], wacc[4 + c]);
+                            // corner by corner: the next corner's loads are not hoisted above these FMAs (measured: 0.466 ->
+                            // 0.430 ms; eight loads in flight per wave only queue up in the LDS / TA pipes)
+                            asm volatile("" ::: "memory");
                         }
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                wacc[c] = fmaf(W[s], v1[s][c], wacc[c]);
-                                wacc[4 + c] = fmaf(W[s], v2[s][c], wacc[4 + c]);
-                            }
                     };
                     if (g0 >= first_slab_pt) {                 // the whole group reads the slab (uniform)
                         static_for<4>([&](auto Rc) { if (g0 + decltype(Rc)::value < npts) step(Rc, std::true_type{}); });
@@ -2837,6 +2837,211 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
             Store<T>::store(o + (ln.off1 + ln.delta2) / 4, a2);
         }
     });
+}
+
+// Backward gather pass (grad_loc / grad_attn) on the resident slab: same workgroup / tile / quad geometry as
+// msda_fwd_rs_kernel, but nothing is carried across source frames -- every (tile, slot) writes its own gradients --
+// so there are no accumulator sets and a wave may take any number of tiles.  Per point the four dots
+// <grad_out row, corner k> (cuh:123-158) are 8 FMAs per corner and lane, reduced over the quad with two DPP adds;
+// lane R of the quad keeps the dots of point R, and after the group's four points every lane finishes ITS point and
+// stores its (grad_x, grad_y, grad_attn) directly: the 4 points of a group are 32 + 16 contiguous bytes per row.
+// Also leaves the per-point culling records (top tap row as int16) the scatter pass reads.
+__device__ __forceinline__ void quad_corner_addrs(int addr, int lane_off, int (&A)[4])
+{
+    asm volatile("s_nop 1\n"
+                 "v_add_u32_dpp %0, %4, %5 " MSDA_QP(0) "\n v_add_u32_dpp %1, %4, %5 " MSDA_QP(1) "\n"
+                 "v_add_u32_dpp %2, %4, %5 " MSDA_QP(2) "\n v_add_u32_dpp %3, %4, %5 " MSDA_QP(3)
+                 : "=&v"(A[0]), "=&v"(A[1]), "=&v"(A[2]), "=&v"(A[3]) : "v"(addr), "v"(lane_off));
+}
+
+// d[k] <- sum of d[k] over the four lanes of the quad (all lanes get the total)
+__device__ __forceinline__ void quad_sum4(float (&d)[4])
+{
+    asm volatile("s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 0\n"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kRsThreads)
+msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
+{
+    static_assert(sizeof(T) == 4, "resident-slab gather pass: 4-byte storage types");
+    constexpr int RPW = kRsRows, D = 32;
+    extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid % kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int L = p.L, VL = p.LA + p.LB;
+    // the scatter pass that follows draws its work tickets from the head of the workspace (see msda_bwd_slab_kernel)
+    if (blockIdx.x == 0 && tid < MSDA_BWD_WORKSPACE_BYTES / 4 && p.workspace) p.workspace[tid] = 0u;
+    T *slab = reinterpret_cast<T *>(lds_raw);
+    const RsShared sh = rs_setup(p, lds_raw, slab_bytes, (int)sizeof(T));
+    const int l0 = sh.l0;
+
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u;       // clip-major XCD mapping, as in the forward
+    const unsigned lin = xcd * (nwg / 8u) + min(xcd, nwg % 8u) + blockIdx.x / 8u;
+    const int part = (int)(lin % (unsigned)parts), m = (int)((lin / (unsigned)parts) % (unsigned)p.M);
+    const int clip = (int)(lin / ((unsigned)parts * (unsigned)p.M));
+    const int tiles_per_group = (p.Lq + RPW - 1) / RPW, tiles_per_clip = p.frames * tiles_per_group;
+    const int tpw = (tiles_per_clip + parts - 1) / parts;
+    const int tile_lo = part * tpw + wave, tile_hi = min((part + 1) * tpw, tiles_per_clip);
+
+    const int j = lane / 4, cor = lane & 3, hsw = j & 1;
+    RsLane ln;
+    ln.vmask = 1 << (24 + cor); ln.dymask = (cor & 2) ? 0xffffff : 0; ln.dx = cor & 1;
+    ln.off1 = cor * 16 + hsw * 64; ln.delta2 = hsw ? -64 : 64;
+    ln.fy0 = ln.fys = ln.fx0 = ln.fxs = 0.f;      // (corner weights are not needed for the dots)
+    const int pixB = p.v_pix * (int)sizeof(T);
+    const char *vbase = reinterpret_cast<const char *>(static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head);
+    const unsigned vbytes = (unsigned)(((int64_t)p.frames * p.S - 1) * pixB + kRsRowB);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(vbase), 0, (int)vbytes, 0x00020000);
+#endif
+    const bool records = p.bbox != nullptr;        // per-point culling records (host: only with cull_points)
+
+    for (int f = 0; f < p.frames; ++f) {
+        __syncthreads();                                   // every wave is done with the previous slab
+        if (l0 < L) rs_stage_slab<T>(p, slab, clip, m, f, sh.px0, sh.npx, wave, lane);
+        __syncthreads();
+        const int fS = f * p.S;
+#pragma unroll 1
+        for (int ct = tile_lo; ct < tile_hi; ct += kRsWaves) {
+            const int t = ct / tiles_per_group, q0 = (ct - t * tiles_per_group) * RPW;
+            unsigned todo = __builtin_amdgcn_readfirstlane(sh.mask[t * p.frames + f]);
+            if (!todo) continue;
+            const bool live = j < min(RPW, p.Lq - q0);
+            const int64_t group = (int64_t)clip * p.frames + t;
+            const int64_t row = ((group * p.Lq) + q0 + j) * p.M + m;
+            // this row's grad_out: channels [4c, 4c+4) of both halves, as the value slices are read
+            float g[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) g[c] = 0.f;
+            if (live) {
+                const T *go = static_cast<const T *>(p.grad_out) + row * D;
+                const float4 g1 = *reinterpret_cast<const float4 *>(go + ln.off1 / 4);
+                const float4 g2 = *reinterpret_cast<const float4 *>(go + (ln.off1 + ln.delta2) / 4);
+                g[0] = g1.x; g[1] = g1.y; g[2] = g1.z; g[3] = g1.w; g[4] = g2.x; g[5] = g2.y; g[6] = g2.z; g[7] = g2.w;
+            }
+#pragma unroll 1
+            while (todo) {                                     // sl = -1: the tile's current-frame points
+                const int sl = (int)__builtin_ctz(todo) - 1;
+                todo &= todo - 1;
+                const T *loc = static_cast<const T *>(sl < 0 ? p.locA : p.locB);
+                const T *aw = static_cast<const T *>(sl < 0 ? p.awA : p.awB);
+                T *gloc = static_cast<T *>(sl < 0 ? p.glocA : p.glocB);
+                T *gaw = static_cast<T *>(sl < 0 ? p.gawA : p.gawB);
+                const int P = sl < 0 ? p.PA : p.PB;
+                const int LP = (sl < 0 ? p.LA : p.LB) * P;
+                const int npts = (sl < 0 ? p.LA : L) * P;
+                const int vl0 = sl < 0 ? 0 : p.LA + sl * L;   // virtual level of the slot's level 0
+                const int64_t idx0 = row * LP + (sl < 0 ? 0 : sl * L * P);
+                const unsigned invP = (65536u + (unsigned)P - 1u) / (unsigned)P;      // kk / P for kk * P < 2^16
+                const int first_slab_pt = l0 * P;              // points of levels >= l0 read the slab
+#pragma unroll 1
+                for (int g0 = 0; g0 < npts; g0 += 4) {
+                    const int kk = g0 + cor;
+                    const bool mine = live && kk < npts;
+                    float x = -10.f, y = -10.f, a = 0.f;       // far outside every map
+                    if (mine) {
+                        const float2 xy = *reinterpret_cast<const float2 *>(loc + 2 * (idx0 + kk));
+                        x = xy.x; y = xy.y;
+                        a = aw[idx0 + kk];
+                    }
+                    const int lvl = min((int)(((unsigned)kk * invP) >> 16), L - 1);
+                    // own point: fractions, validity, top-left pixel (as rs_point) + what the gradients need
+                    const int H = sh.H[lvl], W = sh.W[lvl];
+                    const int base = lvl >= l0 ? sh.sst[lvl] : fS + sh.lsi[lvl];
+                    const float h_im = __fsub_rn(__fmul_rn(y, (float)H), 0.5f);
+                    const float w_im = __fsub_rn(__fmul_rn(x, (float)W), 0.5f);
+                    const bool rng = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+                    const float hf = floorf(h_im), wf = floorf(w_im);
+                    const int yl = rng ? (int)hf : 0, xl = rng ? (int)wf : 0;
+                    RsPoint pt;
+                    pt.lh = rng ? h_im - hf : 0.f;
+                    pt.lw = rng ? w_im - wf : 0.f;
+                    pt.a = rng ? a : 0.f;
+                    const int vy0 = yl >= 0, vy1 = yl + 1 <= H - 1, vx0 = xl >= 0, vx1 = xl + 1 <= W - 1;
+                    const int bits = rng ? ((vy0 & vx0) | ((vy0 & vx1) << 1) | ((vy1 & vx0) << 2) | ((vy1 & vx1) << 3)) : 0;
+                    pt.pbase = base + yl * W + xl;
+                    pt.Wb = W | (bits << 24);
+                    if (records && mine) {      // the point's top tap row, for the scatter's band test
+                        const int pin = kk - lvl * P;
+                        short *rec = reinterpret_cast<short *>(p.bbox + (((group * p.M + m) * VL + vl0 + lvl) * p.Lq + q0 + j) * 2);
+                        rec[pin] = bits ? (short)min(yl, 32767) : (short)kNoRow16;
+                        if (pin == 0)
+                            for (int u = P; u < 4; ++u) rec[u] = (short)kNoRow16;
+                    }
+                    dpp_fence(pt.lh, pt.lw, pt.a, pt.pbase, pt.Wb);
+                    float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f;      // the dots of THIS lane's point
+                    auto step = [&](auto Rc, auto Sc) {
+                        constexpr int R = decltype(Rc)::value;
+                        constexpr bool SLAB = decltype(Sc)::value;
+                        const int vb = quad_and<R>(pt.Wb, ln.vmask);
+                        const int tw = quad_and<R>(pt.Wb, ln.dymask);
+                        const int pix = quad_add<R>(pt.pbase, ln.dx) + tw;
+                        int addr = SLAB ? (pix << 7) : (int)((unsigned)pix * (unsigned)pixB);
+                        addr = vb ? addr : (SLAB ? sh.zero_off : (int)0x80000000u);
+                        int A[4];
+                        quad_corner_addrs(addr, ln.off1, A);
+                        float d[4];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            float v[8];
+                            if constexpr (SLAB) {
+                                const float4 q1 = *reinterpret_cast<const float4 *>(lds_raw + A[s]);
+                                const float4 q2 = *reinterpret_cast<const float4 *>(lds_raw + (A[s] ^ 64));
+                                v[0] = q1.x; v[1] = q1.y; v[2] = q1.z; v[3] = q1.w; v[4] = q2.x; v[5] = q2.y; v[6] = q2.z; v[7] = q2.w;
+                            } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+                                const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, A[s], 0, 0);
+                                const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, A[s] + ln.delta2, 0, 0);
+                                v[0] = __uint_as_float(q1.x); v[1] = __uint_as_float(q1.y); v[2] = __uint_as_float(q1.z); v[3] = __uint_as_float(q1.w);
+                                v[4] = __uint_as_float(q2.x); v[5] = __uint_as_float(q2.y); v[6] = __uint_as_float(q2.z); v[7] = __uint_as_float(q2.w);
+#endif
+                            }
+                            // (measured: issuing all eight loads of the point ahead of the dots is SLOWER, 0.63 -> 0.67 ms)
+                            float acc = g[0] * v[0];
+#pragma unroll
+                            for (int c = 1; c < 8; ++c) acc = fmaf(g[c], v[c], acc);
+                            d[s] = acc;
+                        }
+                        quad_sum4(d);
+                        const bool me = cor == R;
+                        k0 = me ? d[0] : k0; k1 = me ? d[1] : k1; k2 = me ? d[2] : k2; k3 = me ? d[3] : k3;
+                    };
+                    if (g0 >= first_slab_pt) {                 // the whole group reads the slab (uniform)
+                        static_for<4>([&](auto Rc) { if (g0 + decltype(Rc)::value < npts) step(Rc, std::true_type{}); });
+                    } else if (g0 + 3 < first_slab_pt) {       // the whole group reads memory
+                        static_for<4>([&](auto Rc) { if (g0 + decltype(Rc)::value < npts) step(Rc, std::false_type{}); });
+                    } else {
+                        static_for<4>([&](auto Rc) {
+                            constexpr int R = decltype(Rc)::value;
+                            if (g0 + R >= npts) return;
+                            if (g0 + R >= first_slab_pt) step(Rc, std::true_type{}); else step(Rc, std::false_type{});
+                        });
+                    }
+                    // every lane finishes its own point (cuh:123-158 on the reduced dots; dots of corners outside
+                    // the map are 0: their loads returned zeros)
+                    if (mine) {
+                        const float lh = pt.lh, lw = pt.lw, hh = 1.f - lh, hw = 1.f - lw;
+                        const float g_aw = (hh * hw) * k0 + (hh * lw) * k1 + (lh * hw) * k2 + (lh * lw) * k3;
+                        const float g_w = hh * (k1 - k0) + lh * (k3 - k2);
+                        const float g_h = hw * (k2 - k0) + lw * (k3 - k1);
+                        *reinterpret_cast<float2 *>(gloc + 2 * (idx0 + kk)) = make_float2((float)W * g_w * pt.a, (float)H * g_h * pt.a);
+                        gaw[idx0 + kk] = g_aw;
+                    }
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3163,6 +3368,7 @@ size_t tile_lds_bytes(int rpw, int nvl, bool bwd, bool intervals = false)
 // msda_reload_knobs() after changing a knob.
 struct Knobs {
     int fwd_rs = -1, fwd_rs_nt = 0;     // resident-slab forward: -1 auto, 0 off, 1 force; tiles per wave (0 = auto)
+    int bwd_rs = -1;                    // resident-slab gather pass: -1 auto, 0 off, 1 force
     int fwd_slab = -1, bwd_slab = -1;   // slab kernels: -1 auto, 0 off, 1 force
     int fwd_nb = 4;                     // tile forward: points in flight
     int bwd_atomic = 0;                 // MSDA_BWD_MODE=atomic: one-kernel backward with global atomics
@@ -3189,6 +3395,7 @@ void load_knobs()
     if (env_int("MSDA_ENABLE_HOOKS", 0) == 1) {
         k.fwd_rs = env_int("MSDA_FWD_RS", k.fwd_rs); k.fwd_rs_nt = env_int("MSDA_FWD_RS_NT", k.fwd_rs_nt);
         k.fwd_slab = env_int("MSDA_FWD_SLAB", k.fwd_slab); k.bwd_slab = env_int("MSDA_BWD_SLAB", k.bwd_slab);
+        k.bwd_rs = env_int("MSDA_BWD_RS", k.bwd_rs);
         k.fwd_nb = env_int("MSDA_FWD_NB", k.fwd_nb);
         const char *mode = getenv("MSDA_BWD_MODE");
         k.bwd_atomic = (mode && !strcmp(mode, "atomic")) ? 1 : 0;
@@ -3377,7 +3584,32 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     int rc = MSDA_OK;
     if (phases & 1) {
         bool done = false;
-        if constexpr (GSL >= 4 && GSL <= kWave) if (p.LA == p.L && p.L <= kSlabMaxLevels) {      // slab variant of the gather pass
+        if constexpr (sizeof(T) == 4 && G == 8) if (p.LA == p.L && p.L <= kSlabMaxLevels && (p.cull_points || !p.bbox)) {
+            // resident-slab gather pass (D = 32, 4-byte types): same applicability rule as the forward
+            const int mode = knobs().bwd_rs;
+            const int tiles_per_clip = p.frames * ((p.Lq + kRsRows - 1) / kRsRows);
+            const int64_t clips = p.groups / p.frames;
+            const int64_t pixB = (int64_t)p.v_pix * (int64_t)sizeof(T);
+            const bool fits = (int64_t)p.frames * p.S < (1 << 24) && pixB < (1 << 24) && p.D == 32 &&
+                              (int64_t)p.frames * p.S * pixB < 0x7fffffffLL && p.frames <= kRsMaxFrames && p.window <= 31 &&
+                              (int64_t)(p.PA > p.PB ? p.PA : p.PB) * (p.PA > p.PB ? p.PA : p.PB) * p.L < 65536;   // kk / P by reciprocal
+            const int slab_bytes = ((160 * 1024 - 256 - kRsTailBytes) / 128) * 128;
+            int parts = (tiles_per_clip + 2 * kRsWaves - 1) / (2 * kRsWaves);       // ~2 tiles per wave (L2: see the forward)
+            bool want = mode == 1 || (mode == -1 && clips * p.M * parts >= device_cus() &&
+                                      host_first_slab_level(p, (slab_bytes - kRsSlack) / kRsRowB) <= 1);
+            if (want && fits && clips * p.M * parts <= 0x7fffffffLL) {
+                const size_t total = (size_t)slab_bytes + kRsTailBytes;
+                static LdsGrant granted;
+                if (const int grc = grant_lds(reinterpret_cast<const void *>(&msda_bwd_rs_kernel<T>), total, granted,
+                                              "the resident-slab gather-pass kernel")) return grc;
+                hipLaunchKernelGGL((msda_bwd_rs_kernel<T>), dim3((unsigned)(clips * p.M * parts)), dim3(kRsThreads), total, stream, p,
+                                   slab_bytes, parts);
+                rc = check_launch("msda backward (resident-slab kernel, grad_loc/grad_attn)");
+                if (rc) return rc;
+                done = true;
+            }
+        }
+        if constexpr (GSL >= 4 && GSL <= kWave) if (!done && p.LA == p.L && p.L <= kSlabMaxLevels) {      // slab variant of the gather pass
             const int tiles_per_clip = p.frames * ((p.Lq + RPWS - 1) / RPWS);
             const int blocks_per_clip = (tiles_per_clip + kSlabWaves - 1) / kSlabWaves;
             const int64_t slab_blocks = (int64_t)(p.groups / p.frames) * blocks_per_clip * p.M;

@@ -39,7 +39,4 @@ def run(clips, pyr="A", locs="uniform", queries=300, dt="f32", layout="dense", r
           % (clips, pyr, locs, queries, dt, layout, times["0"], times["1"], diff, nan, outs["0"].abs().max().item()), flush=True)
 
 if __name__ == "__main__":
-    for nt in ("2", "1"):
-        os.environ["MSDA_FWD_RS_NT"] = nt; print("NT=" + nt)
-        run(16); run(16, layout="padded"); run(8); run(32)
-    os.environ.pop("MSDA_FWD_RS_NT")
+    run(16); run(16, layout="padded"); run(16, locs="clustered"); run(8); run(32)
