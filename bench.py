@@ -225,6 +225,12 @@ def other_configs(args, device):
     ms = _event_ms(step, 10)
     res["clustered_locations"] = {"workload": "headline batch, reference point + N(0, (3 px)^2) offsets", "fwd_bwd_ms": round(ms, 4),
                                   "M_queries_per_s": round(rows / ms / 1e3, 3)}
+    # (iii) the headline batch in the 16-bit storage types (arithmetic stays fp32)
+    for key, dt in (("headline_bf16", torch.bfloat16), ("headline_f16", torch.float16)):
+        step, fwd, rows = fused_case(args.clips, "uniform", dt)
+        ms, fms = _event_ms(step, 10), _event_ms(fwd, 10)
+        res[key] = {"workload": "headline batch, %s storage" % key.split("_")[1], "fwd_bwd_ms": round(ms, 4), "fwd_ms": round(fms, 4),
+                    "M_queries_per_s": round(rows / ms / 1e3, 3)}
     del step, fwd
 
     def plain(name, dtype, shapes, N, Lq, locs, steps, reps=6, per_kernel=False):

@@ -39,6 +39,7 @@
 
 #include <hip/hip_runtime.h>
 #include <utility>
+#include <type_traits>
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -2512,8 +2513,45 @@ constexpr int kRsThreads = 1024, kRsWaves = kRsThreads / kWave;
 constexpr int kRsRows = kWave / 4;       // rows per wave tile: one quad per row
 constexpr int kRsSlack = 1024;          // bytes: the last LDS-DMA piece may overrun the slab's pixels
 constexpr int kRsMaxFrames = 32;        // frames x frames slot masks live in LDS
-constexpr int kRsRowB = 128;            // bytes of one pixel of one head: D = 32 channels x 4 bytes
+constexpr int kRsRowB = 128;            // bytes of one pixel of one head in a 4-byte type (D = 32); 64 in a 2-byte type
 constexpr int kRsTailBytes = kRsRowB + kRsMaxFrames * kRsMaxFrames * 4 + 4 * kSlabMaxLevels * 4 + 16;   // after the slab
+template <typename T> constexpr int rs_row_bytes() { return 32 * (int)sizeof(T); }
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// The 8 channels a lane holds of one pixel row whose (this lane's) slice starts at LDS byte address `a` / buffer byte
+// offset `a`: 4-byte types -- [4c, 4c+4) of both 64-byte halves, the second half at a ^ 64 (LDS) or a + delta2
+// (memory); 2-byte types -- the 8 contiguous channels [8c, 8c+8) = ONE 16-byte load.
+template <typename T, bool SLAB>
+__device__ __forceinline__ void rs_load_row8(const unsigned char *lds_raw, __amdgpu_buffer_rsrc_t rsrc, int a, int delta2,
+                                             float (&v)[8])
+{
+    if constexpr (sizeof(T) == 4) {
+        if constexpr (SLAB) {
+            const float4 q1 = *reinterpret_cast<const float4 *>(lds_raw + a);
+            const float4 q2 = *reinterpret_cast<const float4 *>(lds_raw + (a ^ 64));
+            v[0] = q1.x; v[1] = q1.y; v[2] = q1.z; v[3] = q1.w; v[4] = q2.x; v[5] = q2.y; v[6] = q2.z; v[7] = q2.w;
+        } else {
+            const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, a, 0, 0);
+            const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, a + delta2, 0, 0);
+            v[0] = __uint_as_float(q1.x); v[1] = __uint_as_float(q1.y); v[2] = __uint_as_float(q1.z); v[3] = __uint_as_float(q1.w);
+            v[4] = __uint_as_float(q2.x); v[5] = __uint_as_float(q2.y); v[6] = __uint_as_float(q2.z); v[7] = __uint_as_float(q2.w);
+        }
+    } else {
+        u32x4 q;
+        if constexpr (SLAB) q = *reinterpret_cast<const u32x4 *>(lds_raw + a);
+        else q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, a, 0, 0);
+        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (sizeof(T) == 2 && std::is_same<T, bf16_t>::value) {
+                v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+            } else {
+                const float2 f = __half22float2(*reinterpret_cast<const __half2 *>(&w[i]));
+                v[2 * i] = f.x; v[2 * i + 1] = f.y;
+            }
+        }
+    }
+}
 
 #define MSDA_QP(s) "quad_perm:[" #s "," #s "," #s "," #s "] row_mask:0xf bank_mask:0xf"
 
@@ -2561,7 +2599,6 @@ __device__ __forceinline__ void quad_corner_records(int addr, float w, int lane_
                  : "v"(addr), "v"(lane_off), "v"(w));
 }
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // Per-lane constants of the corner a lane serves inside its quad (corner = lane & 3: bit 0 = x+1, bit 1 = y+1).
 struct RsLane {
@@ -2578,7 +2615,7 @@ template <typename T>
 __device__ __forceinline__ void rs_stage_slab(const Params &p, T *slab, int clip, int m, int f, int px0, int npx,
                                               int wave, int lane)
 {
-    constexpr int GL = kRsRowB / 16, D = kRsRowB / (int)sizeof(T);
+    constexpr int GL = rs_row_bytes<T>() / 16, D = 32;
     constexpr int PXW = kWave / GL;                 // pixels per LDS-DMA wave instruction
     const T *src = static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head + ((int64_t)f * p.S + px0) * p.v_pix;
     for (int pb = wave * PXW; pb < npx; pb += kRsWaves * PXW) {
@@ -2663,8 +2700,8 @@ template <typename T, int NT>
 __global__ void __launch_bounds__(kRsThreads)
 msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
 {
-    static_assert(sizeof(T) == 4, "resident-slab forward: 4-byte storage types");
-    constexpr int RPW = kRsRows, D = 32;
+    constexpr int RPW = kRsRows, D = 32, ROWB = rs_row_bytes<T>(), ROWSH = ROWB == 128 ? 7 : 6;
+    constexpr bool kHalf = sizeof(T) == 2;
     extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];       // (no static LDS: the slab starts at 0)
     const int tid = threadIdx.x, lane = tid % kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -2697,13 +2734,13 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
     const int j = lane / 4, cor = lane & 3, hsw = j & 1;
     RsLane ln;
     ln.vmask = 1 << (24 + cor); ln.dymask = (cor & 2) ? 0xffffff : 0; ln.dx = cor & 1;
-    ln.off1 = cor * 16 + hsw * 64; ln.delta2 = hsw ? -64 : 64;
+    ln.off1 = kHalf ? cor * 16 : cor * 16 + hsw * 64; ln.delta2 = hsw ? -64 : 64;
     ln.fy0 = (cor & 2) ? 0.f : 1.f; ln.fys = (cor & 2) ? 1.f : -1.f;
     ln.fx0 = (cor & 1) ? 0.f : 1.f; ln.fxs = (cor & 1) ? 1.f : -1.f;
     const int pixB = p.v_pix * (int)sizeof(T);
     // buffer resource over value[clip, :, m, :] (stride 0 = raw, num_records in bytes): out-of-range -> 0
     const char *vbase = reinterpret_cast<const char *>(static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head);
-    const unsigned vbytes = (unsigned)(((int64_t)p.frames * p.S - 1) * pixB + kRsRowB);
+    const unsigned vbytes = (unsigned)(((int64_t)p.frames * p.S - 1) * pixB + ROWB);
 #if defined(__HIP_DEVICE_COMPILE__)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(vbase), 0, (int)vbytes, 0x00020000);
 #endif
@@ -2752,9 +2789,8 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                     const int kk = g0 + cor;
                     float x = -10.f, y = -10.f, a = 0.f;       // far outside every map
                     if (live && kk < npts) {
-                        const float2 xy = *reinterpret_cast<const float2 *>(loc + 2 * (idx0 + kk));
-                        x = xy.x; y = xy.y;
-                        a = aw[idx0 + kk];
+                        load_xy(loc + 2 * (idx0 + kk), x, y);
+                        a = Store<T>::get(aw + idx0 + kk);
                     }
                     const int lvl = min((int)(((unsigned)kk * invP) >> 16), L - 1);
                     RsPoint pt = rs_point(x, y, a, lvl, l0, fS, sh.H, sh.W, sh.lsi, sh.sst);
@@ -2766,7 +2802,7 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                         const int vb = quad_and<R>(pt.Wb, ln.vmask);
                         const int tw = quad_and<R>(pt.Wb, ln.dymask);
                         const int pix = quad_add<R>(pt.pbase, ln.dx) + tw;
-                        int addr = SLAB ? (pix << 7) : (int)((unsigned)pix * (unsigned)pixB);
+                        int addr = SLAB ? (pix << ROWSH) : (int)((unsigned)pix * (unsigned)pixB);
                         addr = vb ? addr : (SLAB ? sh.zero_off : (int)0x80000000u);
                         float wy = ln.fy0, wx = ln.fx0;
                         quad_fmac<R>(wy, pt.lh, ln.fys);
@@ -2777,26 +2813,12 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                         quad_corner_records(addr, w, ln.off1, A, W);
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
-                            float v1[4], v2[4];
-                            if constexpr (SLAB) {
-                                const float4 q1 = *reinterpret_cast<const float4 *>(lds_raw + A[s]);
-                                const float4 q2 = *reinterpret_cast<const float4 *>(lds_raw + (A[s] ^ 64));
-                                v1[0] = q1.x; v1[1] = q1.y; v1[2] = q1.z; v1[3] = q1.w;
-                                v2[0] = q2.x; v2[1] = q2.y; v2[2] = q2.z; v2[3] = q2.w;
-                            } else {
+                            float v[8];
 #if defined(__HIP_DEVICE_COMPILE__)
-                                const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, A[s], 0, 0);
-                                const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, A[s] + ln.delta2, 0, 0);
-                                v1[0] = __uint_as_float(q1.x); v1[1] = __uint_as_float(q1.y);
-                                v1[2] = __uint_as_float(q1.z); v1[3] = __uint_as_float(q1.w);
-                                v2[0] = __uint_as_float(q2.x); v2[1] = __uint_as_float(q2.y);
-                                v2[2] = __uint_as_float(q2.z); v2[3] = __uint_as_float(q2.w);
+                            rs_load_row8<T, SLAB>(lds_raw, rsrc, A[s], ln.delta2, v);
 #endif
-                            }
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) wacc[c] = fmaf(W[s], v1[c], wacc[c]);
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) wacc[4 + c] = fmaf(W[s], v2[c], wacc[4 + c]);
+                            for (int c = 0; c < 8; ++c) wacc[c] = fmaf(W[s], v[c], wacc[c]);
                             // corner by corner: the next corner's loads are not hoisted above these FMAs (measured: 0.466 ->
                             // 0.430 ms; eight loads in flight per wave only queue up in the LDS / TA pipes)
                             asm volatile("" ::: "memory");
@@ -2832,9 +2854,13 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
         if (j < min(RPW, p.Lq - q0)) {
             const int64_t row = (((int64_t)clip * p.frames + t) * p.Lq + q0 + j) * p.M + m;
             T *o = static_cast<T *>(p.out) + row * D;
-            const float a1[4] = {acc[K][0], acc[K][1], acc[K][2], acc[K][3]}, a2[4] = {acc[K][4], acc[K][5], acc[K][6], acc[K][7]};
-            Store<T>::store(o + ln.off1 / 4, a1);
-            Store<T>::store(o + (ln.off1 + ln.delta2) / 4, a2);
+            if constexpr (kHalf) {
+                Store<T>::store(o + cor * 8, acc[K]);       // channels [8c, 8c+8): one 16-byte store
+            } else {
+                const float a1[4] = {acc[K][0], acc[K][1], acc[K][2], acc[K][3]}, a2[4] = {acc[K][4], acc[K][5], acc[K][6], acc[K][7]};
+                Store<T>::store(o + ln.off1 / 4, a1);
+                Store<T>::store(o + (ln.off1 + ln.delta2) / 4, a2);
+            }
         }
     });
 }
@@ -2874,8 +2900,8 @@ template <typename T>
 __global__ void __launch_bounds__(kRsThreads)
 msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
 {
-    static_assert(sizeof(T) == 4, "resident-slab gather pass: 4-byte storage types");
-    constexpr int RPW = kRsRows, D = 32;
+    constexpr int RPW = kRsRows, D = 32, ROWB = rs_row_bytes<T>(), ROWSH = ROWB == 128 ? 7 : 6;
+    constexpr bool kHalf = sizeof(T) == 2;
     extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];
     const int tid = threadIdx.x, lane = tid % kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -2897,11 +2923,11 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
     const int j = lane / 4, cor = lane & 3, hsw = j & 1;
     RsLane ln;
     ln.vmask = 1 << (24 + cor); ln.dymask = (cor & 2) ? 0xffffff : 0; ln.dx = cor & 1;
-    ln.off1 = cor * 16 + hsw * 64; ln.delta2 = hsw ? -64 : 64;
+    ln.off1 = kHalf ? cor * 16 : cor * 16 + hsw * 64; ln.delta2 = hsw ? -64 : 64;
     ln.fy0 = ln.fys = ln.fx0 = ln.fxs = 0.f;      // (corner weights are not needed for the dots)
     const int pixB = p.v_pix * (int)sizeof(T);
     const char *vbase = reinterpret_cast<const char *>(static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head);
-    const unsigned vbytes = (unsigned)(((int64_t)p.frames * p.S - 1) * pixB + kRsRowB);
+    const unsigned vbytes = (unsigned)(((int64_t)p.frames * p.S - 1) * pixB + ROWB);
 #if defined(__HIP_DEVICE_COMPILE__)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(vbase), 0, (int)vbytes, 0x00020000);
 #endif
@@ -2926,9 +2952,13 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
             for (int c = 0; c < 8; ++c) g[c] = 0.f;
             if (live) {
                 const T *go = static_cast<const T *>(p.grad_out) + row * D;
-                const float4 g1 = *reinterpret_cast<const float4 *>(go + ln.off1 / 4);
-                const float4 g2 = *reinterpret_cast<const float4 *>(go + (ln.off1 + ln.delta2) / 4);
-                g[0] = g1.x; g[1] = g1.y; g[2] = g1.z; g[3] = g1.w; g[4] = g2.x; g[5] = g2.y; g[6] = g2.z; g[7] = g2.w;
+                if constexpr (kHalf) {
+                    Store<T>::load(go + cor * 8, g);
+                } else {
+                    const float4 g1 = *reinterpret_cast<const float4 *>(go + ln.off1 / 4);
+                    const float4 g2 = *reinterpret_cast<const float4 *>(go + (ln.off1 + ln.delta2) / 4);
+                    g[0] = g1.x; g[1] = g1.y; g[2] = g1.z; g[3] = g1.w; g[4] = g2.x; g[5] = g2.y; g[6] = g2.z; g[7] = g2.w;
+                }
             }
 #pragma unroll 1
             while (todo) {                                     // sl = -1: the tile's current-frame points
@@ -2951,9 +2981,8 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                     const bool mine = live && kk < npts;
                     float x = -10.f, y = -10.f, a = 0.f;       // far outside every map
                     if (mine) {
-                        const float2 xy = *reinterpret_cast<const float2 *>(loc + 2 * (idx0 + kk));
-                        x = xy.x; y = xy.y;
-                        a = aw[idx0 + kk];
+                        load_xy(loc + 2 * (idx0 + kk), x, y);
+                        a = Store<T>::get(aw + idx0 + kk);
                     }
                     const int lvl = min((int)(((unsigned)kk * invP) >> 16), L - 1);
                     // own point: fractions, validity, top-left pixel (as rs_point) + what the gradients need
@@ -2987,7 +3016,7 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                         const int vb = quad_and<R>(pt.Wb, ln.vmask);
                         const int tw = quad_and<R>(pt.Wb, ln.dymask);
                         const int pix = quad_add<R>(pt.pbase, ln.dx) + tw;
-                        int addr = SLAB ? (pix << 7) : (int)((unsigned)pix * (unsigned)pixB);
+                        int addr = SLAB ? (pix << ROWSH) : (int)((unsigned)pix * (unsigned)pixB);
                         addr = vb ? addr : (SLAB ? sh.zero_off : (int)0x80000000u);
                         int A[4];
                         quad_corner_addrs(addr, ln.off1, A);
@@ -2995,18 +3024,9 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
                             float v[8];
-                            if constexpr (SLAB) {
-                                const float4 q1 = *reinterpret_cast<const float4 *>(lds_raw + A[s]);
-                                const float4 q2 = *reinterpret_cast<const float4 *>(lds_raw + (A[s] ^ 64));
-                                v[0] = q1.x; v[1] = q1.y; v[2] = q1.z; v[3] = q1.w; v[4] = q2.x; v[5] = q2.y; v[6] = q2.z; v[7] = q2.w;
-                            } else {
 #if defined(__HIP_DEVICE_COMPILE__)
-                                const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, A[s], 0, 0);
-                                const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, A[s] + ln.delta2, 0, 0);
-                                v[0] = __uint_as_float(q1.x); v[1] = __uint_as_float(q1.y); v[2] = __uint_as_float(q1.z); v[3] = __uint_as_float(q1.w);
-                                v[4] = __uint_as_float(q2.x); v[5] = __uint_as_float(q2.y); v[6] = __uint_as_float(q2.z); v[7] = __uint_as_float(q2.w);
+                            rs_load_row8<T, SLAB>(lds_raw, rsrc, A[s], ln.delta2, v);
 #endif
-                            }
                             // (measured: issuing all eight loads of the point ahead of the dots is SLOWER, 0.63 -> 0.67 ms)
                             float acc = g[0] * v[0];
 #pragma unroll
@@ -3035,8 +3055,9 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                         const float g_aw = (hh * hw) * k0 + (hh * lw) * k1 + (lh * hw) * k2 + (lh * lw) * k3;
                         const float g_w = hh * (k1 - k0) + lh * (k3 - k2);
                         const float g_h = hw * (k2 - k0) + lw * (k3 - k1);
-                        *reinterpret_cast<float2 *>(gloc + 2 * (idx0 + kk)) = make_float2((float)W * g_w * pt.a, (float)H * g_h * pt.a);
-                        gaw[idx0 + kk] = g_aw;
+                        Store<T>::put(gloc + 2 * (idx0 + kk), (float)W * g_w * pt.a);
+                        Store<T>::put(gloc + 2 * (idx0 + kk) + 1, (float)H * g_h * pt.a);
+                        Store<T>::put(gaw + idx0 + kk, g_aw);
                     }
                 }
             }
@@ -3501,7 +3522,7 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     // the slab kernels run 4 channels per lane for every dtype (SlabStore): twice the lanes per row for 16-bit types
     constexpr int GSL = SlabStore<T>::VEC == Store<T>::VEC ? G : 2 * G;
     constexpr int RPWS = kWave / (GSL <= kWave ? GSL : kWave);
-    if constexpr (sizeof(T) == 4 && G == 8) if (!bwd && p.LA == p.L && p.L <= kSlabMaxLevels) {
+    if constexpr (G * Store<T>::VEC == 32) if (!bwd && p.LA == p.L && p.L <= kSlabMaxLevels) {
         // resident-slab forward (D = 32, 4-byte types): up to NT * 16 tiles of 16 rows per workgroup, so that the
         // per-frame slab staging is amortised
         const int mode = knobs().fwd_rs;                               // -1 auto, 0 off, 1 force
@@ -3523,7 +3544,7 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
         }
         // the slab must be worth staging: every level but the first has to fit (75 % of the taps of a DeVIS call)
         const int slab_bytes = ((160 * 1024 - 256 - kRsTailBytes) / 128) * 128;
-        if (mode != 1 && host_first_slab_level(p, (slab_bytes - kRsSlack) / kRsRowB) > 1) nt = 0;
+        if (mode != 1 && host_first_slab_level(p, (slab_bytes - kRsSlack) / rs_row_bytes<T>()) > 1) nt = 0;
         const int force_nt = knobs().fwd_rs_nt;
         if (force_nt == 1 || force_nt == 2 || force_nt == 4) { nt = force_nt; parts = (tiles_per_clip + kRsWaves * nt - 1) / (kRsWaves * nt); }
         if (mode != 0 && fits && nt && clips * p.M * parts <= 0x7fffffffLL) {
@@ -3584,7 +3605,7 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
     int rc = MSDA_OK;
     if (phases & 1) {
         bool done = false;
-        if constexpr (sizeof(T) == 4 && G == 8) if (p.LA == p.L && p.L <= kSlabMaxLevels && (p.cull_points || !p.bbox)) {
+        if constexpr (G * Store<T>::VEC == 32) if (p.LA == p.L && p.L <= kSlabMaxLevels && (p.cull_points || !p.bbox)) {
             // resident-slab gather pass (D = 32, 4-byte types): same applicability rule as the forward
             const int mode = knobs().bwd_rs;
             const int tiles_per_clip = p.frames * ((p.Lq + kRsRows - 1) / kRsRows);
@@ -3596,7 +3617,7 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
             const int slab_bytes = ((160 * 1024 - 256 - kRsTailBytes) / 128) * 128;
             int parts = (tiles_per_clip + 2 * kRsWaves - 1) / (2 * kRsWaves);       // ~2 tiles per wave (L2: see the forward)
             bool want = mode == 1 || (mode == -1 && clips * p.M * parts >= device_cus() &&
-                                      host_first_slab_level(p, (slab_bytes - kRsSlack) / kRsRowB) <= 1);
+                                      host_first_slab_level(p, (slab_bytes - kRsSlack) / rs_row_bytes<T>()) <= 1);
             if (want && fits && clips * p.M * parts <= 0x7fffffffLL) {
                 const size_t total = (size_t)slab_bytes + kRsTailBytes;
                 static LdsGrant granted;
