@@ -2239,6 +2239,13 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
         const int r0 = direct ? 0 : (part - s_first[l]) * R;
         const int r1 = direct ? H - 1 : min(H, r0 + R) - 1;
         const int npix = direct ? 0 : (r1 - r0 + 1) * W;
+        // Small bands (the last pyramid levels: 60 pixels at 360x640) would keep only npix of the 256 owner quads busy
+        // while every pixel's list is long; their hits are dealt round-robin to SF sub-lists per pixel ("virtual
+        // pixels" pix * SF + hit % SF), each with an owner quad of its own, and the SF partial sums of a pixel are
+        // added up through LDS when the item is finished.  SF = largest power of two with npix * SF <= 256 quads.
+        int sfs = 0;
+        while (npix > 0 && (npix << (sfs + 1)) <= kOwnQuads && sfs < 4) ++sfs;
+        const int SF = 1 << sfs, nvpix = npix << sfs;
         float *gmap = static_cast<float *>(p.grad_value) +
                       (((int64_t)clip * p.frames + f) * p.S + s_lsi[l]) * MD + m * D;     // pixel (0, 0) of the level, head m
 
@@ -2340,7 +2347,7 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
                         for (int c = 0; c < 4; ++c)
                             if (own[c]) {
                                 const unsigned ei = 4u * (unsigned)tid + (unsigned)c;
-                                const unsigned prev = atomicExch(&head[pix00 + dpix[c]], ei);
+                                const unsigned prev = atomicExch(&head[((pix00 + dpix[c]) << sfs) + (tid & (SF - 1))], ei);
                                 ents[ei] = make_uint2(__float_as_uint(wgt[c]), prev);
                             }
                     }
@@ -2355,7 +2362,7 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
                 for (int s = 0; s < kOwnSlots; ++s) {
                     const int pix = s * kOwnQuads + Q;
                     unsigned e = kOwnNil;
-                    if (pix < npix) { e = head[pix]; if (e != kOwnNil) head[pix] = kOwnNil; }
+                    if (pix < nvpix) { e = head[pix]; if (e != kOwnNil) head[pix] = kOwnNil; }
                     while (e != kOwnNil) {
                         const uint2 en = ents[e];
                         const float w = __uint_as_float(en.x);
@@ -2446,7 +2453,7 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
             }
         }
         // ---- owners store their pixels: grad_value is overwritten, every pixel of the band exactly once
-        if (!direct) {
+        if (!direct && SF == 1) {
             float *gband = gmap + (int64_t)r0 * W * MD;
 #pragma unroll
             for (int s = 0; s < kOwnSlots; ++s) {
@@ -2456,6 +2463,25 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
                     *reinterpret_cast<float4 *>(o + ch1) = make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
                     *reinterpret_cast<float4 *>(o + ch2) = make_float4(acc[s][4], acc[s][5], acc[s][6], acc[s][7]);
                 }
+            }
+        } else if (!direct) {
+            // split lists: the partial sums of virtual pixel v = pix * SF + sub (slot 0 of quad v) go through the (now
+            // free) row area as [v][32 channels] floats; one thread per (pixel, 4 channels) adds the SF partials
+            float *part = reinterpret_cast<float *>(rows);
+            if (Q < nvpix) {
+                *reinterpret_cast<float4 *>(part + Q * D + ch1) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+                *reinterpret_cast<float4 *>(part + Q * D + ch2) = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
+            }
+            __syncthreads();
+            float *gband = gmap + (int64_t)r0 * W * MD;
+            for (int i = tid; i < npix * (D / 4); i += kOwnThreads) {
+                const int pix = i / (D / 4), c4 = (i - pix * (D / 4)) * 4;
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int u = 0; u < SF; ++u) {
+                    const float4 t4 = *reinterpret_cast<const float4 *>(part + ((pix << sfs) + u) * D + c4);
+                    sum.x += t4.x; sum.y += t4.y; sum.z += t4.z; sum.w += t4.w;
+                }
+                *reinterpret_cast<float4 *>(gband + (int64_t)pix * MD + c4) = sum;
             }
         }
         __syncthreads();
