@@ -152,7 +152,7 @@ def algorithmic_bytes(args, e):
 
 
 def _event_ms(fn, reps, warm=3):
-    """Average duration of fn() in ms: HIP events on torch's current stream (the stream the library launches on)."""
+    """Median duration of fn() in ms: HIP events on torch's current stream (the stream the library launches on)."""
     st = torch.cuda.current_stream()
     for _ in range(warm):
         fn()
@@ -162,7 +162,8 @@ def _event_ms(fn, reps, warm=3):
         fn()
         e0.record(st)
     torch.cuda.synchronize()
-    return sum(s0.elapsed_time(e0) for s0, e0 in ev) / reps
+    ts = sorted(s0.elapsed_time(e0) for s0, e0 in ev)
+    return ts[len(ts) // 2]      # median: the small calls are host-bound and their mean is at the mercy of the CPU
 
 
 def _plain_op_case(device, dtype, shapes, N, Lq, locs, seed, M=8, D=32, P=4):
