@@ -2168,7 +2168,8 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
         s_first[kScatterMaxLevels + 1], s_lsi[kScatterMaxLevels];
     __shared__ int s_nsrc, s_cnt[3];     // survivor counters rotate: slot j is reset two barriers before it is used again
     __shared__ long long s_src_tab[kScatterMaxSources], s_src_loc[kScatterMaxSources];
-    __shared__ int s_src_q0[kScatterMaxSources];
+    __shared__ int s_src_q0[kScatterMaxSources], s_src_gmv[kScatterMaxSources];
+    __shared__ unsigned s_live[kLiveWords];            // bitmap of the cull batches that hold a live 64-query block
     __shared__ long long s_item;
 
     const int tid = threadIdx.x, lane = tid % kWave;
@@ -2260,6 +2261,7 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
                 s_src_tab[0] = ((g * p.M + m) * VL + l) * p.Lq;
                 s_src_loc[0] = (g * p.Lq * p.M + m) * ((int64_t)p.LA * p.PA) + l * p.PA;
                 s_src_q0[0] = (int)(g * p.Lq);
+                s_src_gmv[0] = (int)((g * p.M + m) * VL + l);
                 s_nsrc = 1 + (int)__popcll(bal);
             }
             if (hit) {
@@ -2269,6 +2271,7 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
                 s_src_tab[n] = ((g * p.M + m) * VL + p.LA + vl) * p.Lq;
                 s_src_loc[n] = (g * p.Lq * p.M + m) * ((int64_t)p.LB * p.PB) + vl * p.PB;
                 s_src_q0[n] = (int)(g * p.Lq);
+                s_src_gmv[n] = (int)((g * p.M + m) * VL + p.LA + vl);
             }
         }
         __syncthreads();
@@ -2399,11 +2402,41 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
                 if (p.bbox) iv = *reinterpret_cast<const int2 *>(p.bbox + (s_src_tab[k] + q) * 2);
             }
         };
+        // Long candidate ranges (encoder shapes, Lq = S): a pre-pass over the 64-query block summaries marks the cull
+        // batches that hold a block whose tap rows can reach the band; with local sampling all but a few are skipped.
+        const int nbat = (ng + kOwnThreads - 1) / kOwnThreads;
+        const bool skipping = p.bsum != nullptr && nbat > 4 && nbat <= 32 * kLiveWords;
+        if (skipping) {
+            if (tid < kLiveWords) s_live[tid] = 0u;
+            __syncthreads();
+            const int nblk = (p.Lq + kCullBlock - 1) / kCullBlock, nb_tot = s_nsrc * nblk;
+            for (int bk = tid; bk < nb_tot; bk += kOwnThreads) {
+                const int ks = bk / nblk, blk = bk - ks * nblk;
+                const int2 mm = *reinterpret_cast<const int2 *>(p.bsum + ((int64_t)s_src_gmv[ks] * nblk + blk) * 2);
+                if (mm.y >= lo && mm.x <= hi) {
+                    const int g0 = ks * p.Lq + blk * kCullBlock, g1 = min(g0 + kCullBlock, ks * p.Lq + p.Lq) - 1;
+                    atomicOr(&s_live[(g0 / kOwnThreads) >> 5], 1u << ((g0 / kOwnThreads) & 31));
+                    atomicOr(&s_live[(g1 / kOwnThreads) >> 5], 1u << ((g1 / kOwnThreads) & 31));
+                }
+            }
+            __syncthreads();
+        }
+        auto next_live = [&](int bq) {       // first batch >= bq worth culling (nbat if none); workgroup-uniform
+            if (!skipping) return min(bq, nbat);
+            while (bq < nbat) {
+                const unsigned wv = s_live[bq >> 5] >> (bq & 31);
+                if (wv) return min(bq + (int)__builtin_ctz(wv), nbat);
+                bq = (bq | 31) + 1;
+            }
+            return nbat;
+        };
         int2 iv;
         unsigned ent;
         bool live;
-        load_records(0, iv, ent, live);
-        for (int gi0 = 0; gi0 < ng || gi0 == 0; gi0 += kOwnThreads) {
+        int bcur = next_live(0);
+        if (bcur < nbat) load_records(bcur * kOwnThreads, iv, ent, live);
+        while (bcur < nbat) {
+            const int bnext = next_live(bcur + 1);
             unsigned pm = 0u;
             if (live) {
                 if (p.bbox) {
@@ -2415,8 +2448,8 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
                 }
             }
             const unsigned ent_now = ent;
-            const bool last = gi0 + kOwnThreads >= ng;
-            if (!last) load_records(gi0 + kOwnThreads, iv, ent, live);        // the next batch's records fly meanwhile
+            const bool last = bnext >= nbat;
+            if (!last) load_records(bnext * kOwnThreads, iv, ent, live);      // the next live batch's records fly meanwhile
             // wave-wide exclusive scan of the per-lane survivor counts (DPP), one LDS atomic per wave
             const int cnt = __popc(pm);
             int v = cnt;
@@ -2451,6 +2484,7 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
                 process_chunk(n, x, y, a, qrow, listed - nn, nn);
                 primed = more;
             }
+            bcur = bnext;
         }
         // ---- owners store their pixels: grad_value is overwritten, every pixel of the band exactly once
         if (!direct && SF == 1) {
@@ -3570,7 +3604,11 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
         }
         // the slab must be worth staging: every level but the first has to fit (75 % of the taps of a DeVIS call)
         const int slab_bytes = ((160 * 1024 - 256 - kRsTailBytes) / 128) * 128;
-        if (mode != 1 && host_first_slab_level(p, (slab_bytes - kRsSlack) / rs_row_bytes<T>()) > 1) nt = 0;
+        // (2-byte types: one 16-byte load per corner on the memory path too, so the kernel wins as soon as ANY level
+        // fits the slab -- 800x1333 in bf16: levels 2-3, forward 0.44 -> 0.40 ms, gather pass 0.79 -> 0.62 ms; 4-byte
+        // types pay two loads per corner there and lose unless level 0 is the only one outside: 0.67 vs 0.52 ms)
+        const int l0_max = sizeof(T) == 2 ? p.L - 1 : 1;
+        if (mode != 1 && host_first_slab_level(p, (slab_bytes - kRsSlack) / rs_row_bytes<T>()) > l0_max) nt = 0;
         const int force_nt = knobs().fwd_rs_nt;
         if (force_nt == 1 || force_nt == 2 || force_nt == 4) { nt = force_nt; parts = (tiles_per_clip + kRsWaves * nt - 1) / (kRsWaves * nt); }
         if (mode != 0 && fits && nt && clips * p.M * parts <= 0x7fffffffLL) {
@@ -3643,7 +3681,7 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
             const int slab_bytes = ((160 * 1024 - 256 - kRsTailBytes) / 128) * 128;
             int parts = (tiles_per_clip + 2 * kRsWaves - 1) / (2 * kRsWaves);       // ~2 tiles per wave (L2: see the forward)
             bool want = mode == 1 || (mode == -1 && clips * p.M * parts >= device_cus() &&
-                                      host_first_slab_level(p, (slab_bytes - kRsSlack) / rs_row_bytes<T>()) <= 1);
+                                      host_first_slab_level(p, (slab_bytes - kRsSlack) / rs_row_bytes<T>()) <= (sizeof(T) == 2 ? p.L - 1 : 1));
             if (want && fits && clips * p.M * parts <= 0x7fffffffLL) {
                 const size_t total = (size_t)slab_bytes + kRsTailBytes;
                 static LdsGrant granted;

@@ -39,4 +39,4 @@ def run(clips, pyr="A", locs="uniform", queries=300, dt="f32", layout="dense", r
           % (clips, pyr, locs, queries, dt, layout, times["0"], times["1"], diff, nan, outs["0"].abs().max().item()), flush=True)
 
 if __name__ == "__main__":
-    run(16); run(16, layout="padded"); run(16, locs="clustered"); run(8); run(32)
+    run(8, pyr="B"); run(8, pyr="B", dt="bf16"); run(16, pyr="B"); run(16, pyr="B", dt="bf16"); run(8, pyr="B", locs="clustered")
