@@ -11,7 +11,7 @@ import torch
 
 from . import build as _build
 
-MSDA_ABI_VERSION = 8
+MSDA_ABI_VERSION = 9
 BWD_WORKSPACE_BYTES = 64
 _DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.float16: 3}
 
@@ -19,7 +19,7 @@ _DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.floa
 EXPORTED_SYMBOLS = (
     "msda_version", "msda_last_error", "msda_forward", "msda_backward",
     "msda_temporal_forward", "msda_temporal_backward", "msda_backward_workspace_bytes",
-    "msda_prep_forward", "msda_prep_backward", "msda_reload_knobs", "msda_last_route",
+    "msda_prep_forward", "msda_prep_backward", "msda_reload_knobs", "msda_last_route", "msda_mask_rows",
 )
 
 _lib = None
@@ -69,6 +69,8 @@ def load():
         lib.msda_reload_knobs.argtypes = []
         lib.msda_prep_backward.restype = _ci
         lib.msda_prep_backward.argtypes = [_ci] + [_vp] * 9 + [ctypes.c_longlong] + [_ci] * 6 + [ctypes.c_longlong] + [_vp] * 5
+        lib.msda_mask_rows.restype = _ci
+        lib.msda_mask_rows.argtypes = [_ci, _vp, _vp] + [ctypes.c_longlong] * 3 + [_vp]
         _lib = lib
     return _lib
 
@@ -227,3 +229,19 @@ def prep_backward(gloc_c, gloc_t, gaw_c, gaw_t, aw_c, aw_t, ref_c, ref_t, shapes
                                        _p(aw_t), _p(ref_c), _p(ref_t), _p(shapes), rows, M, L, W, Pc, Pt, ref_c.shape[-1], ld,
                                        _p(goff_c), _p(goff_t), _p(glogit_c), _p(glogit_t), _stream(gloc_c))
     _check(rc, "msda_prep_backward")
+
+
+def mask_rows(rows, mask, row_elems):
+    """In place: zero ``rows[i, :row_elems]`` of the 2-D (possibly row-padded) view ``rows`` wherever ``mask[i]``
+    (include/msda.h msda_mask_rows; ref ms_deform_attn.py:102-103)."""
+    if not rows.is_cuda:
+        raise RuntimeError("Not implemented on the CPU (msda_mask_rows needs GPU tensors)")
+    if not (rows.dim() == 2 and rows.stride(1) == 1 and rows.shape[1] >= row_elems and
+            (rows.shape[0] <= 1 or rows.stride(0) >= row_elems)):
+        raise ValueError("mask_rows: rows must be a 2-D view with contiguous rows")
+    if not (mask.dtype == torch.bool and mask.device == rows.device and mask.is_contiguous() and mask.numel() == rows.shape[0]):
+        raise ValueError("mask_rows: padding mask must be a contiguous bool tensor with one entry per row, on the rows' device")
+    with torch.cuda.device(rows.device):
+        rc = load().msda_mask_rows(dtype_code(rows.dtype), _p(rows), _p(mask), rows.shape[0], row_elems,
+                                   rows.stride(0) if rows.shape[0] > 1 else max(row_elems, rows.stride(0)), _stream(rows))
+    _check(rc, "msda_mask_rows")

@@ -3951,6 +3951,24 @@ int run_prep(int dtype, const PrepParams &p, bool bwd, void *stream)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Padding mask (ref ms_deform_attn.py:102-103 `value.masked_fill(mask[..., None], 0)`).
+// The reference's masked_fill is a full read + write of `value`; only the masked rows change, so this pass reads the
+// [pixels] byte mask and WRITES the masked rows only (G bytes per thread): cost ~ pixels bytes + the masked rows.
+template <int G>
+__global__ __launch_bounds__(256) void msda_mask_rows_kernel(char *__restrict__ rows, const uint8_t *__restrict__ mask,
+                                                             long long pixels, int chunks, long long stride_bytes)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long pix = idx / chunks;
+    if (pix >= pixels || !mask[pix]) return;
+    char *dst = rows + pix * stride_bytes + (idx - pix * chunks) * G;
+    if constexpr (G == 16) *reinterpret_cast<uint4 *>(dst) = make_uint4(0, 0, 0, 0);
+    else if constexpr (G == 8) *reinterpret_cast<uint2 *>(dst) = make_uint2(0, 0);
+    else if constexpr (G == 4) *reinterpret_cast<uint32_t *>(dst) = 0;
+    else *reinterpret_cast<uint16_t *>(dst) = 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -4139,6 +4157,34 @@ int msda_prep_backward(int dtype, const void *grad_loc_curr, const void *grad_lo
                      (window > 0 && (!grad_loc_temp || !grad_aw_temp || !aw_temp || !grad_offsets_temp || !grad_logits_temp))))
         return fail(MSDA_ERR_ARG, "msda_prep_backward: null pointer argument%s");
     return run_prep(dtype, p, true, stream);
+}
+
+int msda_mask_rows(int dtype, void *rows, const void *padding_mask, long long pixels, long long row_elems,
+                   long long row_stride, void *stream)
+{
+    g_err[0] = 0; g_route[0] = 0;
+    const int e = dtype == MSDA_F32 ? 4 : dtype == MSDA_F64 ? 8 : (dtype == MSDA_BF16 || dtype == MSDA_F16) ? 2 : 0;
+    if (!e) return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
+    if (pixels < 0 || row_elems <= 0 || row_stride < row_elems)
+        return fail(MSDA_ERR_ARG, "msda_mask_rows: bad sizes (pixels, row elements, row stride)%s");
+    if (pixels == 0) return MSDA_OK;
+    if (!rows || !padding_mask) return fail(MSDA_ERR_ARG, "msda_mask_rows: null pointer argument%s");
+    const long long rb = row_elems * e, sb = row_stride * e;
+    const int g = (rb % 16 == 0 && sb % 16 == 0 && (reinterpret_cast<uintptr_t>(rows) & 15) == 0) ? 16 : e;
+    const long long chunks = rb / g, threads = pixels * chunks;
+    if (chunks > 0x7fffffffLL || (threads + 255) / 256 > 0x7fffffffLL)
+        return fail(MSDA_ERR_ARG, "msda_mask_rows: tensor too large for one launch%s");
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *r = static_cast<char *>(rows);
+    const uint8_t *m = static_cast<const uint8_t *>(padding_mask);
+    switch (g) {
+        case 16: hipLaunchKernelGGL(msda_mask_rows_kernel<16>, grid, block, 0, st, r, m, pixels, (int)chunks, sb); break;
+        case 8: hipLaunchKernelGGL(msda_mask_rows_kernel<8>, grid, block, 0, st, r, m, pixels, (int)chunks, sb); break;
+        case 4: hipLaunchKernelGGL(msda_mask_rows_kernel<4>, grid, block, 0, st, r, m, pixels, (int)chunks, sb); break;
+        default: hipLaunchKernelGGL(msda_mask_rows_kernel<2>, grid, block, 0, st, r, m, pixels, (int)chunks, sb); break;
+    }
+    return check_launch("msda mask rows");
 }
 
 }  // extern "C"

@@ -62,7 +62,16 @@ class MSDeformAttnFunction(Function):
 
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
-                attention_weights, im2col_step):
+                attention_weights, im2col_step, padding_mask=None):
+        # padding_mask (not in the reference's signature; used by MSDeformAttn only): the bool [N, S] mask `value`
+        # was produced under.  The backward then zeroes the masked rows of ITS grad_value (the gradient of ref
+        # ms_deform_attn.py:102-103's masked_fill) before returning it, and project_value's backward skips that pass.
+        ctx.has_mask_arg = padding_mask is not None
+        ctx.padding_mask = None
+        if padding_mask is not None:
+            _require(padding_mask.dtype == torch.bool and padding_mask.device == value.device and
+                     padding_mask.numel() == value.shape[0] * value.shape[1], "padding_mask must be a bool [N, S] tensor on value's device")
+            ctx.padding_mask = padding_mask.reshape(-1).contiguous()
         _check_inputs([("value", value), ("spatial_shapes", value_spatial_shapes),
                        ("level_start_index", value_level_start_index),
                        ("sampling_loc", sampling_locations), ("attn_weight", attention_weights)])
@@ -103,7 +112,10 @@ class MSDeformAttnFunction(Function):
                                  grad_loc[n:n + step], grad_aw[n:n + step])
         if acc != value.dtype:
             grad_value = grad_value.to(value.dtype)
-        return grad_value, None, None, grad_loc, grad_aw, None
+        if ctx.padding_mask is not None and grad_value.numel():
+            N, S, M, D = grad_value.shape
+            _native.mask_rows(grad_value.view(N * S, M * D), ctx.padding_mask, M * D)
+        return (grad_value, None, None, grad_loc, grad_aw, None) + ((None,) if ctx.has_mask_arg else ())
 
 
 class MSDeformAttnTemporalFunction(Function):
@@ -210,7 +222,7 @@ class _PaddedValueProj(Function):
     the backward GEMMs are the Linear's own."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, n_heads, pad_heads, padding_mask):
+    def forward(ctx, x, weight, bias, n_heads, pad_heads, padding_mask, consumer_masks_grad):
         N, S, C = x.shape
         out_f = weight.shape[0]
         D = out_f // n_heads
@@ -223,9 +235,12 @@ class _PaddedValueProj(Function):
             torch.mm(x2d, weight.t(), out=out2d)
         value = buf[:, :, :n_heads]
         if padding_mask is not None:
-            value.masked_fill_(padding_mask[..., None, None], 0.0)      # ref :120 on the same elements
+            # ref :102-103 on the same elements; writes the masked rows only (msda_mask_rows), not a pass over value
+            padding_mask = padding_mask.reshape(N * S).contiguous()
+            _native.mask_rows(buf.view(N * S, (n_heads + pad_heads) * D), padding_mask, out_f)
         ctx.save_for_backward(x, weight, padding_mask)
         ctx.has_bias = bias is not None
+        ctx.consumer_masks_grad = consumer_masks_grad
         return value
 
     @staticmethod
@@ -233,26 +248,28 @@ class _PaddedValueProj(Function):
     def backward(ctx, grad_value):
         x, weight, padding_mask = ctx.saved_tensors
         N, S, C = x.shape
-        if padding_mask is not None:
-            grad_value = grad_value.masked_fill(padding_mask[..., None, None], 0.0)
+        if padding_mask is not None and not ctx.consumer_masks_grad:
+            # the gradient of masked_fill: masked rows get none.  Out of place -- an incoming gradient is not ours to
+            # modify; MSDeformAttn avoids this pass by letting the operator mask the grad_value it produces
+            grad_value = grad_value.masked_fill(padding_mask.view(N, S, 1, 1), 0.0)
         g2d = grad_value.reshape(N * S, weight.shape[0])
         x2d = x.reshape(N * S, C)
         grad_x = (g2d @ weight).view(N, S, C) if ctx.needs_input_grad[0] else None
         grad_w = g2d.t() @ x2d if ctx.needs_input_grad[1] else None
         grad_b = g2d.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return grad_x, grad_w, grad_b, None, None, None
+        return grad_x, grad_w, grad_b, None, None, None, None
 
 
-def project_value(x, linear, n_heads, padding_mask=None, pad_heads=1):
-    """``linear(x)`` viewed as ``value[N, S, M, D]`` (masked like ref ms_deform_attn.py:118-121), stored with
+def project_value(x, linear, n_heads, padding_mask=None, pad_heads=1, consumer_masks_grad=False):
+    """``linear(x)`` viewed as ``value[N, S, M, D]`` (masked like ref ms_deform_attn.py:101-103), stored with
     ``pad_heads`` spare head slots per pixel row -- see :class:`_PaddedValueProj`.  ``pad_heads=0`` is the
-    reference's dense layout."""
-    if pad_heads <= 0:
-        value = linear(x)
-        if padding_mask is not None:
-            value = value.masked_fill(padding_mask[..., None], float(0))
-        return value.view(x.shape[0], x.shape[1], n_heads, linear.out_features // n_heads)
-    return _PaddedValueProj.apply(x, linear.weight, linear.bias, n_heads, pad_heads, padding_mask)
+    reference's dense layout.  The mask is applied by ``msda_mask_rows`` (writes the masked rows only).
+    ``consumer_masks_grad``: the caller promises that the gradient flowing back into ``value`` already has zero
+    rows where the mask is set (``MSDeformAttnFunction`` given the same ``padding_mask``), so the backward skips it."""
+    if pad_heads <= 0 and padding_mask is None:
+        return linear(x).view(x.shape[0], x.shape[1], n_heads, linear.out_features // n_heads)
+    return _PaddedValueProj.apply(x, linear.weight, linear.bias, n_heads, max(pad_heads, 0), padding_mask,
+                                  bool(consumer_masks_grad) and padding_mask is not None)
 
 
 def _check_prep_inputs(y, named_refs, shapes):

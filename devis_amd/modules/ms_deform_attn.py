@@ -124,7 +124,8 @@ class MSDeformAttn(nn.Module):
 
         # value_proj writes value[N, S, M, D] with one spare head slot per pixel row (SURVEY f-3): same
         # numbers as ref :118-121, a layout the gather kernels read ~15 % faster; value_pad_heads = 0: dense
-        value = project_value(input_flatten, self.value_proj, M, input_padding_mask, self.value_pad_heads)
+        value = project_value(input_flatten, self.value_proj, M, input_padding_mask, self.value_pad_heads,
+                              consumer_masks_grad=True)         # the operator below zeroes grad_value's masked rows
         if reference_points.shape[-1] not in (2, 4):
             raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
                 reference_points.shape[-1]))
@@ -143,9 +144,9 @@ class MSDeformAttn(nn.Module):
             weights = weights.view(N, Len_q, M, L, P)
             locations = _locations(reference_points[:, :, None, :, None, :], offsets,
                                    _normalizer(input_spatial_shapes), P)
-        output = MSDeformAttnFunction.apply(value, input_spatial_shapes,
-                                            input_level_start_index, locations.contiguous(),
-                                            weights.contiguous(), self.im2col_step)
+        args = (value, input_spatial_shapes, input_level_start_index, locations.contiguous(), weights.contiguous(),
+                self.im2col_step)
+        output = MSDeformAttnFunction.apply(*(args if input_padding_mask is None else args + (input_padding_mask,)))
         return self.output_proj(output), None
 
 

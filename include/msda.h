@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 8
+#define MSDA_ABI_VERSION 9
 #define MSDA_BWD_WORKSPACE_BYTES 64   /* minimum device scratch of the backward entry points (ticket counters) */
 
 enum msda_dtype { MSDA_F32 = 0, MSDA_F64 = 1, MSDA_BF16 = 2, MSDA_F16 = 3 };
@@ -218,6 +218,18 @@ int msda_prep_backward(int dtype, const void *grad_loc_curr, const void *grad_lo
                        int num_levels, int window, int num_curr_point, int num_temp_point, int ref_dim,
                        long long raw_row_stride, void *grad_offsets_curr, void *grad_offsets_temp,
                        void *grad_logits_curr, void *grad_logits_temp, void *stream);
+
+/*
+ * Padding mask.  Replaces `value.masked_fill(input_padding_mask[..., None], 0)`
+ * (ms_deform_attn.py:102-103) and the matching mask on grad_value: zeroes, IN PLACE, row i of `rows` for every i with
+ * padding_mask[i] != 0 and touches nothing else -- the cost is the `pixels` mask bytes plus the masked rows, not a
+ * read + write of the whole tensor.
+ *   rows          [pixels, row_elems] of `dtype`, row i at element offset i * row_stride (row_stride >= row_elems:
+ *                 the dense value tensor has row_stride = M*D, the padded one (M + pad)*D)
+ *   padding_mask  [pixels] bytes (a torch.bool tensor), device
+ */
+int msda_mask_rows(int dtype, void *rows, const void *padding_mask, long long pixels, long long row_elems,
+                   long long row_stride, void *stream);
 
 #ifdef __cplusplus
 }

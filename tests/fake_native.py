@@ -58,3 +58,8 @@ def install(monkeypatch):
     monkeypatch.setattr(_native, "backward", backward)
     monkeypatch.setattr(_native, "temporal_forward", temporal_forward)
     monkeypatch.setattr(_native, "temporal_backward", temporal_backward)
+
+    def mask_rows(rows, mask, row_elems):                 # contract of msda_mask_rows: masked rows -> 0, in place
+        rows[:, :row_elems].masked_fill_(mask.reshape(-1, 1), 0.0)
+
+    monkeypatch.setattr(_native, "mask_rows", mask_rows)

@@ -269,3 +269,42 @@ def test_round2_kernels_forced_on_odd_shapes(case, dtype, tol, monkeypatch):
                 assert bad.mean() <= (1e-3 if dtype == torch.float32 else 2e-2), (c, i, bad.mean())
             else:
                 assert _maxabs(mine, b) <= tol * max(1.0, np.abs(b).max()), (c, i)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16, torch.float16], ids=["f32", "f64", "bf16", "f16"])
+def test_mask_rows_zeroes_exactly_the_masked_rows(dtype):
+    """msda_mask_rows (SURVEY f-3; ref ms_deform_attn.py:102-103): dense and row-padded tensors, 16-byte and odd row
+    sizes, an unaligned base; equal to masked_fill bit for bit, pad columns and unmasked rows untouched (NaN canaries)."""
+    from devis_amd import _native
+    g = torch.Generator().manual_seed(11)
+    for pixels, elems, stride, offset in ((1000, 256, 256, 0), (777, 256, 288, 0), (130, 20, 27, 0), (64, 24, 24, 3), (1, 8, 8, 0)):
+        buf = torch.randn(pixels * stride + offset + 8, generator=g).to(DEV, dtype)
+        rows = buf[offset:offset + pixels * stride].view(pixels, stride)
+        rows[:, elems:] = float("nan")                                  # the pad columns must not be touched
+        mask = (torch.rand(pixels, generator=g) < 0.3).to(DEV)
+        want = rows.clone()
+        want[:, :elems] = want[:, :elems].masked_fill(mask[:, None], 0.0)
+        _native.mask_rows(rows[:, :elems] if stride > elems else rows, mask, elems)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(rows, nan=123.0), torch.nan_to_num(want, nan=123.0)), (pixels, elems, stride)
+        assert torch.isnan(rows[:, elems:]).all()
+    with pytest.raises(ValueError):
+        _native.mask_rows(rows, mask[:0], 8)
+
+
+@pytest.mark.parametrize("pad", [0, 1])
+def test_plain_module_mask_is_applied_by_mask_rows_both_ways(pad, monkeypatch):
+    """MSDeformAttn with a padding mask: value is masked by msda_mask_rows and grad_value by the operator's backward
+    (no masked_fill pass over either); same numbers as the reference module fixtures (which carry a mask), in the
+    padded and the dense value layout."""
+    from devis_amd import _native
+    from devis_amd.modules import MSDeformAttn
+    monkeypatch.setattr(MSDeformAttn, "value_pad_heads", pad)
+    calls = []
+    real = _native.mask_rows
+    monkeypatch.setattr(_native, "mask_rows", lambda *a: (calls.append(a[0].shape), real(*a))[1])
+    got, g = module_cases.run("mod_plain_ref2", DEV, torch.float64)
+    module_cases.compare(got, g, rtol=1e-9, atol=1e-11)
+    assert len(calls) == 2, calls                                      # value, then grad_value
+    got, g = module_cases.run("mod_plain_ref4", DEV, torch.float32)
+    module_cases.compare(got, g, rtol=1e-4, atol=1e-5)

@@ -145,17 +145,21 @@ def test_frame_table_is_cached_per_offset_tensors():
     assert c is not b
 
 
-def test_project_value_padded_equals_dense_linear():
-    """functions.project_value (SURVEY f-3): value_proj written with a padded pixel stride gives the same
-    value tensor and the same gradients (input, weight, bias) as the reference's dense Linear + masked_fill
-    (ms_deform_attn.py:118-121); only the strides differ."""
+def test_project_value_padded_equals_dense_linear(monkeypatch):
+    """functions.project_value (SURVEY f-3): value_proj written with a padded pixel stride and masked by
+    msda_mask_rows (here: its CPU test double) gives the same value tensor and the same gradients (input, weight,
+    bias) as the reference's dense Linear + masked_fill (ms_deform_attn.py:101-103); only the strides differ.  The
+    caller's cotangent is never modified."""
     from devis_amd.functions import project_value
+    fake_native.install(monkeypatch)
     torch.manual_seed(3)
     lin = torch.nn.Linear(24, 32).double()
     x = torch.randn(2, 13, 24, dtype=torch.float64, requires_grad=True)
     mask = torch.rand(2, 13) < 0.3
     cot = torch.randn(2, 13, 4, 8, dtype=torch.float64)
-    res = []
+    cot0 = cot.clone()
+    ref = lin(x).masked_fill(mask[..., None], float(0)).view(2, 13, 4, 8)           # the reference's lines
+    res = [[ref.detach().clone()] + [t.clone() for t in torch.autograd.grad(ref, (x, lin.weight, lin.bias), cot)]]
     for pad in (0, 1, 3):
         v = project_value(x, lin, 4, mask, pad_heads=pad)
         assert v.shape == (2, 13, 4, 8)
@@ -164,10 +168,16 @@ def test_project_value_padded_equals_dense_linear():
             assert v.stride() == (13 * (4 + pad) * 8, (4 + pad) * 8, 8, 1)
         g = torch.autograd.grad(v, (x, lin.weight, lin.bias), cot)
         res.append([v.detach().clone()] + [t.clone() for t in g])
+    # consumer_masks_grad: the backward trusts the incoming gradient to be masked already
+    v = project_value(x, lin, 4, mask, pad_heads=1, consumer_masks_grad=True)
+    g = torch.autograd.grad(v, (x, lin.weight, lin.bias), cot.masked_fill(mask[..., None, None], 0.0))
+    res.append([v.detach().clone()] + [t.clone() for t in g])
     for other in res[1:]:
         for a, b in zip(res[0], other):
             torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-13)
     assert (res[1][0][mask] == 0).all()
+    assert torch.equal(cot, cot0)
+    assert project_value(x, lin, 4, None, pad_heads=0).is_contiguous()
 
 
 def test_cached_argument_builders_match_the_reference_formulas():
