@@ -67,6 +67,33 @@ constexpr int kPch = 16;    // sampling points per LDS chunk (= L*P of the DeVIS
 typedef __hip_bfloat16 bf16_t;
 typedef __half f16_t;
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// raw lane vector (as a buffer load returns it) -> fp32 channels
+__device__ __forceinline__ void unpack_raw(const float *, u32x4 q, float (&v)[4])
+{
+    v[0] = __uint_as_float(q.x); v[1] = __uint_as_float(q.y); v[2] = __uint_as_float(q.z); v[3] = __uint_as_float(q.w);
+}
+__device__ __forceinline__ void unpack_pair(const __hip_bfloat16 *, uint32_t w, float &lo, float &hi)
+{
+    lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u);      // bf16 -> f32 is a 16-bit shift
+}
+__device__ __forceinline__ void unpack_pair(const __half *, uint32_t w, float &lo, float &hi)
+{
+    const float2 f = __half22float2(*reinterpret_cast<const __half2 *>(&w));
+    lo = f.x; hi = f.y;
+}
+template <typename T> __device__ __forceinline__ void unpack_raw(const T *t, u32x4 q, float (&v)[8])
+{
+    unpack_pair(t, q.x, v[0], v[1]); unpack_pair(t, q.y, v[2], v[3]);
+    unpack_pair(t, q.z, v[4], v[5]); unpack_pair(t, q.w, v[6], v[7]);
+}
+template <typename T> __device__ __forceinline__ void unpack_raw(const T *t, u32x2 q, float (&v)[4])
+{
+    unpack_pair(t, q.x, v[0], v[1]); unpack_pair(t, q.y, v[2], v[3]);
+}
+
 template <typename T> struct Store;   // VEC = elements per 16-byte lane vector
 template <> struct Store<float> {
     static constexpr int VEC = 4;
@@ -185,6 +212,28 @@ __device__ __forceinline__ void gather_load(const T *base, int elem_off, unsigne
     S::load(reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + off), v);
 }
 
+// The forward flavour: the same access as a BUFFER load whose resource ends with the clip (`num_records` = the bytes
+// one (clip, head) base can reach).  Corners outside the map carry the offset kOobBytes, beyond every resource, and
+// read as zeros without touching memory -- not as pixel 0 times weight 0, which would turn a non-finite value at
+// an unrelated pixel into NaN (the reference does not read such corners at all, cuh:56-80).  The backward kernels
+// mask the dots of such corners by their validity bits instead and keep the plain loads.
+constexpr unsigned kOobBytes = 0xF0000000u;
+template <typename T> constexpr int oob_elems() { return (int)(kOobBytes / sizeof(T)); }
+template <typename S, typename T, int N>
+__device__ __forceinline__ void gather_load_z(__amdgpu_buffer_rsrc_t rsrc, int elem_off, unsigned lane_bytes, float (&v)[N])
+{
+    const unsigned off = ((unsigned)elem_off * (unsigned)sizeof(T)) + lane_bytes;
+    if constexpr (N * sizeof(T) == 16) unpack_raw(static_cast<const T *>(nullptr), __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0), v);
+    else unpack_raw(static_cast<const T *>(nullptr), __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0), v);
+}
+// resource over everything `vbase` (a (clip, head) base) can reach inside its clip
+template <typename T>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t clip_resource(const T *vbase, int64_t pixels, int v_pix, int D)
+{
+    const int64_t bytes = ((pixels - 1) * v_pix + D) * (int64_t)sizeof(T);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(vbase), 0, (int)bytes, 0x00020000);
+}
+
 // hardware float atomics (global_atomic_add_f32 / _f64, no return value, no CAS loop)
 __device__ __forceinline__ void atomic_accumulate(float *p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_accumulate(double *p, double v) { unsafeAtomicAdd(p, v); }
@@ -251,10 +300,10 @@ struct Taps {
     int hl;            // floor(h_im): top tap row (-1 .. H-1), meaningful when valid != 0
 };
 
-__device__ __forceinline__ Taps make_taps(float x, float y, const Level lv, int MD)
+__device__ __forceinline__ Taps make_taps(float x, float y, const Level lv, int MD, int oob = 0)
 {
     Taps t;
-    t.off[0] = t.off[1] = t.off[2] = t.off[3] = 0;
+    t.off[0] = t.off[1] = t.off[2] = t.off[3] = oob;      // corners outside the map (forward: reads as zeros)
     t.w[0] = t.w[1] = t.w[2] = t.w[3] = 0.f;
     t.lh = t.lw = 0.f;
     t.valid = 0;
@@ -382,7 +431,7 @@ __device__ __forceinline__ void build_chunk(const Params &p, const ChunkRef<T> &
         const int rr = i / kPch, pp = i % kPch;
         const int vl = c.vl_base + min(c.p0 + pp, c.LP - 1) / c.P;
         const float a = st.a[k];
-        const Taps t = make_taps(st.x[k], st.y[k], s_lvl[vl], MD);
+        const Taps t = make_taps(st.x[k], st.y[k], s_lvl[vl], MD, BWD ? 0 : oob_elems<T>());
         s_off[rr * kRowSlots + pp] = make_int4(t.off[0], t.off[1], t.off[2], t.off[3]);
         if (BWD) {
             s_w[rr * kRowSlots + pp] = make_float4(t.w[0], t.w[1], t.w[2], t.w[3]);
@@ -424,6 +473,7 @@ msda_fwd_tile_kernel(const Params p)
     const int rows_valid = min(RPW, p.Lq - q0);
     const int MD = p.M * p.D;
     const T *__restrict__ vbase = static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head;   // wave-uniform
+    const __amdgpu_buffer_rsrc_t rsrc = clip_resource(vbase, (int64_t)p.frames * p.S, p.v_pix, p.D);
     const unsigned lane_bytes = (unsigned)(sub * VEC * (int)sizeof(T));
     const int64_t row0 = ((int64_t)group * p.Lq + q0) * p.M + m;   // row of rr = 0; next row: + M
 
@@ -455,10 +505,10 @@ msda_fwd_tile_kernel(const Params p)
             for (int b = 0; b < NB; ++b) { o[b] = ro[pp + b]; w[b] = rw[pp + b]; }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                gather_load<Store<T>>(vbase, o[b].x, lane_bytes, v[b][0]);
-                gather_load<Store<T>>(vbase, o[b].y, lane_bytes, v[b][1]);
-                gather_load<Store<T>>(vbase, o[b].z, lane_bytes, v[b][2]);
-                gather_load<Store<T>>(vbase, o[b].w, lane_bytes, v[b][3]);
+                gather_load_z<Store<T>, T>(rsrc, o[b].x, lane_bytes, v[b][0]);
+                gather_load_z<Store<T>, T>(rsrc, o[b].y, lane_bytes, v[b][1]);
+                gather_load_z<Store<T>, T>(rsrc, o[b].z, lane_bytes, v[b][2]);
+                gather_load_z<Store<T>, T>(rsrc, o[b].w, lane_bytes, v[b][3]);
             }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
@@ -540,12 +590,13 @@ msda_fwd_slab_kernel(const Params p, int slab_elems)
     Level *s_lvl = reinterpret_cast<Level *>(s_w + RPW * kRowSlots);
 
     if (tid == 0) {
-        const int l0 = first_slab_level(p, slab_elems - 2048 / (int)sizeof(T));    // slack: last LDS-DMA piece
+        // slack: last LDS-DMA piece; one more row: slab row 0 is the ZERO ROW corners outside the map read
+        const int l0 = first_slab_level(p, slab_elems - 2048 / (int)sizeof(T) - p.D);
         const int px0 = l0 < L ? (int)p.lsi[l0] : 0;
         int npx = 0;
         for (int l = l0; l < L; ++l) {
             s_sH[l] = (int)p.shapes[2 * l]; s_sW[l] = (int)p.shapes[2 * l + 1];
-            s_sStart[l] = (int)p.lsi[l] - px0;
+            s_sStart[l] = (int)p.lsi[l] - px0 + 1;                 // + the zero row
             npx += s_sH[l] * s_sW[l];
         }
         s_l0 = l0; s_px0 = px0; s_npx = npx;
@@ -574,6 +625,10 @@ msda_fwd_slab_kernel(const Params p, int slab_elems)
     const T *__restrict__ vbase = static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head;   // wave-uniform
     const unsigned lane_bytes = (unsigned)(sub * VEC * (int)sizeof(T));
     const T *slab_lane = slab + sub * VEC;
+    const __amdgpu_buffer_rsrc_t rsrc = clip_resource(vbase, (int64_t)p.frames * p.S, p.v_pix, p.D);
+    // the zero row (never overwritten by the staging): a corner outside the map carries slab offset 0 / a buffer
+    // offset beyond the clip and reads zeros either way (see gather_load_z)
+    for (int i = tid; i < D; i += kSlabThreads) SlabStore<T>::put(slab + i, 0.f);
     const int64_t row0 = ((int64_t)group * p.Lq + q0) * p.M + m;
 
     float acc[VEC];
@@ -592,7 +647,7 @@ msda_fwd_slab_kernel(const Params p, int slab_elems)
                 const T *gp = src + (int64_t)px * p.v_pix + (lane % GS) * (16 / (int)sizeof(T));
 #if defined(__HIP_DEVICE_COMPILE__)      // device-only builtin: keep the host pass (kernel stub) clean
                 __builtin_amdgcn_global_load_lds(
-                    gp, (__attribute__((address_space(3))) void *)(slab + (size_t)pb * D), 16, 0, 0);
+                    gp, (__attribute__((address_space(3))) void *)(slab + (size_t)(pb + 1) * D), 16, 0, 0);
 #else
                 (void)gp;
 #endif
@@ -634,7 +689,7 @@ msda_fwd_slab_kernel(const Params p, int slab_elems)
                         Level lv; lv.H = s_sH[l]; lv.W = s_sW[l]; lv.start = s_sStart[l]; lv.pad = 0;
                         tp = make_taps(x, y, lv, D);               // offsets inside the slab (stride D)
                     } else {
-                        tp = make_taps(x, y, s_lvl[vl0 + l], p.v_pix);
+                        tp = make_taps(x, y, s_lvl[vl0 + l], p.v_pix, oob_elems<T>());
                     }
                     s_off[rr * kRowSlots + pp] = make_int4(tp.off[0], tp.off[1], tp.off[2], tp.off[3]);
                     s_w[rr * kRowSlots + pp] = make_float4(tp.w[0] * a, tp.w[1] * a, tp.w[2] * a, tp.w[3] * a);
@@ -660,10 +715,10 @@ msda_fwd_slab_kernel(const Params p, int slab_elems)
                             SlabStore<T>::load(slab_lane + o[b].z, v[b][2]);
                             SlabStore<T>::load(slab_lane + o[b].w, v[b][3]);
                         } else {
-                            gather_load<SlabStore<T>>(vbase, o[b].x, lane_bytes, v[b][0]);
-                            gather_load<SlabStore<T>>(vbase, o[b].y, lane_bytes, v[b][1]);
-                            gather_load<SlabStore<T>>(vbase, o[b].z, lane_bytes, v[b][2]);
-                            gather_load<SlabStore<T>>(vbase, o[b].w, lane_bytes, v[b][3]);
+                            gather_load_z<SlabStore<T>, T>(rsrc, o[b].x, lane_bytes, v[b][0]);
+                            gather_load_z<SlabStore<T>, T>(rsrc, o[b].y, lane_bytes, v[b][1]);
+                            gather_load_z<SlabStore<T>, T>(rsrc, o[b].z, lane_bytes, v[b][2]);
+                            gather_load_z<SlabStore<T>, T>(rsrc, o[b].w, lane_bytes, v[b][3]);
                         }
                     }
 #pragma unroll
@@ -2576,7 +2631,6 @@ constexpr int kRsMaxFrames = 32;        // frames x frames slot masks live in LD
 constexpr int kRsRowB = 128;            // bytes of one pixel of one head in a 4-byte type (D = 32); 64 in a 2-byte type
 constexpr int kRsTailBytes = kRsRowB + kRsMaxFrames * kRsMaxFrames * 4 + 4 * kSlabMaxLevels * 4 + 16;   // after the slab
 template <typename T> constexpr int rs_row_bytes() { return 32 * (int)sizeof(T); }
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // The 8 channels a lane holds of one pixel row whose (this lane's) slice starts at LDS byte address `a` / buffer byte
 // offset `a`: 4-byte types -- [4c, 4c+4) of both 64-byte halves, the second half at a ^ 64 (LDS) or a + delta2
@@ -3799,7 +3853,7 @@ int dispatch_tile(const Params &p, bool bwd, hipStream_t stream, bool &taken)
         return MSDA_OK;
     // element offsets inside one clip slab are 32-bit in the tap records
     if ((int64_t)p.frames * p.S * p.M * p.D >= 0x7fffffffLL || (int64_t)p.frames * p.S * p.v_pix >= 0x7fffffffLL ||
-        (int64_t)p.frames * p.S * p.v_pix * (int64_t)sizeof(T) >= 0xffffffffLL)       // gather_load: 32-bit byte offsets
+        (int64_t)p.frames * p.S * p.v_pix * (int64_t)sizeof(T) >= (int64_t)kOobBytes)  // gather_load: 32-bit byte offsets < kOobBytes
         return MSDA_OK;
     if (p.v_clip % VEC || p.v_head % VEC || p.v_pix % VEC) return MSDA_OK;
     // the one-kernel backward scatters grad_value (always dense) at value's offsets
