@@ -3608,6 +3608,39 @@ int host_first_slab_level(const Params &p, long long cap_pixels)
     return (long long)p.S <= cap_pixels ? 0 : ((double)p.S * 0.2551 <= (double)cap_pixels ? 1 : 2);
 }
 
+// Pixels of the levels below l0 (the ones the resident-slab kernels gather through the L2), from the host copy of the
+// shapes or, without one, from the usual stride-2 pyramid proportions.
+long long host_pixels_below(const Params &p, int l0)
+{
+    if (l0 <= 0) return 0;
+    if (p.shapes_host) {
+        long long acc = 0;
+        for (int l = 0; l < l0 && l < p.L; ++l) acc += (long long)p.shapes_host[2 * l] * p.shapes_host[2 * l + 1];
+        return acc;
+    }
+    return l0 >= p.L ? p.S : (long long)((double)p.S * (l0 == 1 ? 0.75 : 0.94));
+}
+
+// Tiles per wave of the resident-slab kernels = how many workgroups share one (clip, head).  Every workgroup of a
+// pair gathers the non-resident levels from the same maps, and what an XCD's 4 MiB L2 keeps of them decides the
+// kernels' speed: take the LARGEST workgroups (least slab staging) whose pairs in flight per
+// XCD still fit the L2, else the smallest.  Measured, forward, 16 clips of the DeVIS decoder shape: fp32 (460 KiB per
+// map) 4 / 2 / 1 tiles per wave = 0.52 / 0.46 / 0.48 ms; bf16 (230 KiB) 0.35 / 0.38 / 0.39 ms.
+int rs_tiles_per_wave(const Params &p, int tiles_per_clip, long long outside_bytes, bool force)
+{
+    const int64_t clips = p.groups / p.frames;
+    const int cus_per_xcd = device_cus() / 8 > 0 ? device_cus() / 8 : 1;
+    int pick = 0;
+    for (int cand : {4, 2, 1}) {
+        const int parts = (tiles_per_clip + kRsWaves * cand - 1) / (kRsWaves * cand);
+        if (!force && clips * p.M * parts < device_cus()) continue;          // must fill the chip
+        pick = cand;
+        const long long pairs = (cus_per_xcd + parts - 1) / parts;
+        if (pairs * outside_bytes <= 4ll * 1024 * 1024) break;
+    }
+    return pick;
+}
+
 // Can grad_value go through the LDS scatter kernel?  MSDA_BWD_MODE=atomic forces the one-kernel
 // backward with global atomics (kept for A/B measurements and as the any-shape path).
 bool standard_value_layout(const Params &p)
@@ -3645,24 +3678,17 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
         const int64_t pixB = (int64_t)p.v_pix * (int64_t)sizeof(T);
         const bool fits = (int64_t)p.frames * p.S < (1 << 24) && pixB < (1 << 24) && p.D == 32 &&
                           (int64_t)p.frames * p.S * pixB < 0x7fffffffLL && p.frames <= kRsMaxFrames && p.window <= 31;
-        // Tiles per wave (NT) and workgroups per (clip, head) (parts).  Measured (16 clips of the DeVIS decoder
-        // shape): the kernel is bound by the L2 misses of the level-0 gathers -- every workgroup of a (clip,
-        // head) pair gathers from the same 460 KiB map, and an XCD's 4 MiB L2 holds the maps of ~8 pairs -- so
-        // MORE, smaller workgroups per pair (parts = 4: 8 pairs in flight per XCD) beat fewer, larger ones
-        // (parts = 2: 16 pairs, 0.55 vs 0.47 ms) although each stages its own copy of the slab.  NT = 1 only
-        // when that is what it takes to fill the chip.
-        int nt = 0, parts = 0;
-        for (int cand : {2, 1}) {
-            const int c = (tiles_per_clip + kRsWaves * cand - 1) / (kRsWaves * cand);
-            if (mode == 1 || clips * p.M * c >= device_cus()) { nt = cand; parts = c; break; }
-        }
+        // tiles per wave (NT) and workgroups per (clip, head) (parts): see rs_tiles_per_wave
         // the slab must be worth staging: every level but the first has to fit (75 % of the taps of a DeVIS call)
         const int slab_bytes = ((160 * 1024 - 256 - kRsTailBytes) / 128) * 128;
+        const int l0_host = host_first_slab_level(p, (slab_bytes - kRsSlack) / rs_row_bytes<T>());
+        int nt = rs_tiles_per_wave(p, tiles_per_clip, host_pixels_below(p, l0_host) * rs_row_bytes<T>(), mode == 1);
+        int parts = nt ? (tiles_per_clip + kRsWaves * nt - 1) / (kRsWaves * nt) : 0;
         // (2-byte types: one 16-byte load per corner on the memory path too, so the kernel wins as soon as ANY level
         // fits the slab -- 800x1333 in bf16: levels 2-3, forward 0.44 -> 0.40 ms, gather pass 0.79 -> 0.62 ms; 4-byte
         // types pay two loads per corner there and lose unless level 0 is the only one outside: 0.67 vs 0.52 ms)
         const int l0_max = sizeof(T) == 2 ? p.L - 1 : 1;
-        if (mode != 1 && host_first_slab_level(p, (slab_bytes - kRsSlack) / rs_row_bytes<T>()) > l0_max) nt = 0;
+        if (mode != 1 && l0_host > l0_max) nt = 0;
         const int force_nt = knobs().fwd_rs_nt;
         if (force_nt == 1 || force_nt == 2 || force_nt == 4) { nt = force_nt; parts = (tiles_per_clip + kRsWaves * nt - 1) / (kRsWaves * nt); }
         if (mode != 0 && fits && nt && clips * p.M * parts <= 0x7fffffffLL) {
@@ -3733,9 +3759,10 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
                               (int64_t)p.frames * p.S * pixB < 0x7fffffffLL && p.frames <= kRsMaxFrames && p.window <= 31 &&
                               (int64_t)(p.PA > p.PB ? p.PA : p.PB) * (p.PA > p.PB ? p.PA : p.PB) * p.L < 65536;   // kk / P by reciprocal
             const int slab_bytes = ((160 * 1024 - 256 - kRsTailBytes) / 128) * 128;
-            int parts = (tiles_per_clip + 2 * kRsWaves - 1) / (2 * kRsWaves);       // ~2 tiles per wave (L2: see the forward)
-            bool want = mode == 1 || (mode == -1 && clips * p.M * parts >= device_cus() &&
-                                      host_first_slab_level(p, (slab_bytes - kRsSlack) / rs_row_bytes<T>()) <= (sizeof(T) == 2 ? p.L - 1 : 1));
+            const int l0_host = host_first_slab_level(p, (slab_bytes - kRsSlack) / rs_row_bytes<T>());
+            const int tpw = rs_tiles_per_wave(p, tiles_per_clip, host_pixels_below(p, l0_host) * rs_row_bytes<T>(), mode == 1);
+            const int parts = tpw ? (tiles_per_clip + tpw * kRsWaves - 1) / (tpw * kRsWaves) : 1;       // (L2: see the forward)
+            bool want = mode == 1 || (mode == -1 && tpw && l0_host <= (sizeof(T) == 2 ? p.L - 1 : 1));
             if (want && fits && clips * p.M * parts <= 0x7fffffffLL) {
                 const size_t total = (size_t)slab_bytes + kRsTailBytes;
                 static LdsGrant granted;
