@@ -266,6 +266,7 @@ struct Params {
                                 // (built from the per-point records; lets long candidate ranges skip dead blocks) or null
     const int64_t *shapes_host; // HOST copy of `shapes` or null: kernel selection only (never dereferenced on the device)
     int cull_points;            // bbox entries are 4 x int16 top tap rows, one per POINT (PA, PB <= 4), not (min, max)
+    int wide_stores;            // bwd: the four gradient arrays are 16-byte aligned (resident-slab gather pass: whole-row stores)
     int dbg;                    // measurement hooks (MSDA_DBG env), 0 in production
 };
 
@@ -3010,6 +3011,32 @@ __device__ __forceinline__ void quad_sum4(float (&d)[4])
                  : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
 }
 
+// 4 x 4 transpose inside a quad: lane c, element e  <-  lane e, element c  (two butterfly stages of one DPP move and
+// three selects per pair of elements)
+template <typename V>
+__device__ __forceinline__ void quad_transpose4(V (&a)[4], int c)
+{
+    static_assert(sizeof(V) == 4, "32-bit elements");
+    auto xchg = [&](int lo, int hi, bool up, int ctrl) {
+        const V send = up ? a[lo] : a[hi];
+        int bits;
+        __builtin_memcpy(&bits, &send, 4);
+        const int got = ctrl == 1 ? __builtin_amdgcn_mov_dpp(bits, 0xB1, 0xf, 0xf, true)      // quad_perm [1,0,3,2]
+                                  : __builtin_amdgcn_mov_dpp(bits, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+        V r;
+        __builtin_memcpy(&r, &got, 4);
+        a[lo] = up ? r : a[lo];
+        a[hi] = up ? a[hi] : r;
+    };
+    xchg(0, 1, (c & 1) != 0, 1); xchg(2, 3, (c & 1) != 0, 1);
+    xchg(0, 2, (c & 2) != 0, 2); xchg(1, 3, (c & 2) != 0, 2);
+}
+// a[i] = v for the (wave-uniform) index i: four selects instead of a dynamically indexed register array
+template <typename V> __device__ __forceinline__ void set4(V (&a)[4], int i, V v)
+{
+    a[0] = i == 0 ? v : a[0]; a[1] = i == 1 ? v : a[1]; a[2] = i == 2 ? v : a[2]; a[3] = i == 3 ? v : a[3];
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kRsThreads)
 msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
@@ -3089,6 +3116,14 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                 const int64_t idx0 = row * LP + (sl < 0 ? 0 : sl * L * P);
                 const unsigned invP = (65536u + (unsigned)P - 1u) / (unsigned)P;      // kk / P for kk * P < 2^16
                 const int first_slab_pt = l0 * P;              // points of levels >= l0 read the slab
+                // 4 levels x 4 points (every DeVIS call): the slot's results are kept in registers and leave as whole rows --
+                // per quad 128 contiguous bytes of grad_loc and 64 of grad_attn in three 16-byte stores per lane, and the
+                // culling records of a level as one 8-byte store per row -- instead of 4- and 2-byte stores group by group
+                // (the 16-byte grad_attn pieces and 2-byte records were written back as partial lines: WRITE_SIZE 572 MB
+                // for 309 MB of results)
+                const bool wide = p.wide_stores && P == 4 && npts == 16;
+                float wx[4] = {0.f, 0.f, 0.f, 0.f}, wy[4] = {0.f, 0.f, 0.f, 0.f}, wa[4] = {0.f, 0.f, 0.f, 0.f};
+                int wr[4] = {0, 0, 0, 0};
 #pragma unroll 1
                 for (int g0 = 0; g0 < npts; g0 += 4) {
                     const int kk = g0 + cor;
@@ -3115,7 +3150,8 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                     const int bits = rng ? ((vy0 & vx0) | ((vy0 & vx1) << 1) | ((vy1 & vx0) << 2) | ((vy1 & vx1) << 3)) : 0;
                     pt.pbase = base + yl * W + xl;
                     pt.Wb = W | (bits << 24);
-                    if (records && mine) {      // the point's top tap row, for the scatter's band test
+                    if (wide) set4(wr, g0 >> 2, bits ? min(yl, 32767) : kNoRow16);
+                    if (records && mine && !wide) {      // the point's top tap row, for the scatter's band test
                         const int pin = kk - lvl * P;
                         short *rec = reinterpret_cast<short *>(p.bbox + (((group * p.M + m) * VL + vl0 + lvl) * p.Lq + q0 + j) * 2);
                         rec[pin] = bits ? (short)min(yl, 32767) : (short)kNoRow16;
@@ -3164,14 +3200,37 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                     }
                     // every lane finishes its own point (cuh:123-158 on the reduced dots; dots of corners outside
                     // the map are 0: their loads returned zeros)
-                    if (mine) {
+                    {
                         const float lh = pt.lh, lw = pt.lw, hh = 1.f - lh, hw = 1.f - lw;
                         const float g_aw = (hh * hw) * k0 + (hh * lw) * k1 + (lh * hw) * k2 + (lh * lw) * k3;
                         const float g_w = hh * (k1 - k0) + lh * (k3 - k2);
                         const float g_h = hw * (k2 - k0) + lw * (k3 - k1);
-                        Store<T>::put(gloc + 2 * (idx0 + kk), (float)W * g_w * pt.a);
-                        Store<T>::put(gloc + 2 * (idx0 + kk) + 1, (float)H * g_h * pt.a);
-                        Store<T>::put(gaw + idx0 + kk, g_aw);
+                        const float gx = (float)W * g_w * pt.a, gy = (float)H * g_h * pt.a;
+                        if (wide) {
+                            set4(wx, g0 >> 2, gx); set4(wy, g0 >> 2, gy); set4(wa, g0 >> 2, g_aw);
+                        } else if (mine) {
+                            Store<T>::put(gloc + 2 * (idx0 + kk), gx);
+                            Store<T>::put(gloc + 2 * (idx0 + kk) + 1, gy);
+                            Store<T>::put(gaw + idx0 + kk, g_aw);
+                        }
+                    }
+                }
+                if (wide) {
+                    // lane c held point c of every level; after the transposes it holds the four points of level c
+                    quad_transpose4(wx, cor); quad_transpose4(wy, cor); quad_transpose4(wa, cor); quad_transpose4(wr, cor);
+                    if (live) {
+                        const float xy[8] = {wx[0], wy[0], wx[1], wy[1], wx[2], wy[2], wx[3], wy[3]};
+                        T *gl = gloc + 2 * (idx0 + 4 * cor);
+                        if constexpr (kHalf) {
+                            Store<T>::store(gl, xy);
+                        } else {
+                            const float lo[4] = {xy[0], xy[1], xy[2], xy[3]}, hi[4] = {xy[4], xy[5], xy[6], xy[7]};
+                            Store<T>::store(gl, lo); Store<T>::store(gl + 4, hi);
+                        }
+                        SlabStore<T>::store(gaw + idx0 + 4 * cor, wa);
+                        if (records)
+                            *reinterpret_cast<int2 *>(p.bbox + (((group * p.M + m) * VL + vl0 + cor) * p.Lq + q0 + j) * 2) =
+                                make_int2((wr[0] & 0xffff) | (wr[1] << 16), (wr[2] & 0xffff) | (wr[3] << 16));
                     }
                 }
             }
@@ -3924,6 +3983,8 @@ int run(int dtype, const Params &p_in, bool bwd, hipStream_t stream)
     // culling records per point when a level has <= 4 points (MSDA_BWD_CULL=2: force (min, max) intervals)
     p.cull_points = bwd && p.bbox && p.PA <= 4 && p.PB <= 4 && knobs().bwd_cull != 2;
     if (!p.cull_points) p.bsum = nullptr;
+    p.wide_stores = bwd && aligned16(p.glocA) && aligned16(p.gawA) && (p.LB == 0 || (aligned16(p.glocB) && aligned16(p.gawB))) &&
+                    (knobs().dbg & 64) == 0;                  // (measurement: MSDA_DBG=64 keeps the narrow stores)
     if (p.groups == 0 || p.Lq == 0) return MSDA_OK;
     bool taken = false;
     int rc = MSDA_OK;
