@@ -267,6 +267,7 @@ struct Params {
     const int64_t *shapes_host; // HOST copy of `shapes` or null: kernel selection only (never dereferenced on the device)
     int cull_points;            // bbox entries are 4 x int16 top tap rows, one per POINT (PA, PB <= 4), not (min, max)
     int wide_stores;            // bwd: the four gradient arrays are 16-byte aligned (resident-slab gather pass: whole-row stores)
+    int wide_loads;             // loc / attn arrays are 16-byte aligned (resident-slab kernels: whole-row loads)
     int dbg;                    // measurement hooks (MSDA_DBG env), 0 in production
 };
 
@@ -2811,6 +2812,63 @@ __device__ __forceinline__ RsShared rs_setup(const Params &p, unsigned char *lds
     return sh;
 }
 
+// 4 x 4 transpose inside a quad: lane c, element e  <-  lane e, element c  (two butterfly stages of one DPP move and
+// three selects per pair of elements)
+template <typename V>
+__device__ __forceinline__ void quad_transpose4(V (&a)[4], int c)
+{
+    static_assert(sizeof(V) == 4, "32-bit elements");
+    auto xchg = [&](int lo, int hi, bool up, int ctrl) {
+        const V send = up ? a[lo] : a[hi];
+        int bits;
+        __builtin_memcpy(&bits, &send, 4);
+        const int got = ctrl == 1 ? __builtin_amdgcn_mov_dpp(bits, 0xB1, 0xf, 0xf, true)      // quad_perm [1,0,3,2]
+                                  : __builtin_amdgcn_mov_dpp(bits, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+        V r;
+        __builtin_memcpy(&r, &got, 4);
+        a[lo] = up ? r : a[lo];
+        a[hi] = up ? a[hi] : r;
+    };
+    xchg(0, 1, (c & 1) != 0, 1); xchg(2, 3, (c & 1) != 0, 1);
+    xchg(0, 2, (c & 2) != 0, 2); xchg(1, 3, (c & 2) != 0, 2);
+}
+// a[i] = v for the (wave-uniform) index i: four selects instead of a dynamically indexed register array
+template <typename V> __device__ __forceinline__ void set4(V (&a)[4], int i, V v)
+{
+    a[0] = i == 0 ? v : a[0]; a[1] = i == 1 ? v : a[1]; a[2] = i == 2 ? v : a[2]; a[3] = i == 3 ? v : a[3];
+}
+
+// a[i] for the (wave-uniform) index i
+template <typename V> __device__ __forceinline__ V get4(const V (&a)[4], int i)
+{
+    return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : a[3];
+}
+// The 16 sampling points (4 levels x 4 points) of one (row, slot), loaded as whole rows: lane c of the row's quad reads
+// points 4c..4c+3 (32 + 16 contiguous bytes for 4-byte types) and the quad transposes, so that element g of lane c is
+// point c of level g -- three 16-byte loads per slot instead of eight 8- / 4-byte loads, one memory latency instead of four.
+template <typename T>
+__device__ __forceinline__ void load_slot_points(const T *loc, const T *aw, int64_t idx0, int cor, bool live,
+                                                 float (&xs)[4], float (&ys)[4], float (&as)[4])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xs[i] = ys[i] = -10.f; as[i] = 0.f; }       // far outside every map
+    if (live) {
+        float xy[8];
+        if constexpr (sizeof(T) == 2) {
+            Store<T>::load(loc + 2 * (idx0 + 4 * cor), xy);
+        } else {
+            float lo[4], hi[4];
+            Store<T>::load(loc + 2 * (idx0 + 4 * cor), lo); Store<T>::load(loc + 2 * (idx0 + 4 * cor) + 4, hi);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xy[i] = lo[i]; xy[4 + i] = hi[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xs[i] = xy[2 * i]; ys[i] = xy[2 * i + 1]; }
+        SlabStore<T>::load(aw + idx0 + 4 * cor, as);
+    }
+    quad_transpose4(xs, cor); quad_transpose4(ys, cor); quad_transpose4(as, cor);
+}
+
 template <typename T, int NT>
 __global__ void __launch_bounds__(kRsThreads)
 msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
@@ -2899,11 +2957,16 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                 const int64_t idx0 = row * LP + (sl < 0 ? 0 : sl * L * P);
                 const unsigned invP = (65536u + (unsigned)P - 1u) / (unsigned)P;      // kk / P for kk * P < 2^16
                 const int first_slab_pt = l0 * P;              // points of levels >= l0 read the slab
+                const bool wide = p.wide_loads && P == 4 && npts == 16;           // (uniform) see load_slot_points
+                float xs[4], ys[4], as[4];
+                if (wide) load_slot_points<T>(loc, aw, idx0, cor, live, xs, ys, as);
 #pragma unroll 1
                 for (int g0 = 0; g0 < npts; g0 += 4) {
                     const int kk = g0 + cor;
                     float x = -10.f, y = -10.f, a = 0.f;       // far outside every map
-                    if (live && kk < npts) {
+                    if (wide) {
+                        x = get4(xs, g0 >> 2); y = get4(ys, g0 >> 2); a = get4(as, g0 >> 2);
+                    } else if (live && kk < npts) {
                         load_xy(loc + 2 * (idx0 + kk), x, y);
                         a = Store<T>::get(aw + idx0 + kk);
                     }
@@ -3011,32 +3074,6 @@ __device__ __forceinline__ void quad_sum4(float (&d)[4])
                  : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
 }
 
-// 4 x 4 transpose inside a quad: lane c, element e  <-  lane e, element c  (two butterfly stages of one DPP move and
-// three selects per pair of elements)
-template <typename V>
-__device__ __forceinline__ void quad_transpose4(V (&a)[4], int c)
-{
-    static_assert(sizeof(V) == 4, "32-bit elements");
-    auto xchg = [&](int lo, int hi, bool up, int ctrl) {
-        const V send = up ? a[lo] : a[hi];
-        int bits;
-        __builtin_memcpy(&bits, &send, 4);
-        const int got = ctrl == 1 ? __builtin_amdgcn_mov_dpp(bits, 0xB1, 0xf, 0xf, true)      // quad_perm [1,0,3,2]
-                                  : __builtin_amdgcn_mov_dpp(bits, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
-        V r;
-        __builtin_memcpy(&r, &got, 4);
-        a[lo] = up ? r : a[lo];
-        a[hi] = up ? a[hi] : r;
-    };
-    xchg(0, 1, (c & 1) != 0, 1); xchg(2, 3, (c & 1) != 0, 1);
-    xchg(0, 2, (c & 2) != 0, 2); xchg(1, 3, (c & 2) != 0, 2);
-}
-// a[i] = v for the (wave-uniform) index i: four selects instead of a dynamically indexed register array
-template <typename V> __device__ __forceinline__ void set4(V (&a)[4], int i, V v)
-{
-    a[0] = i == 0 ? v : a[0]; a[1] = i == 1 ? v : a[1]; a[2] = i == 2 ? v : a[2]; a[3] = i == 3 ? v : a[3];
-}
-
 template <typename T>
 __global__ void __launch_bounds__(kRsThreads)
 msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
@@ -3124,12 +3161,17 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                 const bool wide = p.wide_stores && P == 4 && npts == 16;
                 float wx[4] = {0.f, 0.f, 0.f, 0.f}, wy[4] = {0.f, 0.f, 0.f, 0.f}, wa[4] = {0.f, 0.f, 0.f, 0.f};
                 int wr[4] = {0, 0, 0, 0};
+                const bool wide_ld = p.wide_loads && P == 4 && npts == 16;
+                float xs[4], ys[4], as[4];
+                if (wide_ld) load_slot_points<T>(loc, aw, idx0, cor, live, xs, ys, as);
 #pragma unroll 1
                 for (int g0 = 0; g0 < npts; g0 += 4) {
                     const int kk = g0 + cor;
                     const bool mine = live && kk < npts;
                     float x = -10.f, y = -10.f, a = 0.f;       // far outside every map
-                    if (mine) {
+                    if (wide_ld) {
+                        x = get4(xs, g0 >> 2); y = get4(ys, g0 >> 2); a = get4(as, g0 >> 2);
+                    } else if (mine) {
                         load_xy(loc + 2 * (idx0 + kk), x, y);
                         a = Store<T>::get(aw + idx0 + kk);
                     }
@@ -3985,6 +4027,8 @@ int run(int dtype, const Params &p_in, bool bwd, hipStream_t stream)
     if (!p.cull_points) p.bsum = nullptr;
     p.wide_stores = bwd && aligned16(p.glocA) && aligned16(p.gawA) && (p.LB == 0 || (aligned16(p.glocB) && aligned16(p.gawB))) &&
                     (knobs().dbg & 64) == 0;                  // (measurement: MSDA_DBG=64 keeps the narrow stores)
+    p.wide_loads = aligned16(p.locA) && aligned16(p.awA) && (p.LB == 0 || (aligned16(p.locB) && aligned16(p.awB))) &&
+                   (knobs().dbg & 128) == 0;                  // (measurement: MSDA_DBG=128 keeps the narrow loads)
     if (p.groups == 0 || p.Lq == 0) return MSDA_OK;
     bool taken = false;
     int rc = MSDA_OK;
