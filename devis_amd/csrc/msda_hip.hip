@@ -3780,15 +3780,14 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
         const bool fits = (int64_t)p.frames * p.S < (1 << 24) && pixB < (1 << 24) && p.D == 32 &&
                           (int64_t)p.frames * p.S * pixB < 0x7fffffffLL && p.frames <= kRsMaxFrames && p.window <= 31;
         // tiles per wave (NT) and workgroups per (clip, head) (parts): see rs_tiles_per_wave
-        // the slab must be worth staging: every level but the first has to fit (75 % of the taps of a DeVIS call)
         const int slab_bytes = ((160 * 1024 - 256 - kRsTailBytes) / 128) * 128;
         const int l0_host = host_first_slab_level(p, (slab_bytes - kRsSlack) / rs_row_bytes<T>());
         int nt = rs_tiles_per_wave(p, tiles_per_clip, host_pixels_below(p, l0_host) * rs_row_bytes<T>(), mode == 1);
         int parts = nt ? (tiles_per_clip + kRsWaves * nt - 1) / (kRsWaves * nt) : 0;
-        // (2-byte types: one 16-byte load per corner on the memory path too, so the kernel wins as soon as ANY level
-        // fits the slab -- 800x1333 in bf16: levels 2-3, forward 0.44 -> 0.40 ms, gather pass 0.79 -> 0.62 ms; 4-byte
-        // types pay two loads per corner there and lose unless level 0 is the only one outside: 0.67 vs 0.52 ms)
-        const int l0_max = sizeof(T) == 2 ? p.L - 1 : 1;
+        // the slab must hold at least the last level.  (Since the whole-row loads / stores of the points and gradients the
+        // kernel wins for every dtype as soon as ANY level fits -- 800x1333, levels 2-3 resident: bf16 forward 0.44 -> 0.39
+        // ms, gather pass 0.79 -> 0.54; fp32 0.61 -> 0.55 and 0.80 -> 0.63 against the round-1 slab kernels.)
+        const int l0_max = p.L - 1;
         if (mode != 1 && l0_host > l0_max) nt = 0;
         const int force_nt = knobs().fwd_rs_nt;
         if (force_nt == 1 || force_nt == 2 || force_nt == 4) { nt = force_nt; parts = (tiles_per_clip + kRsWaves * nt - 1) / (kRsWaves * nt); }
@@ -3863,7 +3862,7 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
             const int l0_host = host_first_slab_level(p, (slab_bytes - kRsSlack) / rs_row_bytes<T>());
             const int tpw = rs_tiles_per_wave(p, tiles_per_clip, host_pixels_below(p, l0_host) * rs_row_bytes<T>(), mode == 1);
             const int parts = tpw ? (tiles_per_clip + tpw * kRsWaves - 1) / (tpw * kRsWaves) : 1;       // (L2: see the forward)
-            bool want = mode == 1 || (mode == -1 && tpw && l0_host <= (sizeof(T) == 2 ? p.L - 1 : 1));
+            bool want = mode == 1 || (mode == -1 && tpw && l0_host <= p.L - 1);
             if (want && fits && clips * p.M * parts <= 0x7fffffffLL) {
                 const size_t total = (size_t)slab_bytes + kRsTailBytes;
                 static LdsGrant granted;
