@@ -234,6 +234,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t clip_resource(const T *vbase, 
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(vbase), 0, (int)bytes, 0x00020000);
 }
 
+// LDS byte address of a pointer into shared memory
+__device__ __forceinline__ unsigned lds_addr(const void *q)
+{
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)q;
+}
+
 // hardware float atomics (global_atomic_add_f32 / _f64, no return value, no CAS loop)
 __device__ __forceinline__ void atomic_accumulate(float *p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_accumulate(double *p, double v) { unsafeAtomicAdd(p, v); }
@@ -2187,9 +2193,9 @@ constexpr int kOwnPix = kOwnQuads * kOwnSlots;      // pixels per band
 template <typename T> constexpr int own_chunk() { return sizeof(T) == 4 ? 768 : kOwnThreads; }
 template <typename T> constexpr int own_list() { return own_chunk<T>() + 4 * kOwnThreads; }   // a chunk's worth + one cull batch, worst case
 constexpr unsigned kOwnNil = 0xffffffffu;
-template <typename T> constexpr int own_lds_bytes()
+template <typename T> constexpr int own_lds_bytes()      // (+ 32: the entries start on a 32-byte boundary)
 {
-    return own_chunk<T>() * 32 * (int)sizeof(T) + 4 * own_chunk<T>() * 8 + kOwnPix * 4 + own_list<T>() * 4;
+    return own_chunk<T>() * 32 * (int)sizeof(T) + 32 + 4 * own_chunk<T>() * 8 + kOwnPix * 4 + own_list<T>() * 4;
 }
 
 // (x, y) of one sampling point: one 8- / 4-byte load
@@ -2218,7 +2224,9 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
     constexpr bool kHalf = sizeof(T) == 2;
     extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];
     unsigned char *rows = lds_raw;                                              // [kOwnChunk][kRowB]
-    uint2 *ents = reinterpret_cast<uint2 *>(lds_raw + kOwnChunk * kRowB);       // [4 * kOwnChunk] {weight bits, next}
+    // [4 * kOwnChunk] {weight bits, next reference}, on a 32-byte boundary; a reference = the absolute LDS address of an entry
+    uint2 *ents = reinterpret_cast<uint2 *>(lds_raw + kOwnChunk * kRowB +
+                                            ((32u - (lds_addr(lds_raw) & 31u)) & 31u));
     unsigned *head = reinterpret_cast<unsigned *>(ents + 4 * kOwnChunk);        // [kOwnPix]
     unsigned *list = head + kOwnPix;                                            // [own_list<T>()] (k:6 | pt:2 | q:24)
     __shared__ int s_H[kScatterMaxLevels], s_W[kScatterMaxLevels], s_R[kScatterMaxLevels],
@@ -2259,6 +2267,7 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
     const int Q = tid / 4, cq = tid & 3, hsw = Q & 1;
     const int off1 = kHalf ? cq * 16 : cq * 16 + hsw * 64;
     const int ch1 = kHalf ? cq * 8 : off1 / 4, ch2 = kHalf ? cq * 8 + 4 : (off1 ^ 64) / 4;     // channels of acc[0..3] / acc[4..7]
+    const unsigned ents_lds = lds_addr(ents);
 
     for (int64_t it = blockIdx.x;; it += gridDim.x) {
         int64_t item = it;
@@ -2407,7 +2416,7 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
                         for (int c = 0; c < 4; ++c)
                             if (own[c]) {
                                 const unsigned ei = 4u * (unsigned)tid + (unsigned)c;
-                                const unsigned prev = atomicExch(&head[((pix00 + dpix[c]) << sfs) + (tid & (SF - 1))], ei);
+                                const unsigned prev = atomicExch(&head[((pix00 + dpix[c]) << sfs) + (tid & (SF - 1))], ents_lds + 8u * ei);
                                 ents[ei] = make_uint2(__float_as_uint(wgt[c]), prev);
                             }
                     }
@@ -2423,10 +2432,12 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
                     const int pix = s * kOwnQuads + Q;
                     unsigned e = kOwnNil;
                     if (pix < nvpix) { e = head[pix]; if (e != kOwnNil) head[pix] = kOwnNil; }
+                    // (list references are absolute LDS addresses of the entries: the entry read needs no address
+                    // arithmetic, the row is (A - entries) >> 5 since entries are 8 bytes, 4 per hit)
                     while (e != kOwnNil) {
-                        const uint2 en = ents[e];
+                        const uint2 en = *reinterpret_cast<const uint2 *>(lds_raw + (e - lds_addr(lds_raw)));
                         const float w = __uint_as_float(en.x);
-                        const unsigned char *r = rows + (e >> 2) * kRowB;
+                        const unsigned char *r = rows + ((e - ents_lds) >> 5) * kRowB;
                         float v[8];
                         if constexpr (kHalf) {
                             Store<T>::load(reinterpret_cast<const T *>(r + off1), v);
