@@ -3736,9 +3736,12 @@ long long host_pixels_below(const Params &p, int l0)
 // Tiles per wave of the resident-slab kernels = how many workgroups share one (clip, head).  Every workgroup of a
 // pair gathers the non-resident levels from the same maps, and what an XCD's 4 MiB L2 keeps of them decides the
 // kernels' speed: take the LARGEST workgroups (least slab staging) whose pairs in flight per
-// XCD still fit the L2, else the smallest.  Measured, forward, 16 clips of the DeVIS decoder shape: fp32 (460 KiB per
-// map) 4 / 2 / 1 tiles per wave = 0.52 / 0.46 / 0.48 ms; bf16 (230 KiB) 0.35 / 0.38 / 0.39 ms.
-int rs_tiles_per_wave(const Params &p, int tiles_per_clip, long long outside_bytes, bool force)
+// XCD still fit `l2_budget`, else the smallest.  Measured on the final kernels, 16 / 32 clips of the DeVIS decoder shape,
+// 4 / 2 / 1 tiles per wave: forward fp32 (460 KiB per map) 0.440 / 0.441 / 0.473 and 0.754 / 0.800 / 0.915 ms, bf16
+// (230 KiB) 0.343 / 0.372 / 0.395 ms; gather pass fp32 4 vs 2 tiles: 0.547 vs 0.524 ms.  Hence 8 MiB for the forward
+// (4 tiles per wave for fp32 too: equal at 16 clips, -6 % at 32) and 4 MiB for the gather pass, whose extra streams
+// (grad_out rows, 309 MB of results) compete for the same L2.
+int rs_tiles_per_wave(const Params &p, int tiles_per_clip, long long outside_bytes, bool force, long long l2_budget)
 {
     const int64_t clips = p.groups / p.frames;
     const int cus_per_xcd = device_cus() / 8 > 0 ? device_cus() / 8 : 1;
@@ -3748,7 +3751,8 @@ int rs_tiles_per_wave(const Params &p, int tiles_per_clip, long long outside_byt
         if (!force && clips * p.M * parts < device_cus()) continue;          // must fill the chip
         pick = cand;
         const long long pairs = (cus_per_xcd + parts - 1) / parts;
-        if (pairs * outside_bytes <= 4ll * 1024 * 1024) break;
+        // (beyond 4 MiB only with at least two workgroups per CU: measured equal-or-worse with exactly one)
+        if (pairs * outside_bytes <= (4ll << 20) || (pairs * outside_bytes <= l2_budget && clips * p.M * parts >= 2 * device_cus())) break;
     }
     return pick;
 }
@@ -3793,7 +3797,7 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
         // tiles per wave (NT) and workgroups per (clip, head) (parts): see rs_tiles_per_wave
         const int slab_bytes = ((160 * 1024 - 256 - kRsTailBytes) / 128) * 128;
         const int l0_host = host_first_slab_level(p, (slab_bytes - kRsSlack) / rs_row_bytes<T>());
-        int nt = rs_tiles_per_wave(p, tiles_per_clip, host_pixels_below(p, l0_host) * rs_row_bytes<T>(), mode == 1);
+        int nt = rs_tiles_per_wave(p, tiles_per_clip, host_pixels_below(p, l0_host) * rs_row_bytes<T>(), mode == 1, 8ll << 20);
         int parts = nt ? (tiles_per_clip + kRsWaves * nt - 1) / (kRsWaves * nt) : 0;
         // the slab must hold at least the last level.  (Since the whole-row loads / stores of the points and gradients the
         // kernel wins for every dtype as soon as ANY level fits -- 800x1333, levels 2-3 resident: bf16 forward 0.44 -> 0.39
@@ -3871,7 +3875,7 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
                               (int64_t)(p.PA > p.PB ? p.PA : p.PB) * (p.PA > p.PB ? p.PA : p.PB) * p.L < 65536;   // kk / P by reciprocal
             const int slab_bytes = ((160 * 1024 - 256 - kRsTailBytes) / 128) * 128;
             const int l0_host = host_first_slab_level(p, (slab_bytes - kRsSlack) / rs_row_bytes<T>());
-            const int tpw = rs_tiles_per_wave(p, tiles_per_clip, host_pixels_below(p, l0_host) * rs_row_bytes<T>(), mode == 1);
+            const int tpw = rs_tiles_per_wave(p, tiles_per_clip, host_pixels_below(p, l0_host) * rs_row_bytes<T>(), mode == 1, 4ll << 20);
             const int parts = tpw ? (tiles_per_clip + tpw * kRsWaves - 1) / (tpw * kRsWaves) : 1;       // (L2: see the forward)
             bool want = mode == 1 || (mode == -1 && tpw && l0_host <= p.L - 1);
             if (want && fits && clips * p.M * parts <= 0x7fffffffLL) {
