@@ -228,6 +228,13 @@ def other_configs(args, device):
     ms = _event_ms(step, 10)
     res["clustered_locations"] = {"workload": "headline batch, reference point + N(0, (3 px)^2) offsets", "fwd_bwd_ms": round(ms, 4),
                                   "M_queries_per_s": round(rows / ms / 1e3, 3)}
+    # (ii-b) a larger batch of clips (Bc up to 64): the same kernels, more work per launch
+    step, fwd, rows = fused_case(64, "uniform", torch.float32)
+    ms = _event_ms(step, 6)
+    res["batch_64_clips"] = {"workload": "cfg3, 64 clips per step (headline: %d), uniform locations, f32" % args.clips,
+                             "fwd_bwd_ms": round(ms, 4), "M_queries_per_s": round(rows / ms / 1e3, 3)}
+    del step, fwd
+    torch.cuda.empty_cache()
     # (iii) the headline batch in the 16-bit storage types (arithmetic stays fp32)
     for key, dt in (("headline_bf16", torch.bfloat16), ("headline_f16", torch.float16)):
         step, fwd, rows = fused_case(args.clips, "uniform", dt)
