@@ -2590,6 +2590,397 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
     }
 }
 
+// ---- group-granular variant -------------------------------------------------------------------------------------
+// A chunk is kGrpChunk (row, level) GROUPS -- the <= 4 sampling points one query puts on one level of one source frame --
+// instead of 768 single points: the points of a group share their grad_out row, so the row is staged ONCE per group
+// (the owner kernel above stages it once per point: 22 M 128-byte LDS-DMA requests per launch, 3/4 of them duplicates
+// on the levels that are a single band), a chunk holds up to 4 x 512 = 2048 hits (fewer barriers and exposed latencies
+// per hit, longer lists = better lock-step efficiency of the walk), and the survivor list holds groups (1 entry per
+// cull thread, 6 KiB instead of 19).  Thread t of pass j handles point (t & 3) of group 256 j + t / 4; a group's 16
+// entries are one 128-byte block, so the row of an entry at LDS address A is (A - entries) >> 7.
+constexpr int kGrpChunk = 512;
+template <typename T> constexpr int grp_lds_bytes()
+{
+    return kGrpChunk * 32 * (int)sizeof(T) + 32 + 16 * kGrpChunk * 8 + kOwnPix * 4 + (kGrpChunk + kOwnThreads) * 4;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kOwnThreads)
+msda_bwd_value_grp_kernel(const Params p, int dbg)
+{
+    constexpr int D = 32, kRowB = D * (int)sizeof(T);          // bytes of one staged grad_out row
+    constexpr int kOwnChunk = kGrpChunk;                        // groups per chunk
+    constexpr bool kHalf = sizeof(T) == 2;
+    extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];
+    unsigned char *rows = lds_raw;                                              // [kOwnChunk][kRowB]  one row per group
+    // [16 * kOwnChunk] {weight bits, next reference}, on a 32-byte boundary; a reference = the absolute LDS address of an entry
+    uint2 *ents = reinterpret_cast<uint2 *>(lds_raw + kOwnChunk * kRowB +
+                                            ((32u - (lds_addr(lds_raw) & 31u)) & 31u));
+    unsigned *head = reinterpret_cast<unsigned *>(ents + 16 * kOwnChunk);       // [kOwnPix]
+    unsigned *list = head + kOwnPix;                                            // [kOwnChunk + kOwnThreads] (k:6 | points:4 | q:22)
+    __shared__ int s_H[kScatterMaxLevels], s_W[kScatterMaxLevels], s_R[kScatterMaxLevels],
+        s_first[kScatterMaxLevels + 1], s_lsi[kScatterMaxLevels];
+    __shared__ int s_nsrc, s_cnt[3];     // survivor counters rotate: slot j is reset two barriers before it is used again
+    __shared__ long long s_src_tab[kScatterMaxSources], s_src_loc[kScatterMaxSources];
+    __shared__ int s_src_q0[kScatterMaxSources], s_src_gmv[kScatterMaxSources];
+    __shared__ unsigned s_live[kLiveWords];            // bitmap of the cull batches that hold a live 64-query block
+    __shared__ long long s_item;
+
+    const int tid = threadIdx.x, lane = tid % kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int MD = p.M * D, L = p.L, VL = p.LA + p.LB;
+    if (tid == 0) {
+        int first = 0;
+        for (int l = 0; l < L; ++l) {
+            const int H = (int)p.shapes[2 * l], W = (int)p.shapes[2 * l + 1];
+            const int R = min(H, kOwnPix / max(1, W));          // rows per band; 0 = "direct" level (row wider than a band)
+            s_H[l] = H; s_W[l] = W; s_R[l] = R; s_lsi[l] = (int)p.lsi[l];
+            s_first[l] = first;
+            first += (R > 0) ? (H + R - 1) / R : 1;
+        }
+        s_first[L] = first;
+        s_cnt[0] = s_cnt[1] = s_cnt[2] = 0;
+    }
+    int ci = 0;                             // counter of the current cull batch
+    for (int i = tid; i < kOwnPix; i += kOwnThreads) head[i] = kOwnNil;
+    __syncthreads();
+    const int NB = s_first[L];
+    const int clips = p.groups / p.frames;
+    const int64_t n_items = (int64_t)clips * p.frames * p.M * NB;
+    const bool dynamic = p.workspace != nullptr && (dbg & 16) == 0 && n_items < (int64_t)16 * gridDim.x;
+    const int lane8 = blockIdx.x % 8;
+    const int strideA = p.M * p.LA * p.PA, strideB = p.M * p.LB * p.PB;      // loc/attn elements per query
+    // owner side: quad Q owns pixels s * kOwnQuads + Q of the band.  4-byte types: lane c of the quad holds the
+    // channels [4c, 4c+4) of both 64-byte halves of the row (odd quads read the second half first: LDS banks, as
+    // in the forward); 2-byte types: the 8 channels [8c, 8c+8) = one 16-byte slice of the 64-byte row.
+    const int Q = tid / 4, cq = tid & 3, hsw = Q & 1;
+    const int off1 = kHalf ? cq * 16 : cq * 16 + hsw * 64;
+    const int ch1 = kHalf ? cq * 8 : off1 / 4, ch2 = kHalf ? cq * 8 + 4 : (off1 ^ 64) / 4;     // channels of acc[0..3] / acc[4..7]
+    const unsigned ents_lds = lds_addr(ents);
+
+    for (int64_t it = blockIdx.x;; it += gridDim.x) {
+        int64_t item = it;
+        if (dynamic) {
+            if (tid == 0) s_item = (long long)atomicAdd(p.workspace + lane8, 1u) * 8 + lane8;
+            __syncthreads();
+            item = s_item;
+        }
+        if (item >= n_items) break;
+        int l, part, m, f, clip;
+        if (dynamic) {      // heaviest first: levels from the last to the first (see msda_bwd_value_lds_kernel)
+            const int64_t ctm = (int64_t)clips * p.frames * p.M;
+            l = L - 1;
+            int64_t local = item;
+            while (l > 0 && local >= ctm * (s_first[l + 1] - s_first[l])) {
+                local -= ctm * (s_first[l + 1] - s_first[l]);
+                --l;
+            }
+            const int nb_l = s_first[l + 1] - s_first[l];
+            m = (int)(local % p.M);
+            int64_t rest = local / p.M;
+            part = s_first[l] + (int)(rest % nb_l); rest /= nb_l;
+            f = (int)(rest % p.frames);
+            clip = (int)(rest / p.frames);
+        } else {
+            m = (int)(item % p.M);
+            int64_t rest = item / p.M;
+            part = (int)(rest % NB); rest /= NB;
+            f = (int)(rest % p.frames);
+            clip = (int)(rest / p.frames);
+            l = 0;
+            while (l + 1 < L && s_first[l + 1] <= part) ++l;
+        }
+        const int H = s_H[l], W = s_W[l], R = s_R[l];
+        const bool direct = (R == 0);
+        const int r0 = direct ? 0 : (part - s_first[l]) * R;
+        const int r1 = direct ? H - 1 : min(H, r0 + R) - 1;
+        const int npix = direct ? 0 : (r1 - r0 + 1) * W;
+        // Small bands (the last pyramid levels: 60 pixels at 360x640) would keep only npix of the 256 owner quads busy
+        // while every pixel's list is long; their hits are dealt round-robin to SF sub-lists per pixel ("virtual
+        // pixels" pix * SF + hit % SF), each with an owner quad of its own, and the SF partial sums of a pixel are
+        // added up through LDS when the item is finished.  SF = largest power of two with npix * SF <= 256 quads.
+        int sfs = 0;
+        while (npix > 0 && (npix << (sfs + 1)) <= kOwnQuads && sfs < 4) ++sfs;
+        const int SF = 1 << sfs, nvpix = npix << sfs;
+        float *gmap = static_cast<float *>(p.grad_value) +
+                      (((int64_t)clip * p.frames + f) * p.S + s_lsi[l]) * MD + m * D;     // pixel (0, 0) of the level, head m
+
+        // sources that read frame f: the current-frame points of frame f, then every temporal slot (t, w) with
+        // frame_table[t, w] == f; per source the first culling-table entry, first loc/attn element, first query row
+        if (wave == 0) {
+            const int n_tw = p.frames * p.window;
+            const bool hit = lane < n_tw && p.ftab[lane] == f;
+            const u64 bal = __ballot(hit);
+            if (lane == 0) {
+                const int64_t g = (int64_t)clip * p.frames + f;
+                s_src_tab[0] = ((g * p.M + m) * VL + l) * p.Lq;
+                s_src_loc[0] = (g * p.Lq * p.M + m) * ((int64_t)p.LA * p.PA) + l * p.PA;
+                s_src_q0[0] = (int)(g * p.Lq);
+                s_src_gmv[0] = (int)((g * p.M + m) * VL + l);
+                s_nsrc = 1 + (int)__popcll(bal);
+            }
+            if (hit) {
+                const int n = 1 + (int)__popcll(bal & ((1ull << lane) - 1ull)), t = lane / p.window;
+                const int vl = (lane - t * p.window) * L + l;
+                const int64_t g = (int64_t)clip * p.frames + t;
+                s_src_tab[n] = ((g * p.M + m) * VL + p.LA + vl) * p.Lq;
+                s_src_loc[n] = (g * p.Lq * p.M + m) * ((int64_t)p.LB * p.PB) + vl * p.PB;
+                s_src_q0[n] = (int)(g * p.Lq);
+                s_src_gmv[n] = (int)((g * p.M + m) * VL + p.LA + vl);
+            }
+        }
+        __syncthreads();
+        const int ng = s_nsrc * p.Lq;              // candidate groups: (source, query) pairs, <= 4 points each
+
+        float acc[kOwnSlots][8];
+#pragma unroll
+        for (int s = 0; s < kOwnSlots; ++s)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[s][c] = 0.f;
+
+        // The hit of this thread in pass j of a chunk: point (tid & 3) of group 256 j + tid / 4 if it survived the cull;
+        // its (x, y, attention weight) loads are issued here (the 4 threads of a group read 32 + 16 contiguous bytes).
+        auto fetch_hit = [&](int base, int n, int pass, float &x, float &y, float &a, int &qrow, bool &act) {
+            x = y = -10.f; a = 0.f; qrow = 0; act = false;
+            const int g = pass * (kOwnThreads / 4) + tid / 4, pt = tid & 3;
+            if (g < n) {
+                const unsigned e = list[base + g];
+                const int k = (int)(e >> 26), q = (int)(e & 0x3fffffu);
+                if ((e >> (22 + pt)) & 1u) {
+                    const bool curf = (k == 0);
+                    const int64_t idx = s_src_loc[k] + (int64_t)q * (curf ? strideA : strideB) + pt;
+                    const T *loc = static_cast<const T *>(curf ? p.locA : p.locB);
+                    const T *aw = static_cast<const T *>(curf ? p.awA : p.awB);
+                    load_xy(loc + 2 * idx, x, y);
+                    a = Store<T>::get(aw + idx);
+                    qrow = s_src_q0[k] + q;
+                    act = true;
+                }
+            }
+        };
+        // ---- grad_out rows -> LDS, one per GROUP: wave w stages rows [32 w, 32 w + 32) of the chunk
+        auto stage_rows = [&](int base, int n) {
+            if (direct || (dbg & 4)) return;
+            constexpr int LPR = kRowB / 16, HPI = kWave / LPR;      // lanes per row, rows per instruction
+            const T *go = static_cast<const T *>(p.grad_out) + m * D + (lane % LPR) * (16 / (int)sizeof(T));
+#pragma unroll
+            for (int i = 0; i < 32 / HPI; ++i) {
+                const int r0w = wave * 32 + HPI * i;
+                if (r0w < n) {                                      // uniform: this instruction has at least one live row
+                    const unsigned e = list[base + min(r0w + lane / LPR, n - 1)];
+                    const int qr = s_src_q0[e >> 26] + (int)(e & 0x3fffffu);
+                    const T *gp = go + (int64_t)qr * MD;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    __builtin_amdgcn_global_load_lds(gp, (__attribute__((address_space(3))) void *)(rows + r0w * kRowB), 16, 0, 0);
+#else
+                    (void)gp;
+#endif
+                }
+            }
+        };
+        // ---- taps (cuh:285-288, 38-80) and the entries of the corners this band owns
+        auto taps_link = [&](int pass, bool act, float x, float y, float a, int qrow) {
+            const float h_im = __fsub_rn(__fmul_rn(y, (float)H), 0.5f);
+            const float w_im = __fsub_rn(__fmul_rn(x, (float)W), 0.5f);
+            if (act && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                const float hf = floorf(h_im), wf = floorf(w_im);
+                const int h_low = (int)hf, w_low = (int)wf;
+                const bool top = h_low >= max(r0, 0) && h_low <= r1;          // rows this band owns
+                const bool bot = h_low + 1 >= r0 && h_low + 1 <= min(r1, H - 1);
+                const bool x0 = w_low >= 0, x1 = w_low + 1 <= W - 1;
+                const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+                const float wgt[4] = {hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a};
+                const bool own[4] = {top && x0, top && x1, bot && x0, bot && x1};
+                const int pix00 = (h_low - r0) * W + w_low;
+                const int dpix[4] = {0, 1, W, W + 1};
+                if (direct) {
+                    // a level whose single row does not fit a band: float atomics straight to memory
+                    const T *gr = static_cast<const T *>(p.grad_out) + (int64_t)qrow * MD + m * D;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (own[c]) {
+                            float *dst = gmap + (int64_t)(pix00 + dpix[c]) * MD;
+                            for (int ch = 0; ch < D; ++ch) atomic_accumulate(dst + ch, wgt[c] * Store<T>::get(gr + ch));
+                        }
+                } else if (!(dbg & 2)) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (own[c]) {
+                            const unsigned ei = 4u * (unsigned)(pass * kOwnThreads + tid) + (unsigned)c;
+                            const unsigned prev = atomicExch(&head[((pix00 + dpix[c]) << sfs) + (tid & (SF - 1))], ents_lds + 8u * ei);
+                            ents[ei] = make_uint2(__float_as_uint(wgt[c]), prev);
+                        }
+                }
+            }
+        };
+        // ---- owners walk their pixels' lists (references are absolute LDS addresses; the row is (A - entries) >> 7)
+        auto walk = [&]() {
+            if (direct || (dbg & 1)) return;
+#pragma unroll
+            for (int s = 0; s < kOwnSlots; ++s) {
+                const int pix = s * kOwnQuads + Q;
+                unsigned e = kOwnNil;
+                if (pix < nvpix) { e = head[pix]; if (e != kOwnNil) head[pix] = kOwnNil; }
+                while (e != kOwnNil) {
+                    const uint2 en = *reinterpret_cast<const uint2 *>(lds_raw + (e - lds_addr(lds_raw)));
+                    const float w = __uint_as_float(en.x);
+                    const unsigned char *r = rows + ((e - ents_lds) >> 7) * kRowB;
+                    float v[8];
+                    if constexpr (kHalf) {
+                        Store<T>::load(reinterpret_cast<const T *>(r + off1), v);
+                    } else {
+                        const float4 v1 = *reinterpret_cast<const float4 *>(r + off1);
+                        const float4 v2 = *reinterpret_cast<const float4 *>(r + (off1 ^ 64));
+                        v[0] = v1.x; v[1] = v1.y; v[2] = v1.z; v[3] = v1.w; v[4] = v2.x; v[5] = v2.y; v[6] = v2.z; v[7] = v2.w;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[s][c] = fmaf(w, v[c], acc[s][c]);
+                    e = en.y;
+                }
+            }
+        };
+        // One chunk of n groups: rows on their way, both passes' point loads issued, entries linked, lists walked.
+        auto process_chunk = [&](int base, int n) {
+            stage_rows(base, n);
+            float x0, y0, a0, x1, y1, a1;
+            int q0, q1;
+            bool act0, act1 = false;
+            fetch_hit(base, n, 0, x0, y0, a0, q0, act0);
+            const bool two = n > kOwnThreads / 4;
+            if (two) fetch_hit(base, n, 1, x1, y1, a1, q1, act1);
+            taps_link(0, act0, x0, y0, a0, q0);
+            if (two) taps_link(1, act1, x1, y1, a1, q1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's rows have landed
+            __syncthreads();
+            walk();
+            __syncthreads();
+        };
+
+        // ---- cull the candidate groups in batches of one per thread against the band; chunks are cut from the END
+        // of the survivor list, so nothing has to move
+        int listed = 0;
+        const int lo = min(r0 - 1, 32767), hi = min(r1, 32767);
+        auto load_records = [&](int gi0, int2 &iv, unsigned &ent, bool &live) {
+            const int gi = gi0 + tid;
+            live = gi < ng;
+            iv = make_int2((int)0x80008000u, (int)0x80008000u);
+            ent = 0u;
+            if (live) {
+                const int k = gi / p.Lq, q = gi - k * p.Lq;
+                ent = ((unsigned)k << 26) | (unsigned)q;              // (q < 2^22: host)
+                if (p.bbox) iv = *reinterpret_cast<const int2 *>(p.bbox + (s_src_tab[k] + q) * 2);
+            }
+        };
+        // Long candidate ranges (encoder shapes, Lq = S): a pre-pass over the 64-query block summaries marks the cull
+        // batches that hold a block whose tap rows can reach the band; with local sampling all but a few are skipped.
+        const int nbat = (ng + kOwnThreads - 1) / kOwnThreads;
+        const bool skipping = p.bsum != nullptr && nbat > 4 && nbat <= 32 * kLiveWords;
+        if (skipping) {
+            if (tid < kLiveWords) s_live[tid] = 0u;
+            __syncthreads();
+            const int nblk = (p.Lq + kCullBlock - 1) / kCullBlock, nb_tot = s_nsrc * nblk;
+            for (int bk = tid; bk < nb_tot; bk += kOwnThreads) {
+                const int ks = bk / nblk, blk = bk - ks * nblk;
+                const int2 mm = *reinterpret_cast<const int2 *>(p.bsum + ((int64_t)s_src_gmv[ks] * nblk + blk) * 2);
+                if (mm.y >= lo && mm.x <= hi) {
+                    const int g0 = ks * p.Lq + blk * kCullBlock, g1 = min(g0 + kCullBlock, ks * p.Lq + p.Lq) - 1;
+                    atomicOr(&s_live[(g0 / kOwnThreads) >> 5], 1u << ((g0 / kOwnThreads) & 31));
+                    atomicOr(&s_live[(g1 / kOwnThreads) >> 5], 1u << ((g1 / kOwnThreads) & 31));
+                }
+            }
+            __syncthreads();
+        }
+        auto next_live = [&](int bq) {       // first batch >= bq worth culling (nbat if none); workgroup-uniform
+            if (!skipping) return min(bq, nbat);
+            while (bq < nbat) {
+                const unsigned wv = s_live[bq >> 5] >> (bq & 31);
+                if (wv) return min(bq + (int)__builtin_ctz(wv), nbat);
+                bq = (bq | 31) + 1;
+            }
+            return nbat;
+        };
+        int2 iv;
+        unsigned ent;
+        bool live;
+        int bcur = next_live(0);
+        if (bcur < nbat) load_records(bcur * kOwnThreads, iv, ent, live);
+        while (bcur < nbat) {
+            const int bnext = next_live(bcur + 1);
+            unsigned pm = 0u;
+            if (live) {
+                if (p.bbox) {
+                    const int hr[4] = {(int)(short)(iv.x & 0xffff), iv.x >> 16, (int)(short)(iv.y & 0xffff), iv.y >> 16};
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp) pm |= (hr[jp] >= lo && hr[jp] <= hi) ? (1u << jp) : 0u;
+                } else {
+                    pm = (1u << ((ent >> 26) == 0u ? p.PA : p.PB)) - 1u;       // no culling table: every point is a candidate
+                }
+            }
+            const unsigned ent_now = ent;
+            const bool last = bnext >= nbat;
+            if (!last) load_records(bnext * kOwnThreads, iv, ent, live);      // the next live batch's records fly meanwhile
+            // wave-wide exclusive scan of the per-lane survivor flags (DPP), one LDS atomic per wave
+            const int cnt = pm != 0u;
+            int v = cnt;
+            v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+            const int total = __builtin_amdgcn_readlane(v, kWave - 1);
+            int wbase = 0;
+            if (tid == 0) s_cnt[(ci + 1) % 3] = 0;      // last read before the previous barrier, next used after the next one
+            if (lane == 0 && total) wbase = atomicAdd(&s_cnt[ci], total);
+            wbase = __shfl(wbase, 0, kWave);
+            if (cnt) list[listed + wbase + v - cnt] = ent_now | (pm << 22);
+            __syncthreads();
+            listed += s_cnt[ci];
+            ci = (ci + 1) % 3;
+            if (dbg & 8) listed = 0;                    // measurement: cull only
+            while (listed >= kOwnChunk || (last && listed > 0)) {
+                const int n = min(kOwnChunk, listed);
+                listed -= n;
+                process_chunk(listed, n);
+            }
+            bcur = bnext;
+        }
+        // ---- owners store their pixels: grad_value is overwritten, every pixel of the band exactly once
+        if (!direct && SF == 1) {
+            float *gband = gmap + (int64_t)r0 * W * MD;
+#pragma unroll
+            for (int s = 0; s < kOwnSlots; ++s) {
+                const int pix = s * kOwnQuads + Q;
+                if (pix < npix) {
+                    float *o = gband + (int64_t)pix * MD;
+                    *reinterpret_cast<float4 *>(o + ch1) = make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
+                    *reinterpret_cast<float4 *>(o + ch2) = make_float4(acc[s][4], acc[s][5], acc[s][6], acc[s][7]);
+                }
+            }
+        } else if (!direct) {
+            // split lists: the partial sums of virtual pixel v = pix * SF + sub (slot 0 of quad v) go through the (now
+            // free) row area as [v][32 channels] floats; one thread per (pixel, 4 channels) adds the SF partials
+            float *part = reinterpret_cast<float *>(rows);
+            if (Q < nvpix) {
+                *reinterpret_cast<float4 *>(part + Q * D + ch1) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+                *reinterpret_cast<float4 *>(part + Q * D + ch2) = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
+            }
+            __syncthreads();
+            float *gband = gmap + (int64_t)r0 * W * MD;
+            for (int i = tid; i < npix * (D / 4); i += kOwnThreads) {
+                const int pix = i / (D / 4), c4 = (i - pix * (D / 4)) * 4;
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int u = 0; u < SF; ++u) {
+                    const float4 t4 = *reinterpret_cast<const float4 *>(part + ((pix << sfs) + u) * D + c4);
+                    sum.x += t4.x; sum.y += t4.y; sum.z += t4.z; sum.w += t4.w;
+                }
+                *reinterpret_cast<float4 *>(gband + (int64_t)pix * MD + c4) = sum;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // The LDS scatter kernels OVERWRITE every pixel of a level whose row fits the band budget.  Pixels they
 // do not own -- levels that take the float-atomic branch, or rows of `value` outside every level when
 // spatial_shapes does not tile [0, S) -- are zero-filled here, so that callers need not memset grad_value.
@@ -3946,6 +4337,14 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
             hipLaunchKernelGGL(msda_zero_unowned_kernel, dim3(zb), dim3(256), 0, stream, p, kOwnPix * p.D);
             rc = check_launch("msda backward (zero-fill of pixels outside the bands)");
             if (rc) return rc;
+            if ((knobs().scatter_dbg & 2048) && p.Lq < (1 << 22)) {       // group-granular variant
+                static LdsGrant granted_grp;
+                if (const int grc = grant_lds(reinterpret_cast<const void *>(&msda_bwd_value_grp_kernel<T>), (size_t)grp_lds_bytes<T>(), granted_grp,
+                                              "the group-granular owner-computes scatter kernel")) return grc;
+                hipLaunchKernelGGL((msda_bwd_value_grp_kernel<T>), dim3(grid), dim3(kOwnThreads), (size_t)grp_lds_bytes<T>(), stream, p,
+                                   knobs().scatter_dbg & 255);
+                return check_launch("msda backward (owner-computes scatter kernel, group-granular)");
+            }
             return variant == 0 ? own_launch(&msda_bwd_value_own_kernel<T, 0>) : own_launch(&msda_bwd_value_own_kernel<T, 2>);
         }
     }
