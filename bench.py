@@ -117,7 +117,8 @@ ROUTE_KERNELS = [   # msda_last_route() phrase -> kernel symbol
     ("forward (slab kernel)", "msda_fwd_slab_kernel"),
     ("forward (tile kernel)", "msda_fwd_tile_kernel"), ("forward (generic kernel)", "msda_fwd_generic_kernel"),
     ("slab kernel, grad_loc/grad_attn", "msda_bwd_slab_kernel"), ("tile kernel, grad_loc/grad_attn", "msda_bwd_tile_kernel"),
-    ("owner-computes scatter", "msda_bwd_value_own_kernel"), ("per-point culling", "msda_bwd_value_points_kernel"),
+    ("group-granular", "msda_bwd_value_grp_kernel"), ("owner-computes scatter", "msda_bwd_value_own_kernel"),
+    ("per-point culling", "msda_bwd_value_points_kernel"),
     ("LDS scatter kernel)", "msda_bwd_value_lds_kernel"), ("global atomics", "msda_bwd_tile_kernel<atomics>"),
     ("backward (generic kernel)", "msda_bwd_generic_kernel"),
 ]

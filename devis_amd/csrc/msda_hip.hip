@@ -56,6 +56,13 @@
 // Every FMA the kernels want is spelled fmaf().  (devis_amd/build.py also passes -ffp-contract=off.)
 #pragma clang fp contract(off)
 
+#ifndef MSDA_GRP_F32
+#define MSDA_GRP_F32 512
+#endif
+#ifndef MSDA_GRP_16
+#define MSDA_GRP_16 512
+#endif
+
 namespace {
 
 constexpr int kWave = 64;   // gfx950 wavefront
@@ -2598,10 +2605,10 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
 // per hit, longer lists = better lock-step efficiency of the walk), and the survivor list holds groups (1 entry per
 // cull thread, 6 KiB instead of 19).  Thread t of pass j handles point (t & 3) of group 256 j + t / 4; a group's 16
 // entries are one 128-byte block, so the row of an entry at LDS address A is (A - entries) >> 7.
-constexpr int kGrpChunk = 512;
+template <typename T> constexpr int grp_chunk() { return sizeof(T) == 4 ? MSDA_GRP_F32 : MSDA_GRP_16; }       // groups per chunk
 template <typename T> constexpr int grp_lds_bytes()
 {
-    return kGrpChunk * 32 * (int)sizeof(T) + 32 + 16 * kGrpChunk * 8 + kOwnPix * 4 + (kGrpChunk + kOwnThreads) * 4;
+    return grp_chunk<T>() * 32 * (int)sizeof(T) + 32 + 16 * grp_chunk<T>() * 8 + kOwnPix * 4 + (grp_chunk<T>() + kOwnThreads) * 4;
 }
 
 template <typename T>
@@ -2609,7 +2616,8 @@ __global__ void __launch_bounds__(kOwnThreads)
 msda_bwd_value_grp_kernel(const Params p, int dbg)
 {
     constexpr int D = 32, kRowB = D * (int)sizeof(T);          // bytes of one staged grad_out row
-    constexpr int kOwnChunk = kGrpChunk;                        // groups per chunk
+    constexpr int kOwnChunk = grp_chunk<T>();                   // groups per chunk
+    constexpr int kPasses = (4 * kOwnChunk + kOwnThreads - 1) / kOwnThreads;
     constexpr bool kHalf = sizeof(T) == 2;
     extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];
     unsigned char *rows = lds_raw;                                              // [kOwnChunk][kRowB]  one row per group
@@ -2758,14 +2766,16 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                 }
             }
         };
-        // ---- grad_out rows -> LDS, one per GROUP: wave w stages rows [32 w, 32 w + 32) of the chunk
+        // ---- grad_out rows -> LDS, one per GROUP: wave w stages rows [RPWV w, RPWV (w + 1)) of the chunk
         auto stage_rows = [&](int base, int n) {
             if (direct || (dbg & 4)) return;
             constexpr int LPR = kRowB / 16, HPI = kWave / LPR;      // lanes per row, rows per instruction
             const T *go = static_cast<const T *>(p.grad_out) + m * D + (lane % LPR) * (16 / (int)sizeof(T));
+            constexpr int RPWV = kOwnChunk / (kOwnThreads / kWave);   // rows per wave
+            static_assert(kOwnChunk % (kOwnThreads / kWave) == 0 && RPWV % HPI == 0, "rows per wave");
 #pragma unroll
-            for (int i = 0; i < 32 / HPI; ++i) {
-                const int r0w = wave * 32 + HPI * i;
+            for (int i = 0; i < RPWV / HPI; ++i) {
+                const int r0w = wave * RPWV + HPI * i;
                 if (r0w < n) {                                      // uniform: this instruction has at least one live row
                     const unsigned e = list[base + min(r0w + lane / LPR, n - 1)];
                     const int qr = s_src_q0[e >> 26] + (int)(e & 0x3fffffu);
@@ -2842,14 +2852,15 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         // One chunk of n groups: rows on their way, both passes' point loads issued, entries linked, lists walked.
         auto process_chunk = [&](int base, int n) {
             stage_rows(base, n);
-            float x0, y0, a0, x1, y1, a1;
-            int q0, q1;
-            bool act0, act1 = false;
-            fetch_hit(base, n, 0, x0, y0, a0, q0, act0);
-            const bool two = n > kOwnThreads / 4;
-            if (two) fetch_hit(base, n, 1, x1, y1, a1, q1, act1);
-            taps_link(0, act0, x0, y0, a0, q0);
-            if (two) taps_link(1, act1, x1, y1, a1, q1);
+            float hx[kPasses], hy[kPasses], ha[kPasses];
+            int hq[kPasses];
+            bool hact[kPasses];
+#pragma unroll
+            for (int j = 0; j < kPasses; ++j)
+                if (j == 0 || n > j * (kOwnThreads / 4)) fetch_hit(base, n, j, hx[j], hy[j], ha[j], hq[j], hact[j]);
+#pragma unroll
+            for (int j = 0; j < kPasses; ++j)
+                if (j == 0 || n > j * (kOwnThreads / 4)) taps_link(j, hact[j], hx[j], hy[j], ha[j], hq[j]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's rows have landed
             __syncthreads();
             walk();
@@ -4014,7 +4025,7 @@ struct Knobs {
     int bwd_cull = 1;                   // 0: no culling structure, 2: (min, max) intervals instead of per-point records
     int bwd_summary = 1;                // 64-query block summaries for long candidate ranges
     int scatter_lds_kb = 144, scatter_wg_per_cu = 1, scatter_dbg = 0;
-    int scatter_own = -1;               // owner-computes scatter: -1 auto, 0 off, 1 force (where it applies)
+    int scatter_own = -1;               // owner-computes scatter: -1 auto, 0 off, 1 force (where it applies), 2 the point-granular kernel
     int force_generic = 0;
     int dbg = 0;
 };
@@ -4337,7 +4348,7 @@ int launch_tile(const Params &p, bool bwd, hipStream_t stream)
             hipLaunchKernelGGL(msda_zero_unowned_kernel, dim3(zb), dim3(256), 0, stream, p, kOwnPix * p.D);
             rc = check_launch("msda backward (zero-fill of pixels outside the bands)");
             if (rc) return rc;
-            if ((knobs().scatter_dbg & 2048) && p.Lq < (1 << 22)) {       // group-granular variant
+            if (own != 2 && p.Lq < (1 << 22)) {      // group-granular variant (MSDA_SCATTER_OWN=2: the point-granular kernel)
                 static LdsGrant granted_grp;
                 if (const int grc = grant_lds(reinterpret_cast<const void *>(&msda_bwd_value_grp_kernel<T>), (size_t)grp_lds_bytes<T>(), granted_grp,
                                               "the group-granular owner-computes scatter kernel")) return grc;

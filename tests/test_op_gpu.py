@@ -266,8 +266,10 @@ def test_full_size_properties_cfg3():
                                  {"MSDA_BWD_CULL": "0"},                 # no culling table at all
                                  {"MSDA_SCATTER_OWN": "0"},             # LDS-atomic scatter instead of owner-computes
                                  {"MSDA_SCATTER_OWN": "0", "MSDA_SCATTER_DBG": "16"},
-                                 {"MSDA_SCATTER_DBG": "16"},            # owner-computes scatter, static item order
-                                 {"MSDA_SCATTER_DBG": "256"}])          # ... without the cross-chunk prefetch
+                                 {"MSDA_SCATTER_DBG": "16"},            # (group-granular) owner-computes scatter, static item order
+                                 {"MSDA_SCATTER_OWN": "2"},          # point-granular owner-computes scatter
+                                 {"MSDA_SCATTER_OWN": "2", "MSDA_SCATTER_DBG": "16"},          # ... static item order
+                                 {"MSDA_SCATTER_OWN": "2", "MSDA_SCATTER_DBG": "256"}])         # ... without the cross-chunk prefetch
 def test_backward_alternate_routes(env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
