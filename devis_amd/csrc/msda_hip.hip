@@ -2849,20 +2849,28 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                 }
             }
         };
-        // One chunk of n groups: rows on their way, both passes' point loads issued, entries linked, lists walked.
-        auto process_chunk = [&](int base, int n) {
-            stage_rows(base, n);
-            float hx[kPasses], hy[kPasses], ha[kPasses];
-            int hq[kPasses];
-            bool hact[kPasses];
+        // One chunk of n groups: rows on their way, all passes' point loads issued (unless the previous chunk already did:
+        // `primed`), entries linked, barrier, the NEXT chunk's point loads issued so that their memory latency hides behind
+        // the walk, lists walked.
+        float hx[kPasses], hy[kPasses], ha[kPasses];
+        int hq[kPasses];
+        bool hact[kPasses];
+        auto fetch_chunk = [&](int base, int n) {
 #pragma unroll
-            for (int j = 0; j < kPasses; ++j)
+            for (int j = 0; j < kPasses; ++j) {
+                hact[j] = false;
                 if (j == 0 || n > j * (kOwnThreads / 4)) fetch_hit(base, n, j, hx[j], hy[j], ha[j], hq[j], hact[j]);
+            }
+        };
+        auto process_chunk = [&](int base, int n, bool primed, int nbase, int nn) {
+            stage_rows(base, n);
+            if (!primed) fetch_chunk(base, n);
 #pragma unroll
             for (int j = 0; j < kPasses; ++j)
                 if (j == 0 || n > j * (kOwnThreads / 4)) taps_link(j, hact[j], hx[j], hy[j], ha[j], hq[j]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's rows have landed
             __syncthreads();
+            if (nn > 0) fetch_chunk(nbase, nn);
             walk();
             __syncthreads();
         };
@@ -2949,10 +2957,14 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             listed += s_cnt[ci];
             ci = (ci + 1) % 3;
             if (dbg & 8) listed = 0;                    // measurement: cull only
+            bool primed = false;
             while (listed >= kOwnChunk || (last && listed > 0)) {
                 const int n = min(kOwnChunk, listed);
                 listed -= n;
-                process_chunk(listed, n);
+                const bool more = listed >= kOwnChunk || (last && listed > 0);
+                const int nn = more ? min(kOwnChunk, listed) : 0;
+                process_chunk(listed, n, primed, listed - nn, nn);
+                primed = more;
             }
             bcur = bnext;
         }
