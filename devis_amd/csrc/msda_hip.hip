@@ -2569,8 +2569,9 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
                 const int pix = s * kOwnQuads + Q;
                 if (pix < npix) {
                     float *o = gband + (int64_t)pix * MD;
-                    *reinterpret_cast<float4 *>(o + ch1) = make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
-                    *reinterpret_cast<float4 *>(o + ch2) = make_float4(acc[s][4], acc[s][5], acc[s][6], acc[s][7]);
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store((f32x4){acc[s][0], acc[s][1], acc[s][2], acc[s][3]}, reinterpret_cast<f32x4 *>(o + ch1));
+                    __builtin_nontemporal_store((f32x4){acc[s][4], acc[s][5], acc[s][6], acc[s][7]}, reinterpret_cast<f32x4 *>(o + ch2));
                 }
             }
         } else if (!direct) {
@@ -2976,8 +2977,9 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                 const int pix = s * kOwnQuads + Q;
                 if (pix < npix) {
                     float *o = gband + (int64_t)pix * MD;
-                    *reinterpret_cast<float4 *>(o + ch1) = make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
-                    *reinterpret_cast<float4 *>(o + ch2) = make_float4(acc[s][4], acc[s][5], acc[s][6], acc[s][7]);
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store((f32x4){acc[s][0], acc[s][1], acc[s][2], acc[s][3]}, reinterpret_cast<f32x4 *>(o + ch1));
+                    __builtin_nontemporal_store((f32x4){acc[s][4], acc[s][5], acc[s][6], acc[s][7]}, reinterpret_cast<f32x4 *>(o + ch2));
                 }
             }
         } else if (!direct) {
@@ -3691,10 +3693,17 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                         if constexpr (kHalf) {
                             Store<T>::store(gl, xy);
                         } else {
-                            const float lo[4] = {xy[0], xy[1], xy[2], xy[3]}, hi[4] = {xy[4], xy[5], xy[6], xy[7]};
-                            Store<T>::store(gl, lo); Store<T>::store(gl + 4, hi);
+                            // (non-temporal: the 309 MB of results must not evict the level-0 lines the gathers live on)
+                            typedef float f32x4 __attribute__((ext_vector_type(4)));
+                            __builtin_nontemporal_store((f32x4){xy[0], xy[1], xy[2], xy[3]}, reinterpret_cast<f32x4 *>(gl));
+                            __builtin_nontemporal_store((f32x4){xy[4], xy[5], xy[6], xy[7]}, reinterpret_cast<f32x4 *>(gl + 4));
                         }
-                        SlabStore<T>::store(gaw + idx0 + 4 * cor, wa);
+                        if constexpr (kHalf) {
+                            SlabStore<T>::store(gaw + idx0 + 4 * cor, wa);
+                        } else {
+                            typedef float f32x4 __attribute__((ext_vector_type(4)));
+                            __builtin_nontemporal_store((f32x4){wa[0], wa[1], wa[2], wa[3]}, reinterpret_cast<f32x4 *>(gaw + idx0 + 4 * cor));
+                        }
                         if (records)
                             *reinterpret_cast<int2 *>(p.bbox + (((group * p.M + m) * VL + vl0 + cor) * p.Lq + q0 + j) * 2) =
                                 make_int2((wr[0] & 0xffff) | (wr[1] << 16), (wr[2] & 0xffff) | (wr[3] << 16));
