@@ -2606,10 +2606,11 @@ msda_bwd_value_own_kernel(const Params p, int dbg)
 // per hit, longer lists = better lock-step efficiency of the walk), and the survivor list holds groups (1 entry per
 // cull thread, 6 KiB instead of 19).  Thread t of pass j handles point (t & 3) of group 256 j + t / 4; a group's 16
 // entries are one 128-byte block, so the row of an entry at LDS address A is (A - entries) >> 7.
+constexpr int kGrpList = 3 * kOwnThreads;       // survivor list entries (groups)
 template <typename T> constexpr int grp_chunk() { return sizeof(T) == 4 ? MSDA_GRP_F32 : MSDA_GRP_16; }       // groups per chunk
 template <typename T> constexpr int grp_lds_bytes()
 {
-    return grp_chunk<T>() * 32 * (int)sizeof(T) + 32 + 16 * grp_chunk<T>() * 8 + kOwnPix * 4 + (grp_chunk<T>() + kOwnThreads) * 4;
+    return grp_chunk<T>() * 32 * (int)sizeof(T) + 32 + 16 * grp_chunk<T>() * 8 + kOwnPix * 4 + kGrpList * 4;
 }
 
 template <typename T>
@@ -2626,7 +2627,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
     uint2 *ents = reinterpret_cast<uint2 *>(lds_raw + kOwnChunk * kRowB +
                                             ((32u - (lds_addr(lds_raw) & 31u)) & 31u));
     unsigned *head = reinterpret_cast<unsigned *>(ents + 16 * kOwnChunk);       // [kOwnPix]
-    unsigned *list = head + kOwnPix;                                            // [kOwnChunk + kOwnThreads] (k:6 | points:4 | q:22)
+    unsigned *list = head + kOwnPix;                                            // [kGrpList] (k:6 | points:4 | q:22)
     __shared__ int s_H[kScatterMaxLevels], s_W[kScatterMaxLevels], s_R[kScatterMaxLevels],
         s_first[kScatterMaxLevels + 1], s_lsi[kScatterMaxLevels];
     __shared__ int s_nsrc, s_cnt[3];     // survivor counters rotate: slot j is reset two barriers before it is used again
@@ -2958,11 +2959,14 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             listed += s_cnt[ci];
             ci = (ci + 1) % 3;
             if (dbg & 8) listed = 0;                    // measurement: cull only
+            // chunks are processed when the list could not take another cull batch, or at the end: an item of <= 2 batches
+            // (every decoder call) is culled completely first and its chunks then run back to back, each one's point loads
+            // issued under the previous one's walk
             bool primed = false;
-            while (listed >= kOwnChunk || (last && listed > 0)) {
+            while (listed > kGrpList - kOwnThreads || (last && listed > 0)) {
                 const int n = min(kOwnChunk, listed);
                 listed -= n;
-                const bool more = listed >= kOwnChunk || (last && listed > 0);
+                const bool more = listed > kGrpList - kOwnThreads || (last && listed > 0);
                 const int nn = more ? min(kOwnChunk, listed) : 0;
                 process_chunk(listed, n, primed, listed - nn, nn);
                 primed = more;
