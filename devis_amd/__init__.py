@@ -16,6 +16,7 @@ from .functions import (MSDeformAttnFunction, MSDeformAttnTemporalFunction,  # n
                         ms_deform_attn_core_pytorch)
 from .modules import (MSDeformAttn, TemporalMSDeformAttnDecoder,  # noqa: F401
                       TemporalMSDeformAttnEncoder)
+from .argument_builders import patch_transformer  # noqa: F401
 
 __all__ = ["MSDeformAttnFunction", "MSDeformAttnTemporalFunction", "ms_deform_attn_core_pytorch",
-           "MSDeformAttn", "TemporalMSDeformAttnEncoder", "TemporalMSDeformAttnDecoder"]
+           "MSDeformAttn", "TemporalMSDeformAttnEncoder", "TemporalMSDeformAttnDecoder", "patch_transformer"]

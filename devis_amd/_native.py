@@ -35,14 +35,12 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
-        path = _build.lib_path()
-        if not os.path.exists(path) or (_build.is_stale() and _build.have_compiler()):     # an edited .hip is never silently ignored
-            try:
-                _build.build()
-            except Exception as e:  # no hipcc on this box and no prebuilt library
-                raise RuntimeError(
-                    "devis_amd: the HIP library %s is missing and could not be built (%s). "
-                    "There is no CPU fallback for MSDeformAttn." % (path, e))
+        try:
+            path = _build.ensure()      # builds when missing / stale (file-locked); a stale library without hipcc warns
+        except Exception as e:  # no hipcc on this box and no prebuilt library
+            raise RuntimeError(
+                "devis_amd: the HIP library %s is missing and could not be built (%s). "
+                "There is no CPU fallback for MSDeformAttn." % (_build.lib_path(), e))
         lib = ctypes.CDLL(path)
         for name in EXPORTED_SYMBOLS:
             if not hasattr(lib, name):
@@ -73,6 +71,10 @@ def load():
         lib.msda_mask_rows.argtypes = [_ci, _vp, _vp] + [ctypes.c_longlong] * 3 + [_vp]
         _lib = lib
     return _lib
+
+
+def is_loaded():
+    return _lib is not None
 
 
 def reload_knobs():

@@ -66,7 +66,6 @@ class MSDeformAttnFunction(Function):
         # padding_mask (not in the reference's signature; used by MSDeformAttn only): the bool [N, S] mask `value`
         # was produced under.  The backward then zeroes the masked rows of ITS grad_value (the gradient of ref
         # ms_deform_attn.py:102-103's masked_fill) before returning it, and project_value's backward skips that pass.
-        ctx.has_mask_arg = padding_mask is not None
         ctx.padding_mask = None
         if padding_mask is not None:
             _require(padding_mask.dtype == torch.bool and padding_mask.device == value.device and
@@ -115,7 +114,9 @@ class MSDeformAttnFunction(Function):
         if ctx.padding_mask is not None and grad_value.numel():
             N, S, M, D = grad_value.shape
             _native.mask_rows(grad_value.view(N * S, M * D), ctx.padding_mask, M * D)
-        return (grad_value, None, None, grad_loc, grad_aw, None) + ((None,) if ctx.has_mask_arg else ())
+        # one gradient slot per forward argument INCLUDING the optional padding_mask: autograd accepts trailing None
+        # gradients beyond the inputs apply() was given, so the 6-argument (reference) call works with the same tuple
+        return grad_value, None, None, grad_loc, grad_aw, None, None
 
 
 class MSDeformAttnTemporalFunction(Function):

@@ -144,9 +144,8 @@ class MSDeformAttn(nn.Module):
             weights = weights.view(N, Len_q, M, L, P)
             locations = _locations(reference_points[:, :, None, :, None, :], offsets,
                                    _normalizer(input_spatial_shapes), P)
-        args = (value, input_spatial_shapes, input_level_start_index, locations.contiguous(), weights.contiguous(),
-                self.im2col_step)
-        output = MSDeformAttnFunction.apply(*(args if input_padding_mask is None else args + (input_padding_mask,)))
+        output = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index, locations.contiguous(),
+                                            weights.contiguous(), self.im2col_step, input_padding_mask)
         return self.output_proj(output), None
 
 
@@ -257,9 +256,15 @@ class TemporalMSDeformAttnBase(nn.Module):
     @staticmethod
     def _frame_table(temporal_offsets, n_frames, device):
         """[T, W] absolute frame indices: frame_table[t] = temporal_offsets[t] + t (ref :339, :445).
-        The transformer hands the SAME offset tensors to every layer (devis_transformer.py:103-113), so
-        the table -- four tiny kernels per call, two calls per decoder layer -- is built once per list of
-        tensors and reused while the very same tensor objects come back."""
+        The transformer hands the SAME offset tensors to every layer of one forward (devis_transformer.py:103-121,
+        151-169) but builds NEW ones every forward, so the table is cached while the very same tensor objects come
+        back and otherwise rebuilt WITHOUT a host synchronisation: a handful of tiny
+        launches once per stack per forward.
+
+        The reference indexes value[temporal_offsets[t] + t] with torch semantics: a negative index wraps once,
+        anything else out of range trips the indexing kernel's device-side assert.  The kernels take absolute frame ids
+        in [0, T), so the table is normalised here and the range check is the same kind of asynchronous device-side
+        assert (``torch._assert_async``; on CPU tensors it raises at once)."""
         cached = TemporalMSDeformAttnBase._table_cache
         if cached is not None and cached[1] == n_frames and cached[2] == device and \
                 len(cached[0]) == len(temporal_offsets) and \
@@ -267,13 +272,12 @@ class TemporalMSDeformAttnBase(nn.Module):
             return cached[3]
         table = torch.stack([o.to(device) for o in temporal_offsets]) \
             + torch.arange(n_frames, device=device)[:, None]
-        # The reference indexes value[temporal_offsets[t] + t] (ref :339, :445) with Python semantics: a negative
-        # index wraps once, anything else out of range raises.  The kernels take absolute frame ids in [0, T), so the
-        # table is normalised and checked here -- once per list of offset tensors (the result is cached).
-        table = torch.where(table < 0, table + n_frames, table)
-        if bool(((table < 0) | (table >= n_frames)).any()):
+        in_range = ((table >= -n_frames) & (table < n_frames)).all()
+        if in_range.is_cuda:
+            torch._assert_async(in_range)
+        elif not bool(in_range):
             raise IndexError("temporal_offsets point outside the clip's %d frames" % n_frames)
-        table = table.to(torch.int32).contiguous()
+        table = torch.remainder(table, n_frames).to(torch.int32).contiguous()
         TemporalMSDeformAttnBase._table_cache = ([(o, o._version) for o in temporal_offsets], n_frames, device, table)
         return table
 

@@ -17,8 +17,11 @@ os.environ["MSDA_ENABLE_HOOKS"] = "1"
 
 
 def _reload_knobs():
+    """Re-read the knobs -- only if the library is already loaded (a CPU test on the oracle-backed double must not
+    dlopen, let alone compile, the HIP library from a fixture teardown; a later load() reads the environment anyway)."""
     from devis_amd import _native
-    _native.reload_knobs()
+    if _native.is_loaded():
+        _native.reload_knobs()
 
 
 _orig_setenv, _orig_delenv = pytest.MonkeyPatch.setenv, pytest.MonkeyPatch.delenv
@@ -43,8 +46,7 @@ pytest.MonkeyPatch.setenv, pytest.MonkeyPatch.delenv = _setenv, _delenv
 def _knobs_follow_environment():
     """Set up before (hence torn down after) monkeypatch: the knobs are re-read once the environment is restored."""
     yield
-    if any(k.startswith("MSDA_") for k in os.environ) or True:
-        _reload_knobs()
+    _reload_knobs()
 
 
 def pytest_configure(config):

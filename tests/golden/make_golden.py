@@ -307,12 +307,88 @@ def make_config_sized_fixtures(Mo):
         print("wrote cfg_%s: %d arrays, |out| max %.3e" % (kind, len(got), np.abs(got["out"]).max()))
 
 
+def import_reference_transformer():
+    """The reference's call-site code: src/models/deformable_transformer.py and devis_transformer.py
+    imported as a package whose __init__ is skipped (it pulls in torchvision backbones) and whose only other import
+    outside ops/ -- util.misc.inverse_sigmoid, not used by anything recorded here -- is a placeholder that raises."""
+    import_reference()
+    top = types.ModuleType("refsrc"); top.__path__ = ["/root/reference/src"]; sys.modules["refsrc"] = top
+    pkg = types.ModuleType("refsrc.models"); pkg.__path__ = ["/root/reference/src/models"]; sys.modules["refsrc.models"] = pkg
+    util = types.ModuleType("refsrc.util"); util.__path__ = []; sys.modules["refsrc.util"] = util
+    misc = types.ModuleType("refsrc.util.misc")
+
+    def inverse_sigmoid(*a, **k):
+        raise NotImplementedError("placeholder: not part of the recorded call sites")
+    misc.inverse_sigmoid = inverse_sigmoid
+    sys.modules["refsrc.util.misc"] = misc
+    return (importlib.import_module("refsrc.models.deformable_transformer"),
+            importlib.import_module("refsrc.models.devis_transformer"))
+
+
+class _Recorder(torch.nn.Module):
+    """Stands in for an encoder / decoder LAYER: records the arguments the reference's stack hands it."""
+
+    def __init__(self):
+        super().__init__()
+        self.calls = []
+
+    def forward(self, *args, **kwargs):
+        self.calls.append((args, kwargs))
+        return args[0]
+
+
+def make_call_site_fixtures():
+    """What the reference's transformer stacks hand the attention modules (devis_transformer.py:94-121,146-169;
+    deformable_transformer.py:185-198): encoder reference points, temporal offsets (connect-all and windowed, clip ends
+    mirrored), repeated shapes / level starts.  `frames[t]` = arange(T)[offsets[t] + t], i.e. the frames the
+    reference's `value[temporal_offsets[t] + t]` (ops/modules/ms_deform_attn.py:339,445) selects."""
+    DT, DV = import_reference_transformer()
+    g = torch.Generator().manual_seed(77)
+    shapes = [(12, 20), (6, 10), (3, 5)]
+    ss = torch.as_tensor(shapes, dtype=torch.long)
+    lsi = lsi_of(ss)
+    S = int(ss.prod(1).sum())
+    d = {"spatial_shapes": ss.numpy(), "level_start_index": lsi.numpy()}
+    for T in (5, 6):
+        vr = torch.rand(T, len(shapes), 2, generator=g) * 0.4 + 0.6
+        d["T%d/valid_ratios" % T] = vr.numpy()
+        d["T%d/reference_points" % T] = DT.DeformableTransformerEncoder.get_reference_points(ss, vr, torch.device("cpu")).numpy()
+        src = torch.zeros(T, S, 8)
+        for mode, connect_all, window in (("all", True, 2), ("win2", False, 2), ("win4", False, 4)):
+            enc = DV.DeVISTransformerEncoder(_Recorder(), 1, window, connect_all)
+            enc(src, ss, lsi, vr)
+            (a, kw), = enc.layers[0].calls          # (_get_clones deep-copied the recorder)
+            offsets = kw["temporal_offsets"]
+            key = "T%d/enc_%s/" % (T, mode)
+            d[key + "offsets"] = torch.stack(offsets).numpy()
+            d[key + "frames"] = torch.stack([torch.arange(T)[o + t] for t, o in enumerate(offsets)]).numpy()
+            d[key + "temporal_shapes"] = a[3][1].numpy()
+            d[key + "temporal_lsi"] = a[4][1].numpy()
+            assert torch.equal(a[2], torch.from_numpy(d["T%d/reference_points" % T]))
+        dec = DV.DeVISTransformerDecoder(_Recorder(), 1)
+        dec.refine_reference_point = lambda lid, out, ref, inter, inter_ref: (ref, inter + [out], inter_ref + [ref])
+        dec(torch.zeros(1, 7 * T, 8), torch.rand(1, 7 * T, 2, generator=g), src, ss, lsi, vr)
+        (a, kw), = dec.layers[0].calls
+        offsets = kw["temporal_offsets"]
+        key = "T%d/dec/" % T
+        d[key + "offsets"] = torch.stack(offsets).numpy()
+        d[key + "frames"] = torch.stack([torch.arange(T)[o + t] for t, o in enumerate(offsets)]).numpy()
+        d[key + "temporal_shapes"] = a[4][1].numpy()
+        d[key + "temporal_lsi"] = a[5][1].numpy()
+    np.savez_compressed(os.path.join(HERE, "args_call_sites.npz"), **d)
+    print("wrote args_call_sites: %d arrays" % len(d))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF_OPS):
         sys.exit("reference not present: golden vectors can only be regenerated in the build container")
     F, Mo = import_reference()
+    if "--call-sites-only" in sys.argv:
+        make_call_site_fixtures()
+        sys.exit(0)
     if "--config-sized-only" not in sys.argv:
         make_op_fixtures(F)
         make_module_fixtures(Mo)
     make_config_sized_fixtures(Mo)
+    make_call_site_fixtures()
     os.system("du -sh %s" % HERE)

@@ -8,8 +8,13 @@ from conftest import golden
 C, M, L, T, Q = 32, 4, 2, 3, 5      # dimensions used by make_golden.py
 
 
-def build(name, device, dtype):
-    from devis_amd.modules import MSDeformAttn, TemporalMSDeformAttnDecoder, TemporalMSDeformAttnEncoder
+def build(name, device, dtype, modules=None):
+    """`modules`: the package to take the three classes from (default devis_amd.modules; tests/test_dropin.py passes
+    the same package imported as src.models.ops.modules)."""
+    if modules is None:
+        import devis_amd.modules as modules
+    MSDeformAttn, TemporalMSDeformAttnDecoder, TemporalMSDeformAttnEncoder = (
+        modules.MSDeformAttn, modules.TemporalMSDeformAttnDecoder, modules.TemporalMSDeformAttnEncoder)
     g = golden(name)
     if name.startswith("mod_plain"):
         mod = MSDeformAttn(d_model=C, n_levels=L, n_heads=M, n_points=3)
@@ -33,8 +38,8 @@ def _t(g, key, device, dtype):
     return x.to(device=device, dtype=dtype if x.is_floating_point() else x.dtype)
 
 
-def run(name, device, dtype, fused=True):
-    mod, g = build(name, device, dtype)
+def run(name, device, dtype, fused=True, modules=None):
+    mod, g = build(name, device, dtype, modules)
     if hasattr(mod, "fused"):
         mod.fused = fused
     query = _t(g, "in/query", device, dtype).requires_grad_(True)

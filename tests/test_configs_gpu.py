@@ -63,63 +63,96 @@ def test_cfg4_im2col_step_values_agree_bitwise():
     assert _maxabs(a[1], b[1]) <= 1e-3 * max(1.0, np.abs(b[1]).max())      # grad_value: summation order may differ
 
 
-def test_bench_scale_batch_against_the_oracle():
-    """The regime bench.py times -- 16 cfg3 clips in ONE fused call (resident-slab forward, slab gather pass,
-    owner-computes scatter) -- compared clip by clip with the CPU oracle in the reference's 2*T-call pattern
-    (helpers.temporal_reference), not with other runs of the same library."""
+BENCH_SCALE = [
+    # dtype, clips, value layout, tiles per wave the forward must have run with (None: not asserted), tol out, tol grads
+    (torch.float32, 16, "dense", None, 1e-5, 1e-4),
+    (torch.float32, 16, "padded", None, 1e-5, 1e-4),       # the layout devis_amd's own value_proj writes (modules' default)
+    (torch.float32, 32, "dense", 4, 1e-5, 1e-4),           # >= 32 clips: 4 tiles per wave (accumulator sets 2 and 3 in use)
+    (torch.bfloat16, 16, "dense", 4, 1e-2, 2e-2),          # 16-bit storage: 4 tiles per wave at the bench's 16 clips
+    (torch.float16, 16, "dense", 4, 1e-3, 4e-3),
+]
+
+
+@pytest.mark.parametrize("dtype,clips,layout,want_nt,tol_out,tol_grad", BENCH_SCALE,
+                         ids=["f32-16", "f32-16-padded", "f32-32-nt4", "bf16-16-nt4", "f16-16-nt4"])
+def test_bench_scale_batch_against_the_oracle(dtype, clips, layout, want_nt, tol_out, tol_grad):
+    """The regimes bench.py times -- 16 / 32 cfg3 clips in ONE fused call (resident-slab forward and gather pass with
+    2 or 4 tiles per wave, owner-computes scatter), fp32 and 16-bit storage, dense and padded `value` -- compared clip
+    by clip with the CPU oracle in the reference's 2*T-call pattern (helpers.temporal_reference; ref semantics
+    ms_deform_im2col_cuda.cuh:237-299, ms_deform_attn.py:325-364), not with other runs of the same library.  16-bit:
+    the oracle runs in fp64 on the SAME rounded inputs."""
+    from devis_amd import _native
     from devis_amd.functions import MSDeformAttnTemporalFunction
-    clips, T, Lq = 16, 6, 300
-    ds = [make_temporal_inputs(900 + c, T=T, W=5, M=8, D=32, Lq=Lq, shapes=PYR_A, Pc=4, Pt=4) for c in range(clips)]
+    T, Lq, M, D = 6, 300, 8, 32
+    check = sorted({0, clips // 2 - 1, clips - 1})
+    ds = [round_to(make_temporal_inputs(900 + c, T=T, W=5, M=M, D=D, Lq=Lq, shapes=PYR_A, Pc=4, Pt=4, dtype=np.float64), dtype)
+          if dtype != torch.float32 else make_temporal_inputs(900 + c, T=T, W=5, M=M, D=D, Lq=Lq, shapes=PYR_A, Pc=4, Pt=4)
+          for c in range(clips)]
     shapes, lsi, ftab = (torch.from_numpy(ds[0][k]).to(DEV) for k in ("shapes", "lsi", "ftab"))
     keys = ("value", "loc_c", "aw_c", "loc_t", "aw_t")
-    leaves = [torch.from_numpy(np.concatenate([d[k] for d in ds], 0)).to(DEV).requires_grad_(True) for k in keys]
-    go = torch.from_numpy(np.concatenate([d["grad_out"] for d in ds], 0)).to(DEV)
+    cat = lambda k: torch.from_numpy(np.concatenate([d[k] for d in ds], 0)).to(DEV, dtype)
+    leaves = [cat(k).requires_grad_(True) for k in keys]
+    if layout == "padded":
+        buf = torch.zeros((clips * T, leaves[0].shape[1], M + 1, D), dtype=dtype, device=DEV)
+        buf[:, :, :M] = leaves[0].detach()
+        leaves[0] = buf[:, :, :M].requires_grad_(True)
+        assert not leaves[0].is_contiguous()
+    go = cat("grad_out")
+    routes = []
+    leaves[0].register_hook(lambda g: routes.append(_native.last_route()))      # (the backward runs on autograd's thread)
     out = MSDeformAttnTemporalFunction.apply(leaves[0], shapes, lsi, ftab, *leaves[1:], clips)
+    fwd_route = _native.last_route()
     grads = torch.autograd.grad(out, leaves, go)
+    torch.cuda.synchronize()
+    assert "resident-slab" in fwd_route and "resident-slab" in routes[0] and "owner-computes" in routes[0], (fwd_route, routes)
+    if want_nt is not None:
+        assert "%d tiles per wave" % want_nt in fwd_route, fwd_route
     got = [x.detach().double().cpu().numpy() for x in (out,) + tuple(grads)]
-    for c in (0, 7, 15):
+    fkeys = ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")
+    for c in check:
         d = ds[c]
-        args = [np.asarray(d[k], dtype=np.float64) if d[k].dtype.kind == "f" else d[k]
-                for k in ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")]
-        ref = temporal_reference(*args)
-        args32 = [np.asarray(d[k], dtype=np.float32) if d[k].dtype.kind == "f" else d[k]
-                  for k in ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")]
-        ref32 = temporal_reference(*args32)           # fp32 oracle for grad_loc (cell borders)
+        ref = temporal_reference(*[np.asarray(d[k], dtype=np.float64) if d[k].dtype.kind == "f" else d[k] for k in fkeys])
+        # fp32 oracle for grad_loc (a location within rounding distance of a cell border takes the other cell's derivative)
+        ref32 = temporal_reference(*[np.asarray(d[k], dtype=np.float32) if d[k].dtype.kind == "f" else d[k] for k in fkeys])
         names = ("out", "grad_value", "grad_loc_c", "grad_aw_c", "grad_loc_t", "grad_aw_t")
         for i, name in enumerate(names):
             mine = got[i][c * T:(c + 1) * T]
             want = ref32[i] if name.startswith("grad_loc") else ref[i]
-            tol = 1e-4 if i else 1e-5
-            assert _maxabs(mine, want) <= tol * max(1.0, np.abs(want).max()), (c, name)
+            tol = tol_grad if i else tol_out
+            scale = max(1.0, np.abs(want).max())
+            if name.startswith("grad_loc") and dtype != torch.float32:
+                # 16-bit results: rounding on top of the border effect -- all but a few per mille within tolerance
+                assert (np.abs(mine - want) > tol * scale).mean() <= 2e-3, (c, name)
+            else:
+                assert _maxabs(mine, want) <= tol * scale, (c, name, _maxabs(mine, want), scale)
 
 
 MODULE_FIXTURES = [n for n in golden_names("mod_") if n != "mod_fresh_init"]
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-@pytest.mark.parametrize("name", MODULE_FIXTURES)
-def test_modules_reduced_precision_vs_reference_fixture(name, dtype):
-    """The three nn.Modules in bf16 / f16 against the fp64 fixtures captured from the REFERENCE modules (north_star:
-    1e-2 for bf16).  Parameters and inputs are the fixture's, rounded by the module cast; outputs are compared with
-    a norm-wise bound (reduced-precision Linears dominate the error), gradients more loosely."""
-    got, g = module_cases.run(name, DEV, dtype, fused=True)
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3)], ids=["bf16", "f16"])
+@pytest.mark.parametrize("kind", ["dec", "enc"])
+def test_config_sized_modules_reduced_precision_vs_reference_fixture(kind, dtype, tol):
+    """The temporal decoder / encoder at DeVIS's real size in bf16 / f16 (parameters, activations and `value` stored in
+    16 bits, arithmetic fp32) against the fp64 fixture captured from the REFERENCE modules (tests/golden/cfg_*.npz):
+    outputs within the north_star's 1e-2 (bf16) of the output scale, norm-wise AND on the sampled elements; the
+    decoder's auxiliary returns (locations, weights) likewise; gradients norm-wise (piecewise-constant bilinear
+    derivatives: a location rounded across a cell border flips single terms)."""
+    from conftest import golden
+    from devis_amd.modules import TemporalMSDeformAttnDecoder, TemporalMSDeformAttnEncoder
+    g = golden("cfg_" + kind)
+    cls = TemporalMSDeformAttnDecoder if kind == "dec" else TemporalMSDeformAttnEncoder
+    got = module_cases.cfg_run(kind, cls, device=DEV, dtype=dtype)
     for k, v in got.items():
-        exp = g[k]
-        a = v.detach().double().cpu().numpy()
-        assert a.shape == exp.shape and np.isfinite(a).all(), k
-        scale = max(1.0, float(np.abs(exp).max()))
-        rel = float(np.linalg.norm(a - exp) / max(1e-12, np.linalg.norm(exp)))
+        assert np.isfinite(v).all(), k
+        mine, want = module_cases.cfg_sample(v)["sample"], g[k + "/sample"]
+        rel = float(np.linalg.norm(mine - want) / max(1e-12, np.linalg.norm(want)))
         if k == "out" or k.startswith("aux/"):
-            assert rel <= (2e-2 if dtype == torch.bfloat16 else 4e-3), (k, rel)
-            # (element-wise the bound is looser than the operator's 1e-2: the sampling LOCATIONS themselves are rounded
-            # to 8 / 11 mantissa bits here, which moves taps by up to a few hundredths of a pixel)
-            assert float(np.abs(a - exp).max()) <= (8e-2 if dtype == torch.bfloat16 else 1.5e-2) * scale, k
+            scale = max(1.0, float(np.abs(want).max()))
+            assert rel <= tol, (k, rel)
+            assert float(np.abs(mine - want).max()) <= 4 * tol * scale, (k, float(np.abs(mine - want).max()), scale)
         else:
-            # gradients: the bilinear derivative is piecewise constant, and reduced-precision locations put some
-            # taps in the neighbouring cell -- a norm-wise sanity bound, not a precision claim
-            # (the gradients of the offset Linears are sums of such jumps on these 6x4 / 3x2-pixel fixture maps: finite only)
-            if "sampling_offsets" not in k:
-                assert rel <= (5e-1 if dtype == torch.bfloat16 else 2e-1), (k, rel)
+            assert rel <= 10 * tol, (k, rel)
 
 
 def test_gradcheck_reference_large_head_dims():
@@ -170,9 +203,11 @@ def test_fused_prep_takes_reference_points_of_another_dtype():
         mod(query, ref32, src, shapes.to(torch.int32), lsi, None)
 
 
-def test_frame_table_wraps_negative_offsets_and_rejects_out_of_range():
+def test_frame_table_wraps_negative_offsets_on_the_device():
     """temporal_offsets[t] + t indexes `value` with Python semantics in the reference (ms_deform_attn.py:339,445):
-    a negative index wraps once, anything else out of range raises."""
+    a negative index wraps once.  (Out-of-range offsets: tests/test_host_cpu.py -- on device tensors they trip an
+    asynchronous device-side assert, like the reference's indexing, which a test process cannot survive.)  The table is
+    built without a host synchronisation."""
     from devis_amd.modules.ms_deform_attn import TemporalMSDeformAttnBase
     T = 4
     offs = [torch.tensor([-1, 1], device=DEV) for _ in range(T)]
@@ -180,9 +215,6 @@ def test_frame_table_wraps_negative_offsets_and_rejects_out_of_range():
     offs[T - 1] = torch.tensor([-1, -2], device=DEV)
     table = TemporalMSDeformAttnBase._frame_table(offs, T, torch.device(DEV)).cpu().tolist()
     assert table[0] == [T - 1, 1] and table[T - 1] == [T - 2, T - 3]
-    bad = [torch.tensor([1, 2], device=DEV) for _ in range(T)]      # frame T-1 + 1 = T: out of range
-    with pytest.raises(IndexError):
-        TemporalMSDeformAttnBase._frame_table(bad, T, torch.device(DEV))
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 1e-4)], ids=["f64", "f32"])

@@ -91,6 +91,22 @@ def test_function_wiring_and_im2col_chunking(monkeypatch):
                                    torch.from_numpy(g["level_start_index"]), l, a, 2)
 
 
+def test_function_accepts_an_explicit_none_padding_mask(monkeypatch):
+    """apply(v, ss, lsi, loc, aw, step, None) -- seven inputs, the optional mask explicitly None -- and the
+    reference's six-input call both get one gradient slot per input."""
+    fake_native.install(monkeypatch)
+    from devis_amd.functions import MSDeformAttnFunction
+    g = golden("op_testpy_shape")
+    ss, lsi = torch.from_numpy(g["spatial_shapes"]), torch.from_numpy(g["level_start_index"])
+    for extra in ((), (None,)):
+        v, l, a = (torch.from_numpy(g[k]).double().requires_grad_(True)
+                   for k in ("value", "sampling_locations", "attention_weights"))
+        out = MSDeformAttnFunction.apply(v, ss, lsi, l, a, 2, *extra)
+        gv, gl, ga = torch.autograd.grad(out, (v, l, a), torch.from_numpy(g["grad_output"]))
+        np.testing.assert_allclose(gv.numpy(), g["grad_value"], rtol=1e-11, atol=1e-14)
+        np.testing.assert_allclose(ga.numpy(), g["grad_attn_weight"], rtol=1e-11, atol=1e-14)
+
+
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", MODULE_FIXTURES)
 def test_modules_match_reference_modules(monkeypatch, name, fused):
@@ -180,31 +196,59 @@ def test_project_value_padded_equals_dense_linear(monkeypatch):
     assert project_value(x, lin, 4, None, pad_heads=0).is_contiguous()
 
 
-def test_cached_argument_builders_match_the_reference_formulas():
-    """level tables, encoder reference points and temporal tables, cached per pyramid, equal the
-    reference's inline code (deformable_transformer.py:69-94,185-198; devis_transformer.py:94-118,147-158) bit for
-    bit, and repeated calls hand back the same objects."""
+def test_cached_reference_points_match_the_reference_call_site():
+    """the cached get_reference_points equals, bit for bit, what the REFERENCE's
+    DeformableTransformerEncoder.get_reference_points (deformable_transformer.py:185-198) returned for the same pyramid
+    and valid ratios (tests/golden/args_call_sites.npz, recorded from the reference's encoder stack), and
+    patch_transformer() installs it on a class shaped like the reference's."""
+    import types
+    import devis_amd
     from devis_amd import argument_builders as ab
-    shapes = [(12, 20), (6, 10), (3, 5)]
-    dev = torch.device("cpu")
-    ss, lsi = ab.level_tables(shapes, dev)
-    ref_ss = torch.as_tensor(shapes, dtype=torch.long)
-    assert torch.equal(ss, ref_ss) and torch.equal(lsi, torch.cat((ref_ss.new_zeros((1,)), ref_ss.prod(1).cumsum(0)[:-1])))
-    assert ab.level_tables(shapes, dev)[0] is ss
-    vr = torch.rand(2, 3, 2, generator=torch.Generator().manual_seed(5)) * 0.5 + 0.5
-    lst = []
-    for lvl, (H_, W_) in enumerate(shapes):           # the reference's get_reference_points, restated
-        ry, rx = torch.meshgrid(torch.linspace(0.5, H_ - 0.5, H_), torch.linspace(0.5, W_ - 0.5, W_), indexing='ij')
-        ry = ry.reshape(-1)[None] / (vr[:, None, lvl, 1] * H_)
-        rx = rx.reshape(-1)[None] / (vr[:, None, lvl, 0] * W_)
-        lst.append(torch.stack((rx, ry), -1))
-    want = torch.cat(lst, 1)[:, :, None] * vr[:, None]
-    assert torch.equal(ab.reference_points(shapes, vr, dev), want)
-    T = 5
-    offs, rep, start = ab.temporal_tables(ss, T, dev)
-    for t in range(T):
-        assert offs[t].tolist() == [u for u in range(-t, T - t) if u != 0]
-    assert torch.equal(rep, ss.repeat(T - 1, 1)) and torch.equal(start, torch.cat((rep.new_zeros((1,)), rep.prod(1).cumsum(0)[:-1])))
-    assert ab.temporal_tables(ss, T, dev)[0][2] is offs[2]
-    offs_w, rep_w, _ = ab.temporal_tables(ss, T, dev, t_window=2)
-    assert [o.tolist() for o in offs_w] == [[1, 1], [-1, 1], [-1, 1], [-1, 1], [-1, -1]] and rep_w.shape[0] == 2 * len(shapes)
+    g = golden("args_call_sites")
+    ss = torch.from_numpy(g["spatial_shapes"])
+    for T in (5, 6):
+        vr = torch.from_numpy(g["T%d/valid_ratios" % T])
+        want = torch.from_numpy(g["T%d/reference_points" % T])
+        assert torch.equal(ab.get_reference_points(ss, vr, torch.device("cpu")), want)
+        assert torch.equal(ab.get_reference_points([tuple(r) for r in ss.tolist()], vr, torch.device("cpu")), want)   # cache hit
+    assert len(ab._grid_cache) == 1
+
+    class DeformableTransformerEncoder:                      # the attribute layout of deformable_transformer.py:178-198
+        @staticmethod
+        def get_reference_points(spatial_shapes, valid_ratios, device):
+            raise AssertionError("the un-patched builder ran")
+
+        def forward(self, spatial_shapes, valid_ratios):
+            return self.get_reference_points(spatial_shapes, valid_ratios, device=valid_ratios.device)
+
+    class DeVISTransformerEncoder(DeformableTransformerEncoder):       # devis_transformer.py:83
+        pass
+
+    mod = types.SimpleNamespace(DeformableTransformerEncoder=DeformableTransformerEncoder)
+    previous = devis_amd.patch_transformer(mod)
+    assert isinstance(previous, staticmethod)
+    assert torch.equal(DeVISTransformerEncoder().forward(ss, vr), want)
+
+
+@pytest.mark.parametrize("mode", ["enc_all", "enc_win2", "enc_win4", "dec"])
+@pytest.mark.parametrize("T", [5, 6])
+def test_frame_table_selects_the_frames_the_reference_indexes(T, mode):
+    """SURVEY 8 a13: from the temporal_offsets the REFERENCE's stacks build (devis_transformer.py:97-118, 146-153;
+    recorded in args_call_sites.npz -- connect-all, windows of 2 and 4 with mirrored clip ends) _frame_table derives
+    exactly the frames value[temporal_offsets[t] + t] (ms_deform_attn.py:339,445) selects."""
+    from devis_amd.modules.ms_deform_attn import TemporalMSDeformAttnBase
+    g = golden("args_call_sites")
+    offs = [torch.from_numpy(r.copy()) for r in g["T%d/%s/offsets" % (T, mode)]]
+    table = TemporalMSDeformAttnBase._frame_table(offs, T, torch.device("cpu"))
+    assert table.dtype == torch.int32 and table.tolist() == g["T%d/%s/frames" % (T, mode)].tolist()
+
+
+def test_frame_table_rejects_out_of_range_offsets():
+    """A negative index wraps once, anything else out of range is an error (ADVICE r1): IndexError for host tensors;
+    for device tensors the same asynchronous device-side assert the reference's own indexing kernel raises."""
+    from devis_amd.modules.ms_deform_attn import TemporalMSDeformAttnBase
+    T = 4
+    for bad in ([torch.tensor([1, 2]) for _ in range(T)],                  # frame T-1 + 1 = T
+                [torch.tensor([-1, -2 * T]) for _ in range(T)]):           # wraps more than once
+        with pytest.raises(IndexError):
+            TemporalMSDeformAttnBase._frame_table(bad, T, torch.device("cpu"))
