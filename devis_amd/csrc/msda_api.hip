@@ -1,0 +1,621 @@
+// msda_api.hip -- host side of libmsda_hip.so: the extern "C" ABI of include/msda.h, argument checks, kernel selection
+// (which family takes a shape: resident-slab / tile / generic kernels; owner-computes / LDS / atomic scatter), the test
+// knobs and the per-device caches.  The kernels live in the other translation units of this directory.
+#include "msda_common.h"
+
+namespace msda {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, const char *detail)
+{
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+thread_local char g_route[512] = "";     // kernels launched by the last entry-point call of this thread (msda_last_route)
+
+int check_launch(const char *what)
+{
+    const size_t used = strlen(g_route);
+    if (used + 3 < sizeof(g_route)) snprintf(g_route + used, sizeof(g_route) - used, "%s%s", used ? "; " : "", what);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return MSDA_ERR_HIP;
+    }
+    return MSDA_OK;
+}
+
+namespace {
+
+bool aligned16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
+
+size_t tile_lds_bytes(int rpw, int nvl, bool bwd, bool intervals = false)
+{
+    return (size_t)rpw * kRowSlots * 16 * (bwd ? 3 : 2) + (size_t)nvl * sizeof(Level) +
+           (intervals ? (size_t)rpw * nvl * 8 : 0);     // + the per-(row, level) tap-row intervals
+}
+
+// ---- test / measurement knobs -------------------------------------------------------------------------------
+// All of them are environment variables that are read ONCE (first call into the library, or msda_reload_knobs())
+// and only when MSDA_ENABLE_HOOKS=1: a production process cannot have its results or speed changed by a stray
+// variable, and the launch path does not call getenv.  tests/ and bench.py set MSDA_ENABLE_HOOKS=1 and call
+// msda_reload_knobs() after changing a knob.
+struct Knobs {
+    int fwd_rs = -1, fwd_rs_nt = 0;     // resident-slab forward: -1 auto, 0 off, 1 force; tiles per wave (0 = auto)
+    int bwd_rs = -1;                    // resident-slab gather pass: -1 auto, 0 off, 1 force
+    int bwd_atomic = 0;                 // MSDA_BWD_MODE=atomic: one-kernel backward with global atomics
+    int bwd_phases = 3;                 // 1 = gather pass only, 2 = scatter pass only, 3 = both
+    int bwd_cull = 1;                   // 0: no culling structure, 2: (min, max) intervals instead of per-point records
+    int bwd_summary = 1;                // 64-query block summaries for long candidate ranges
+    int scatter_lds_kb = 144, scatter_dbg = 0;
+    int scatter_own = -1;               // owner-computes scatter: -1 auto, 0 off (the LDS-atomic scatter instead)
+    int force_generic = 0;
+    int dbg = 0;
+};
+Knobs g_knobs;
+int g_knobs_loaded = 0;
+
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return (e && e[0]) ? atoi(e) : dflt;
+}
+
+void load_knobs()
+{
+    Knobs k;
+    if (env_int("MSDA_ENABLE_HOOKS", 0) == 1) {
+        k.fwd_rs = env_int("MSDA_FWD_RS", k.fwd_rs); k.fwd_rs_nt = env_int("MSDA_FWD_RS_NT", k.fwd_rs_nt);
+        k.bwd_rs = env_int("MSDA_BWD_RS", k.bwd_rs);
+        const char *mode = getenv("MSDA_BWD_MODE");
+        k.bwd_atomic = (mode && !strcmp(mode, "atomic")) ? 1 : 0;
+        k.bwd_phases = env_int("MSDA_BWD_PHASES", k.bwd_phases);
+        k.bwd_cull = env_int("MSDA_BWD_CULL", k.bwd_cull);
+        k.bwd_summary = env_int("MSDA_BWD_SUMMARY", k.bwd_summary);
+        k.scatter_lds_kb = env_int("MSDA_SCATTER_LDS_KB", k.scatter_lds_kb);
+        k.scatter_dbg = env_int("MSDA_SCATTER_DBG", k.scatter_dbg);
+        k.scatter_own = env_int("MSDA_SCATTER_OWN", k.scatter_own);
+        k.force_generic = env_int("MSDA_FORCE_GENERIC", 0) == 1;
+        k.dbg = env_int("MSDA_DBG", 0);
+    }
+    g_knobs = k;
+    __atomic_store_n(&g_knobs_loaded, 1, __ATOMIC_RELEASE);
+}
+
+inline const Knobs &knobs()
+{
+    if (!__atomic_load_n(&g_knobs_loaded, __ATOMIC_ACQUIRE)) load_knobs();      // benign race: every thread reads the same environment
+    return g_knobs;
+}
+
+int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    return dev;
+}
+
+}  // namespace
+
+// ---- per-device caches --------------------------------------------------------------------------------------
+int device_cus()
+{
+    static int cus[kMaxDevices];        // 0 = not asked yet; benign race: every thread computes the same value
+    const int dev = current_device();
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
+int grant_lds(const void *kernel, size_t bytes, LdsGrant &granted, const char *what)
+{
+    const int dev = current_device();
+    if (bytes <= granted.bytes[dev]) return MSDA_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return fail(MSDA_ERR_HIP, "msda: cannot reserve the LDS budget of %s", what);
+    granted.bytes[dev] = bytes;
+    return MSDA_OK;
+}
+
+namespace {
+
+int elem_bytes(int dtype) { return dtype == MSDA_F32 ? 4 : dtype == MSDA_F64 ? 8 : 2; }
+
+// How many of the LAST pyramid levels fit `cap_pixels` pixels of LDS slab (the device-side rule of first_slab_level,
+// evaluated on the host copy of spatial_shapes when the caller passed one; otherwise guessed from the pixel count:
+// with the usual stride-2 pyramids level 0 holds ~3/4 of the S pixels).  Returns the first slab level l0.
+int host_first_slab_level(const Params &p, long long cap_pixels)
+{
+    if (p.shapes_host) {
+        int l0 = p.L;
+        long long acc = 0;
+        for (int l = p.L - 1; l >= 0; --l) {
+            acc += (long long)p.shapes_host[2 * l] * p.shapes_host[2 * l + 1];
+            if (acc > cap_pixels) break;
+            l0 = l;
+        }
+        return l0;
+    }
+    if (p.L == 1) return (long long)p.S <= cap_pixels ? 0 : 1;
+    return (long long)p.S <= cap_pixels ? 0 : ((double)p.S * 0.2551 <= (double)cap_pixels ? 1 : 2);
+}
+
+// Pixels of the levels below l0 (the ones the resident-slab kernels gather through the L2), from the host copy of the
+// shapes or, without one, from the usual stride-2 pyramid proportions.
+long long host_pixels_below(const Params &p, int l0)
+{
+    if (l0 <= 0) return 0;
+    if (p.shapes_host) {
+        long long acc = 0;
+        for (int l = 0; l < l0 && l < p.L; ++l) acc += (long long)p.shapes_host[2 * l] * p.shapes_host[2 * l + 1];
+        return acc;
+    }
+    return l0 >= p.L ? p.S : (long long)((double)p.S * (l0 == 1 ? 0.75 : 0.94));
+}
+
+// Tiles per wave of the resident-slab kernels = how many workgroups share one (clip, head).  Every workgroup of a
+// pair gathers the non-resident levels from the same maps, and what an XCD's 4 MiB L2 keeps of them decides the
+// kernels' speed: take the LARGEST workgroups (least slab staging) whose pairs in flight per
+// XCD still fit `l2_budget`, else the smallest.  Measured on the round-2 kernels, 16 / 32 clips of the DeVIS decoder
+// shape, 4 / 2 / 1 tiles per wave: forward fp32 (460 KiB per map) 0.440 / 0.441 / 0.473 and 0.754 / 0.800 / 0.915 ms,
+// bf16 (230 KiB) 0.343 / 0.372 / 0.395 ms; gather pass fp32 4 vs 2 tiles: 0.547 vs 0.524 ms.  Hence 8 MiB for the
+// forward (4 tiles per wave for fp32 too: equal at 16 clips, -6 % at 32) and 4 MiB for the gather pass, whose extra
+// streams (grad_out rows, 309 MB of results) compete for the same L2.
+int rs_tiles_per_wave(const Params &p, int tiles_per_clip, long long outside_bytes, bool force, long long l2_budget)
+{
+    const int64_t clips = p.groups / p.frames;
+    const int cus_per_xcd = device_cus() / 8 > 0 ? device_cus() / 8 : 1;
+    int pick = 0;
+    for (int cand : {4, 2, 1}) {
+        const int parts = (tiles_per_clip + kRsWaves * cand - 1) / (kRsWaves * cand);
+        if (!force && clips * p.M * parts < device_cus()) continue;          // must fill the chip
+        pick = cand;
+        const long long pairs = (cus_per_xcd + parts - 1) / parts;
+        // (beyond 4 MiB only with at least two workgroups per CU: measured equal-or-worse with exactly one)
+        if (pairs * outside_bytes <= (4ll << 20) || (pairs * outside_bytes <= l2_budget && clips * p.M * parts >= 2 * device_cus())) break;
+    }
+    return pick;
+}
+
+bool standard_value_layout(const Params &p)
+{
+    return p.v_clip == (int64_t)p.frames * p.S * p.M * p.D && p.v_head == p.D && p.v_pix == p.M * p.D;
+}
+
+// Can grad_value go through a scatter kernel (owner-computes or LDS atomics)?  MSDA_BWD_MODE=atomic forces the
+// one-kernel backward with global atomics (kept for A/B measurements and as the any-shape path).
+bool scatter_applicable(const Params &p)
+{
+    if (knobs().bwd_atomic) return false;
+    if (p.L > kScatterMaxLevels || (p.D % 4) != 0) return false;
+    if (1 + p.frames * p.window > kScatterMaxSources || p.Lq >= (1 << 24)) return false;   // survivor-list entry fields
+    if (p.window == 0 && p.LA != p.L) return false;
+    if ((int64_t)p.groups * p.Lq >= 0x7fffffffLL) return false;       // query rows are 32-bit in the hit records
+    return true;
+}
+
+// The owner-computes scatter (msda_bwd_value_grp_kernel) takes D = 32 with <= 4 points per level and the per-point
+// culling records (or no records at all).
+bool owner_scatter_applicable(const Params &p, int esz)
+{
+    return p.D == 32 && (esz == 4 || esz == 2) && p.PA <= 4 && p.PB <= 4 && p.Lq < (1 << 22) && knobs().scatter_own != 0 &&
+           knobs().scatter_lds_kb == 144 && scatter_applicable(p);
+}
+
+// The resident-slab kernels take D = 32 in 2- / 4-byte types when the index arithmetic fits and at least the last
+// pyramid level fits the slab.  One predicate for forward and gather pass: a forward / backward pair never splits
+// between kernel families on a shape limit.
+bool rs_fits(const Params &p, int esz)
+{
+    const int64_t pixB = (int64_t)p.v_pix * esz;
+    const int64_t pmax = p.PA > p.PB ? p.PA : p.PB;
+    return p.D == 32 && (esz == 4 || esz == 2) && p.LA == p.L && p.L <= kSlabMaxLevels &&
+           (int64_t)p.frames * p.S < (1 << 24) && pixB < (1 << 24) && (int64_t)p.frames * p.S * pixB < 0x7fffffffLL &&
+           p.frames <= kRsMaxFrames && p.window <= 31 &&
+           pmax * pmax * p.L < 65536;         // the kernels take a point's level as (k * ceil(2^16 / P)) >> 16
+}
+
+// Launches the forward, or the backward's gather pass + scatter, on the tile / resident-slab / scatter kernels.
+int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
+{
+    const int esz = elem_bytes(dtype), VEC = 16 / esz, G = p.D / VEC, RPW = kWave / G;
+    const int64_t tiles = (int64_t)p.groups * ((p.Lq + RPW - 1) / RPW);
+    const int64_t blocks = tiles * p.M;
+    if (blocks > 0x7fffffffLL) return fail(MSDA_ERR_ARG, "msda: problem too large for one launch%s");
+    const size_t lds = tile_lds_bytes(RPW, p.LA + p.LB, bwd, bwd && p.bbox != nullptr);
+    const int rs_tiles_per_clip = p.frames * ((p.Lq + kRsRows - 1) / kRsRows);
+    const int64_t clips = p.groups / p.frames;
+    const int rs_row = 32 * esz;                                  // bytes of one pixel of one head
+    const bool rs_ok = rs_fits(p, esz);
+    const int l0_host = rs_ok ? host_first_slab_level(p, (kRsSlabBytes - kRsSlack) / rs_row) : p.L;
+
+    if (!bwd) {
+        if (rs_ok) {
+            // resident-slab forward: up to NT * 16 tiles of 16 rows per workgroup, so that the per-frame slab staging is
+            // amortised; tiles per wave (NT) and workgroups per (clip, head) (parts): see rs_tiles_per_wave
+            const int mode = knobs().fwd_rs;                               // -1 auto, 0 off, 1 force
+            int nt = rs_tiles_per_wave(p, rs_tiles_per_clip, host_pixels_below(p, l0_host) * rs_row, mode == 1, 8ll << 20);
+            // the slab must hold at least the last level.  (Since the whole-row loads / stores of the points and gradients
+            // the kernel wins for every dtype as soon as ANY level fits -- 800x1333, levels 2-3 resident.)
+            if (mode != 1 && l0_host > p.L - 1) nt = 0;
+            const int force_nt = knobs().fwd_rs_nt;
+            if (force_nt == 1 || force_nt == 2 || force_nt == 4) nt = force_nt;
+            const int parts = nt ? (rs_tiles_per_clip + kRsWaves * nt - 1) / (kRsWaves * nt) : 0;
+            if (mode != 0 && nt && clips * p.M * parts <= 0x7fffffffLL)
+                return launch_fwd_rs(dtype, nt, p, parts, (unsigned)(clips * p.M * parts), stream);
+        }
+        return launch_fwd_tile(dtype, G, p, (unsigned)blocks, lds, stream);
+    }
+    if (!scatter_applicable(p)) {
+        if (hipMemsetAsync(p.grad_value, 0, (size_t)p.groups * p.S * p.M * p.D * sizeof(float), stream) != hipSuccess)
+            return fail(MSDA_ERR_HIP, "msda backward: hipMemsetAsync(grad_value) failed%s");
+        return launch_bwd_tile(dtype, G, true, p, (unsigned)blocks, lds, stream);
+    }
+    // MSDA_BWD_PHASES (measurement hook for bench.py): 1 = gather pass only, 2 = scatter pass only
+    // (needs the workspace a previous gather pass filled), 3 = both (default)
+    const int phases = knobs().bwd_phases;
+    int rc = MSDA_OK;
+    if (phases & 1) {
+        bool done = false;
+        if (rs_ok && (p.cull_points || !p.bbox)) {
+            // resident-slab gather pass: same applicability rule as the forward
+            const int mode = knobs().bwd_rs;
+            const int tpw = rs_tiles_per_wave(p, rs_tiles_per_clip, host_pixels_below(p, l0_host) * rs_row, mode == 1, 4ll << 20);
+            const int parts = tpw ? (rs_tiles_per_clip + tpw * kRsWaves - 1) / (tpw * kRsWaves) : 1;       // (L2: see the forward)
+            const bool want = mode == 1 || (mode == -1 && tpw && l0_host <= p.L - 1);
+            if (want && clips * p.M * parts <= 0x7fffffffLL) {
+                rc = launch_bwd_rs(dtype, p, parts, (unsigned)(clips * p.M * parts), stream);
+                if (rc) return rc;
+                done = true;
+            }
+        }
+        if (!done) {
+            rc = launch_bwd_tile(dtype, G, false, p, (unsigned)blocks, lds, stream);
+            if (rc) return rc;
+        }
+        if (p.cull_points && p.bsum) {       // block summaries of the per-point records just written
+            rc = launch_cull_summary(p, stream);
+            if (rc) return rc;
+        }
+    }
+    if (!(phases & 2)) return rc;
+    unsigned grid = (unsigned)device_cus();      // persistent: one 1024-thread workgroup per CU
+    grid -= grid % 8;                            // multiple of the XCD count: item % M stays put
+    if (owner_scatter_applicable(p, esz) && (p.cull_points || !p.bbox)) {
+        // owner-computes scatter: no float atomics; pixels outside its bands are zero-filled first
+        rc = launch_zero_unowned(p, kOwnPix * p.D, stream);
+        if (rc) return rc;
+        return launch_scatter_grp(dtype, p, grid, knobs().scatter_dbg & 255, stream);
+    }
+    // LDS-atomic scatter: 144 KiB of 8-byte accumulators per workgroup
+    const int cap_bytes = knobs().scatter_lds_kb * 1024;
+    rc = launch_zero_unowned(p, cap_bytes / 8, stream);
+    if (rc) return rc;
+    return launch_scatter_lds(dtype, G, p, grid, cap_bytes, knobs().scatter_dbg, stream);
+}
+
+// Shapes the 16-byte-lane kernels take: D a multiple of the lane vector with 64 / G rows per wave, aligned bases,
+// 32-bit element offsets inside a clip.
+bool fast_path_takes(int dtype, const Params &p, bool bwd)
+{
+    if (dtype == MSDA_F64) return false;
+    const int esz = elem_bytes(dtype), VEC = 16 / esz;
+    if (p.D % VEC) return false;
+    const int G = p.D / VEC;
+    if (G != 1 && G != 2 && G != 4 && G != 8 && G != 16 && G != 32 && G != 64) return false;
+    // every 16-B lane vector must be aligned: bases 16-B aligned and D a multiple of VEC
+    if (!aligned16(p.value) || (!bwd && !aligned16(p.out)) || (bwd && (!aligned16(p.grad_out) || !aligned16(p.grad_value))))
+        return false;
+    // element offsets inside one clip slab are 32-bit in the tap records
+    if ((int64_t)p.frames * p.S * p.M * p.D >= 0x7fffffffLL || (int64_t)p.frames * p.S * p.v_pix >= 0x7fffffffLL ||
+        (int64_t)p.frames * p.S * p.v_pix * (int64_t)esz >= (int64_t)kOobBytes)  // gather_load: 32-bit byte offsets < kOobBytes
+        return false;
+    if (p.v_clip % VEC || p.v_head % VEC || p.v_pix % VEC) return false;
+    // the one-kernel backward scatters grad_value (always dense) at value's offsets
+    if (bwd && !scatter_applicable(p) && !standard_value_layout(p)) return false;
+    if (tile_lds_bytes(kWave / G, p.LA + p.LB, bwd) > 60 * 1024) return false;
+    return true;
+}
+
+int run(int dtype, const Params &p_in, bool bwd, hipStream_t stream)
+{
+    if (dtype < MSDA_F32 || dtype > MSDA_F16) return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
+    Params p = p_in;
+    p.dbg = knobs().dbg;
+    // culling records per point (4 x int16) when the owner-computes scatter will read them; (min, max) intervals for the
+    // LDS-atomic scatter (MSDA_BWD_CULL=2 forces them)
+    p.cull_points = bwd && p.bbox && knobs().bwd_cull != 2 && owner_scatter_applicable(p, elem_bytes(dtype));
+    if (!p.cull_points) p.bsum = nullptr;
+    p.wide_stores = bwd && aligned16(p.glocA) && aligned16(p.gawA) && (p.LB == 0 || (aligned16(p.glocB) && aligned16(p.gawB))) &&
+                    (knobs().dbg & 64) == 0;                  // (measurement: MSDA_DBG=64 keeps the narrow stores)
+    p.wide_loads = aligned16(p.locA) && aligned16(p.awA) && (p.LB == 0 || (aligned16(p.locB) && aligned16(p.awB))) &&
+                   (knobs().dbg & 128) == 0;                  // (measurement: MSDA_DBG=128 keeps the narrow loads)
+    if (p.groups == 0 || p.Lq == 0) return MSDA_OK;
+    if (!knobs().force_generic && fast_path_takes(dtype, p, bwd)) return launch_fast(dtype, p, bwd, stream);
+    return launch_generic(dtype, p, bwd, stream);
+}
+
+int check_common(const void *value, const int64_t *shapes, const int64_t *lsi, int groups, int S,
+                 int M, int D, int L, int Lq)
+{
+    if (!value || !shapes || !lsi) return fail(MSDA_ERR_ARG, "msda: null pointer argument%s");
+    if (groups < 0 || Lq < 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0)
+        return fail(MSDA_ERR_ARG, "msda: sizes must be positive%s");
+    return MSDA_OK;
+}
+
+// `value_strides` (host pointer, may be null): element strides {between clips, between heads, between pixels}
+// of `value`; null = the standard dense [groups, S, M, D].
+int set_value_strides(Params &p, const int64_t *vs)
+{
+    p.v_clip = (int64_t)p.frames * p.S * p.M * p.D; p.v_head = p.D; p.v_pix = p.M * p.D;
+    if (!vs) return MSDA_OK;
+    if (vs[0] < 0 || vs[1] < 0 || vs[2] <= 0 || vs[2] > 0x7fffffffLL)
+        return fail(MSDA_ERR_ARG, "msda: bad value_strides%s");
+    p.v_clip = vs[0]; p.v_head = vs[1]; p.v_pix = (int)vs[2];
+    return MSDA_OK;
+}
+
+int zero_grad_value(int dtype, void *grad_value, int groups, int S, int M, int D, void *stream)
+{
+    if (dtype < MSDA_F32 || dtype > MSDA_F16) return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
+    if (!grad_value) return fail(MSDA_ERR_ARG, "msda backward: null grad_value%s");
+    const size_t bytes = (size_t)groups * S * M * D * (dtype == MSDA_F64 ? sizeof(double) : sizeof(float));
+    if (hipMemsetAsync(grad_value, 0, bytes, static_cast<hipStream_t>(stream)) != hipSuccess)
+        return fail(MSDA_ERR_HIP, "msda backward: hipMemsetAsync(grad_value) failed%s");
+    return MSDA_OK;
+}
+
+long long workspace_table_bytes(int batch, int num_query, int num_heads, int virtual_levels)
+{
+    return (long long)batch * num_query * num_heads * virtual_levels * 8;
+}
+
+// ticket counters + per-point culling records + their 64-query block summaries
+long long workspace_need(int batch, int num_query, int num_heads, int virtual_levels)
+{
+    const long long nblk = (num_query + kCullBlock - 1) / kCullBlock;
+    return MSDA_BWD_WORKSPACE_BYTES + workspace_table_bytes(batch, num_query, num_heads, virtual_levels) +
+           (long long)batch * num_heads * virtual_levels * nblk * 8;
+}
+
+void attach_workspace(Params &p, void *workspace, long long bytes, int batch, int num_query, int num_heads, int vl)
+{
+    p.workspace = (workspace && bytes >= MSDA_BWD_WORKSPACE_BYTES) ? static_cast<unsigned *>(workspace) : nullptr;
+    p.bbox = nullptr;
+    p.bsum = nullptr;
+    if (p.workspace && bytes >= workspace_need(batch, num_query, num_heads, vl) && knobs().bwd_cull != 0) {
+        p.bbox = reinterpret_cast<int *>(p.workspace) + MSDA_BWD_WORKSPACE_BYTES / 4;
+        // block summaries only pay for long candidate ranges (and index (group, head, level) rows with 32 bits)
+        if (num_query >= 2048 && (long long)batch * num_heads * vl < 0x7fffffffLL && knobs().bwd_summary != 0)
+            p.bsum = p.bbox + workspace_table_bytes(batch, num_query, num_heads, vl) / 4;
+    }
+}
+
+int run_prep(int dtype, const PrepParams &p, bool bwd, void *stream)
+{
+    if (p.rows < 0 || p.M <= 0 || p.L <= 0 || p.W < 0 || p.Pc <= 0 || (p.W > 0 && p.Pt <= 0) || (p.d != 2 && p.d != 4))
+        return fail(MSDA_ERR_ARG, "msda prep: bad sizes (rows, heads, levels, window, points, reference dim)%s");
+    if (!p.shapes || !p.ref_c || (p.W > 0 && !p.ref_t)) return fail(MSDA_ERR_ARG, "msda prep: null pointer argument%s");
+    if (p.rows == 0) return MSDA_OK;
+    return launch_prep(dtype, p, bwd, static_cast<hipStream_t>(stream));
+}
+
+}  // namespace
+}  // namespace msda
+
+using namespace msda;
+
+extern "C" {
+
+int msda_version(void) { return MSDA_ABI_VERSION; }
+
+void msda_reload_knobs(void) { load_knobs(); }
+
+const char *msda_last_route(void) { return g_route; }
+
+long long msda_backward_workspace_bytes(int batch, int num_query, int num_heads, int virtual_levels)
+{
+    return workspace_need(batch, num_query, num_heads, virtual_levels);
+}
+
+const char *msda_last_error(void) { return g_err; }
+
+int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,
+                 const int64_t *level_start_index, const void *sampling_loc, const void *attn_weight,
+                 int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                 int num_query, int num_point, void *out, const int64_t *value_strides,
+                 const int64_t *spatial_shapes_host, void *stream)
+{
+    g_err[0] = 0; g_route[0] = 0;
+    int rc = check_common(value, spatial_shapes, level_start_index, batch, spatial_size, num_heads,
+                          channels, num_levels, num_query);
+    if (rc) return rc;
+    if (batch == 0 || num_query == 0) return MSDA_OK;
+    if (!sampling_loc || !attn_weight || !out || num_point <= 0)
+        return fail(MSDA_ERR_ARG, "msda_forward: null pointer or non-positive num_point%s");
+    Params p;
+    memset(&p, 0, sizeof(p));
+    p.value = value; p.shapes = spatial_shapes; p.lsi = level_start_index;
+    p.locA = sampling_loc; p.awA = attn_weight; p.out = out;
+    p.groups = batch; p.frames = 1; p.window = 0;
+    p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
+    p.LA = num_levels; p.PA = num_point; p.LB = 0; p.PB = 1;
+    p.shapes_host = spatial_shapes_host;
+    rc = set_value_strides(p, value_strides);
+    if (rc) return rc;
+    return run(dtype, p, false, static_cast<hipStream_t>(stream));
+}
+
+int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
+                  const int64_t *level_start_index, const void *sampling_loc,
+                  const void *attn_weight, const void *grad_out,
+                  int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                  int num_query, int num_point,
+                  void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
+                  void *workspace, long long workspace_bytes, const int64_t *value_strides,
+                  const int64_t *spatial_shapes_host, void *stream)
+{
+    g_err[0] = 0; g_route[0] = 0;
+    int rc = check_common(value, spatial_shapes, level_start_index, batch, spatial_size, num_heads,
+                          channels, num_levels, num_query);
+    if (rc) return rc;
+    if (batch == 0) return MSDA_OK;
+    if (num_query == 0) return zero_grad_value(dtype, grad_value, batch, spatial_size, num_heads, channels, stream);
+    if (!sampling_loc || !attn_weight || !grad_out || !grad_value || !grad_sampling_loc ||
+        !grad_attn_weight || num_point <= 0)
+        return fail(MSDA_ERR_ARG, "msda_backward: null pointer or non-positive num_point%s");
+    Params p;
+    memset(&p, 0, sizeof(p));
+    p.value = value; p.shapes = spatial_shapes; p.lsi = level_start_index;
+    p.locA = sampling_loc; p.awA = attn_weight; p.grad_out = grad_out;
+    p.grad_value = grad_value; p.glocA = grad_sampling_loc; p.gawA = grad_attn_weight;
+    attach_workspace(p, workspace, workspace_bytes, batch, num_query, num_heads, num_levels);
+    p.groups = batch; p.frames = 1; p.window = 0;
+    p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
+    p.LA = num_levels; p.PA = num_point; p.LB = 0; p.PB = 1;
+    p.shapes_host = spatial_shapes_host;
+    rc = set_value_strides(p, value_strides);
+    if (rc) return rc;
+    return run(dtype, p, true, static_cast<hipStream_t>(stream));
+}
+
+int msda_temporal_forward(int dtype, const void *value, const int64_t *spatial_shapes,
+                          const int64_t *level_start_index, const int32_t *frame_table,
+                          const void *loc_curr, const void *aw_curr,
+                          const void *loc_temp, const void *aw_temp,
+                          int clips, int frames, int window, int spatial_size, int num_heads,
+                          int channels, int num_levels, int num_query,
+                          int num_curr_point, int num_temp_point, void *out, const int64_t *value_strides,
+                          const int64_t *spatial_shapes_host, void *stream)
+{
+    g_err[0] = 0; g_route[0] = 0;
+    int rc = check_common(value, spatial_shapes, level_start_index, clips, spatial_size, num_heads,
+                          channels, num_levels, num_query);
+    if (rc) return rc;
+    if (frames <= 0 || window < 0 || num_curr_point <= 0 || (window > 0 && num_temp_point <= 0))
+        return fail(MSDA_ERR_ARG, "msda_temporal_forward: bad frames/window/points%s");
+    if (clips == 0 || num_query == 0) return MSDA_OK;
+    if (!loc_curr || !aw_curr || !out || (window > 0 && (!frame_table || !loc_temp || !aw_temp)))
+        return fail(MSDA_ERR_ARG, "msda_temporal_forward: null pointer argument%s");
+    Params p;
+    memset(&p, 0, sizeof(p));
+    p.value = value; p.shapes = spatial_shapes; p.lsi = level_start_index; p.ftab = frame_table;
+    p.locA = loc_curr; p.awA = aw_curr; p.locB = loc_temp; p.awB = aw_temp; p.out = out;
+    p.groups = clips * frames; p.frames = frames; p.window = window;
+    p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
+    p.LA = num_levels; p.PA = num_curr_point;
+    p.LB = window * num_levels; p.PB = window > 0 ? num_temp_point : 1;
+    p.shapes_host = spatial_shapes_host;
+    rc = set_value_strides(p, value_strides);
+    if (rc) return rc;
+    return run(dtype, p, false, static_cast<hipStream_t>(stream));
+}
+
+int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_shapes,
+                           const int64_t *level_start_index, const int32_t *frame_table,
+                           const void *loc_curr, const void *aw_curr,
+                           const void *loc_temp, const void *aw_temp, const void *grad_out,
+                           int clips, int frames, int window, int spatial_size, int num_heads,
+                           int channels, int num_levels, int num_query,
+                           int num_curr_point, int num_temp_point,
+                           void *grad_value, void *grad_loc_curr, void *grad_aw_curr,
+                           void *grad_loc_temp, void *grad_aw_temp, void *workspace, long long workspace_bytes,
+                           const int64_t *value_strides, const int64_t *spatial_shapes_host, void *stream)
+{
+    g_err[0] = 0; g_route[0] = 0;
+    int rc = check_common(value, spatial_shapes, level_start_index, clips, spatial_size, num_heads,
+                          channels, num_levels, num_query);
+    if (rc) return rc;
+    if (frames <= 0 || window < 0 || num_curr_point <= 0 || (window > 0 && num_temp_point <= 0))
+        return fail(MSDA_ERR_ARG, "msda_temporal_backward: bad frames/window/points%s");
+    if (clips == 0) return MSDA_OK;
+    if (num_query == 0)
+        return zero_grad_value(dtype, grad_value, clips * frames, spatial_size, num_heads, channels, stream);
+    if (!loc_curr || !aw_curr || !grad_out || !grad_value || !grad_loc_curr || !grad_aw_curr ||
+        (window > 0 && (!frame_table || !loc_temp || !aw_temp || !grad_loc_temp || !grad_aw_temp)))
+        return fail(MSDA_ERR_ARG, "msda_temporal_backward: null pointer argument%s");
+    Params p;
+    memset(&p, 0, sizeof(p));
+    p.value = value; p.shapes = spatial_shapes; p.lsi = level_start_index; p.ftab = frame_table;
+    p.locA = loc_curr; p.awA = aw_curr; p.locB = loc_temp; p.awB = aw_temp; p.grad_out = grad_out;
+    p.grad_value = grad_value; p.glocA = grad_loc_curr; p.gawA = grad_aw_curr;
+    p.glocB = grad_loc_temp; p.gawB = grad_aw_temp;
+    attach_workspace(p, workspace, workspace_bytes, clips * frames, num_query, num_heads, num_levels * (1 + window));
+    p.groups = clips * frames; p.frames = frames; p.window = window;
+    p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
+    p.LA = num_levels; p.PA = num_curr_point;
+    p.LB = window * num_levels; p.PB = window > 0 ? num_temp_point : 1;
+    p.shapes_host = spatial_shapes_host;
+    rc = set_value_strides(p, value_strides);
+    if (rc) return rc;
+    return run(dtype, p, true, static_cast<hipStream_t>(stream));
+}
+
+int msda_prep_forward(int dtype, const void *offsets_curr, const void *offsets_temp, const void *logits_curr,
+                      const void *logits_temp, const void *ref_curr, const void *ref_temp,
+                      const int64_t *spatial_shapes, long long rows, int num_heads, int num_levels, int window,
+                      int num_curr_point, int num_temp_point, int ref_dim, long long raw_row_stride,
+                      void *loc_curr, void *loc_temp, void *aw_curr, void *aw_temp, void *stream)
+{
+    g_err[0] = 0; g_route[0] = 0;
+    PrepParams p;
+    memset(&p, 0, sizeof(p));
+    p.off_c = offsets_curr; p.off_t = offsets_temp; p.logit_c = logits_curr; p.logit_t = logits_temp;
+    p.ref_c = ref_curr; p.ref_t = ref_temp; p.shapes = spatial_shapes;
+    p.loc_c = loc_curr; p.loc_t = loc_temp; p.aw_c = aw_curr; p.aw_t = aw_temp;
+    p.rows = rows; p.M = num_heads; p.L = num_levels; p.W = window; p.Pc = num_curr_point;
+    p.Pt = window > 0 ? num_temp_point : 1; p.d = ref_dim; p.ld = raw_row_stride;
+    if (rows > 0 && (!offsets_curr || !logits_curr || !loc_curr || !aw_curr ||
+                     (window > 0 && (!offsets_temp || !logits_temp || !loc_temp || !aw_temp))))
+        return fail(MSDA_ERR_ARG, "msda_prep_forward: null pointer argument%s");
+    return run_prep(dtype, p, false, stream);
+}
+
+int msda_prep_backward(int dtype, const void *grad_loc_curr, const void *grad_loc_temp, const void *grad_aw_curr,
+                       const void *grad_aw_temp, const void *aw_curr, const void *aw_temp, const void *ref_curr,
+                       const void *ref_temp, const int64_t *spatial_shapes, long long rows, int num_heads,
+                       int num_levels, int window, int num_curr_point, int num_temp_point, int ref_dim,
+                       long long raw_row_stride, void *grad_offsets_curr, void *grad_offsets_temp,
+                       void *grad_logits_curr, void *grad_logits_temp, void *stream)
+{
+    g_err[0] = 0; g_route[0] = 0;
+    PrepParams p;
+    memset(&p, 0, sizeof(p));
+    p.gloc_c = grad_loc_curr; p.gloc_t = grad_loc_temp; p.gaw_c = grad_aw_curr; p.gaw_t = grad_aw_temp;
+    p.aw_c = const_cast<void *>(aw_curr); p.aw_t = const_cast<void *>(aw_temp);
+    p.ref_c = ref_curr; p.ref_t = ref_temp; p.shapes = spatial_shapes;
+    p.goff_c = grad_offsets_curr; p.goff_t = grad_offsets_temp; p.glogit_c = grad_logits_curr; p.glogit_t = grad_logits_temp;
+    p.rows = rows; p.M = num_heads; p.L = num_levels; p.W = window; p.Pc = num_curr_point;
+    p.Pt = window > 0 ? num_temp_point : 1; p.d = ref_dim; p.ld = raw_row_stride;
+    if (rows > 0 && (!grad_loc_curr || !grad_aw_curr || !aw_curr || !grad_offsets_curr || !grad_logits_curr ||
+                     (window > 0 && (!grad_loc_temp || !grad_aw_temp || !aw_temp || !grad_offsets_temp || !grad_logits_temp))))
+        return fail(MSDA_ERR_ARG, "msda_prep_backward: null pointer argument%s");
+    return run_prep(dtype, p, true, stream);
+}
+
+int msda_mask_rows(int dtype, void *rows, const void *padding_mask, long long pixels, long long row_elems,
+                   long long row_stride, void *stream)
+{
+    g_err[0] = 0; g_route[0] = 0;
+    const int e = dtype == MSDA_F32 ? 4 : dtype == MSDA_F64 ? 8 : (dtype == MSDA_BF16 || dtype == MSDA_F16) ? 2 : 0;
+    if (!e) return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
+    if (pixels < 0 || row_elems <= 0 || row_stride < row_elems)
+        return fail(MSDA_ERR_ARG, "msda_mask_rows: bad sizes (pixels, row elements, row stride)%s");
+    if (pixels == 0) return MSDA_OK;
+    if (!rows || !padding_mask) return fail(MSDA_ERR_ARG, "msda_mask_rows: null pointer argument%s");
+    const long long rb = row_elems * e, sb = row_stride * e;
+    const int g = (rb % 16 == 0 && sb % 16 == 0 && (reinterpret_cast<uintptr_t>(rows) & 15) == 0) ? 16 : e;
+    const long long chunks = rb / g, threads = pixels * chunks;
+    if (chunks > 0x7fffffffLL || (threads + 255) / 256 > 0x7fffffffLL)
+        return fail(MSDA_ERR_ARG, "msda_mask_rows: tensor too large for one launch%s");
+    return launch_mask_rows(g, static_cast<char *>(rows), static_cast<const uint8_t *>(padding_mask), pixels, (int)chunks, sb,
+                            (unsigned)((threads + 255) / 256), static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,18 +1,27 @@
 #!/bin/bash
-# Same-box A/B of two builds of the library (boxes differ by +-5 %, so numbers from different gpurun calls do not compare):
-# devis_amd/libmsda_hip.so (built from the committed source, hash file current -> no rebuild on the box) against
-# devis_amd/libmsda_exp.so (built by hand from the experimental source:  hipcc ... -o devis_amd/libmsda_exp.so), two
-# rounds each.  usage: gpurun -- bash scripts/ab_bench.sh [bench.py args]
-cd ${GRAFT_REPO_ROOT:-/root/repo}
+# Same-box A/B of several builds of the library (boxes differ by +-5 %, so numbers from different gpurun calls do not
+# compare).  Builds are selected with MSDA_LIB (devis_amd/build.py: the in-tree library is never overwritten):
+#   python -m devis_amd.build -DMSDA_SOMETHING=1 --out=devis_amd/libmsda_exp_x.so        (in the build container)
+#   gpurun -- bash scripts/ab_bench.sh devis_amd/libmsda_hip.so devis_amd/libmsda_exp_x.so [-- bench.py args]
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
+libs=(); args=()
+while [ $# -gt 0 ]; do
+  if [ "$1" = "--" ]; then shift; args=("$@"); break; fi
+  [ -f "$1" ] || { echo "no such library: $1" >&2; exit 1; }
+  libs+=("$1"); shift
+done
 for rep in 1 2; do
-  python3 bench.py --no-other-configs --no-cpu-baseline "$@" > gpurun_out/ab_base.json 2>/dev/null
-  cp devis_amd/libmsda_hip.so /tmp/keep.so; cp devis_amd/libmsda_exp.so devis_amd/libmsda_hip.so
-  python3 bench.py --no-other-configs --no-cpu-baseline "$@" > gpurun_out/ab_exp.json 2>/dev/null
-  cp /tmp/keep.so devis_amd/libmsda_hip.so
-  python3 -c "
-import json
-for f in ('ab_base','ab_exp'):
-    d=json.loads(open('gpurun_out/%s.json'%f).read().strip().splitlines()[-1])
-    print(f, d['value'], {k[:18]:v['avg_ms'] for k,v in d['kernels'].items()})"
+  for lib in "${libs[@]}"; do
+    tag=$(basename "$lib" .so)
+    MSDA_LIB="$PWD/$lib" python3 bench.py --no-other-configs --no-cpu-baseline --steps 40 "${args[@]}" > "gpurun_out/ab_$tag.json" 2> "gpurun_out/ab_$tag.err" \
+      || { echo "$tag: bench failed"; tail -3 "gpurun_out/ab_$tag.err"; continue; }
+    python3 - "$tag" <<'PY'
+import json, sys
+tag = sys.argv[1]
+d = json.loads(open('gpurun_out/ab_%s.json' % tag).read().strip().splitlines()[-1])
+print("%-28s %7.3f M-q/s  " % (tag, d['value']) + "  ".join("%s %.4f" % (k.split(' ')[0].replace('msda_', '')[:14], v['avg_ms']) for k, v in d['kernels'].items()), flush=True)
+PY
+  done
 done

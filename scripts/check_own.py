@@ -38,7 +38,7 @@ def run(clips, env, pyr="A", locs="uniform", queries=300, reps=10):
 if __name__ == "__main__":
     for clips, locs, pyr, q in ((16, "uniform", "A", 300), (1, "local", "A", 4820), (1, "local", "B", 22223), (1, "uniform", "B", 22223)):
         base = None
-        for name, env in (("lds-atomic", {"MSDA_SCATTER_OWN": "0"}), ("own", {"MSDA_SCATTER_DBG": "0"}), ("own, point-granular", {"MSDA_SCATTER_OWN": "2"})):
+        for name, env in (("lds-atomic", {"MSDA_SCATTER_OWN": "0"}), ("own", {"MSDA_SCATTER_DBG": "0"})):
             ms, gv = run(clips, env, locs=locs, pyr=pyr, queries=q)
             if base is None: base = gv
             print("clips %2d %-9s pyr %s q %5d %-18s scatter %.4f ms   max|diff vs lds-atomic| %.3e (scale %.3f)" % (clips, locs, pyr, q, name, ms, (gv - base).abs().max().item(), base.abs().max().item()), flush=True)

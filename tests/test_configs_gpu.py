@@ -273,16 +273,15 @@ RS_CASES = [
 ]
 
 
-@pytest.mark.parametrize("scatter", ["1", "2"], ids=["group-granular", "point-granular"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2), (torch.float16, 2e-3)], ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("case", range(len(RS_CASES)))
-def test_round2_kernels_forced_on_odd_shapes(case, dtype, tol, scatter, monkeypatch):
+def test_round2_kernels_forced_on_odd_shapes(case, dtype, tol, monkeypatch):
     """The resident-slab forward / gather pass and the owner-computes scatter, FORCED onto shapes they would not pick by
     themselves (few rows, 1-3 points per level, 1-4 levels, mirrored / partial frame tables, 2 clips), against the fp64
     oracle in the reference's call pattern on the same rounded inputs; msda_last_route confirms the kernels ran."""
     from devis_amd import _native
     T, W, ftab, Lq, shapes, Pc, Pt = RS_CASES[case]
-    monkeypatch.setenv("MSDA_FWD_RS", "1"); monkeypatch.setenv("MSDA_BWD_RS", "1"); monkeypatch.setenv("MSDA_SCATTER_OWN", scatter)
+    monkeypatch.setenv("MSDA_FWD_RS", "1"); monkeypatch.setenv("MSDA_BWD_RS", "1")
     clips = 2
     ft = None if ftab is None else np.array(ftab, dtype=np.int32)
     ds = [round_to(make_temporal_inputs(500 + 10 * case + c, T, W, 8, 32, Lq, shapes, Pc, Pt, ftab=ft), dtype) for c in range(clips)]
@@ -291,7 +290,6 @@ def test_round2_kernels_forced_on_odd_shapes(case, dtype, tol, scatter, monkeypa
     got = _run_temporal(cat, dtype, clips, routes)
     route = _native.last_route() + " | " + " | ".join(routes)
     assert "forward (resident-slab" in route and "resident-slab kernel, grad_loc" in route and "owner-computes" in route, route
-    assert ("group-granular" in route) == (scatter == "1"), route
     for c, d in enumerate(ds):
         args = [np.asarray(d[k], dtype=np.float64) if d[k].dtype.kind == "f" else d[k]
                 for k in ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")]
@@ -345,10 +343,9 @@ def test_plain_module_mask_is_applied_by_mask_rows_both_ways(pad, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["f32", "f16"])
-@pytest.mark.parametrize("env", [{}, {"MSDA_FWD_SLAB": "1", "MSDA_BWD_SLAB": "1", "MSDA_FWD_RS": "0", "MSDA_BWD_RS": "0"},
-                                 {"MSDA_FWD_RS": "1", "MSDA_BWD_RS": "1"}, {"MSDA_FWD_RS": "0", "MSDA_FWD_SLAB": "0", "MSDA_BWD_RS": "0", "MSDA_BWD_SLAB": "0"},
-                                 {"MSDA_FORCE_GENERIC": "1"}, {"MSDA_SCATTER_OWN": "0"}],
-                         ids=["default", "slab", "resident-slab", "tile", "generic", "lds-scatter"])
+@pytest.mark.parametrize("env", [{}, {"MSDA_FWD_RS": "1", "MSDA_BWD_RS": "1"}, {"MSDA_FWD_RS": "0", "MSDA_BWD_RS": "0"},
+                                 {"MSDA_FORCE_GENERIC": "1"}, {"MSDA_SCATTER_OWN": "0"}, {"MSDA_BWD_MODE": "atomic"}],
+                         ids=["default", "resident-slab", "tile", "generic", "lds-scatter", "atomic"])
 def test_non_finite_pixels_nobody_samples_do_not_leak(env, dtype, monkeypatch):
     """The reference never reads a corner outside the map (cuh:56-80, 265-288), so an inf / NaN in a pixel no point
     samples cannot reach any output.  Kernels that fetch a placeholder for such corners must fetch zeros, not

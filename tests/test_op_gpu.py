@@ -80,9 +80,9 @@ def test_generic_kernels_fp32(name, monkeypatch):
 @pytest.mark.parametrize("D", [32, 64, 8])
 def test_reduced_precision_vs_fp64_oracle_on_rounded_inputs(dtype, tol_out, tol_rel, D, slab, monkeypatch):
     """bf16/f16 storage, fp32 arithmetic.  The oracle runs in fp64 on the SAME rounded inputs.
-    `forced`: the slab kernels (4 channels = 8 bytes per lane for the 16-bit types)."""
+    `forced`: the resident-slab kernels where they apply (D = 32), which this small shape would not pick."""
     if slab == "forced":
-        monkeypatch.setenv("MSDA_FWD_SLAB", "1"); monkeypatch.setenv("MSDA_BWD_SLAB", "1")
+        monkeypatch.setenv("MSDA_FWD_RS", "1"); monkeypatch.setenv("MSDA_BWD_RS", "1")
     d = make_inputs(7, 2, 8, D, 33, [(12, 20), (6, 10), (3, 5), (2, 3)], 4, "wide", np.float64, value_scale=1.0)
     d = round_to(d, dtype)
     ref = oracle_fwd_bwd(d, np.float64)
@@ -258,7 +258,6 @@ def test_full_size_properties_cfg3():
 @pytest.mark.parametrize("env", [{"MSDA_BWD_MODE": "atomic"},            # one-kernel backward, global float atomics
                                  {"MSDA_SCATTER_LDS_KB": "1"},           # no level row fits LDS -> "direct" branch
                                  {"MSDA_SCATTER_LDS_KB": "8"},           # many thin bands, straddling points
-                                 {"MSDA_SCATTER_WG_PER_CU": "3"},
                                  {"MSDA_SCATTER_DBG": "16"},             # static item order: the software pipeline
                                  {"MSDA_SCATTER_DBG": "16", "MSDA_SCATTER_LDS_KB": "8"},
                                  {"MSDA_BWD_CULL": "2"},                 # interval culling records (legacy scatter)
@@ -266,10 +265,8 @@ def test_full_size_properties_cfg3():
                                  {"MSDA_BWD_CULL": "0"},                 # no culling table at all
                                  {"MSDA_SCATTER_OWN": "0"},             # LDS-atomic scatter instead of owner-computes
                                  {"MSDA_SCATTER_OWN": "0", "MSDA_SCATTER_DBG": "16"},
-                                 {"MSDA_SCATTER_DBG": "16"},            # (group-granular) owner-computes scatter, static item order
-                                 {"MSDA_SCATTER_OWN": "2"},          # point-granular owner-computes scatter
-                                 {"MSDA_SCATTER_OWN": "2", "MSDA_SCATTER_DBG": "16"},          # ... static item order
-                                 {"MSDA_SCATTER_OWN": "2", "MSDA_SCATTER_DBG": "256"}])         # ... without the cross-chunk prefetch
+                                 {"MSDA_FWD_RS": "1", "MSDA_BWD_RS": "1"},                       # resident-slab gather pass on a tiny shape
+                                 {"MSDA_FWD_RS": "1", "MSDA_BWD_RS": "1", "MSDA_SCATTER_DBG": "16"}])
 def test_backward_alternate_routes(env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -400,10 +397,10 @@ def test_full_size_temporal_encoder_800x1333():
     assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
 
 
-def test_forward_slab_kernel_forced(monkeypatch):
-    """MSDA_FWD_SLAB=1 forces the 16-wave slab forward (small levels served from a workgroup-shared LDS
-    slab) on shapes the host heuristic would leave to the tile kernel."""
-    monkeypatch.setenv("MSDA_FWD_SLAB", "1")
+def test_forward_resident_slab_kernel_forced(monkeypatch):
+    """MSDA_FWD_RS=1 forces the resident-slab forward (levels 1.. of a source frame in a workgroup-shared LDS slab) on
+    shapes the host heuristic would leave to the tile kernel (fixtures with D != 32 stay there)."""
+    monkeypatch.setenv("MSDA_FWD_RS", "1")
     for name in ("op_devis_small", "op_batched_im2col", "op_out_of_range", "op_many_levels", "op_cfg1", "op_generic_D64"):
         g, d = _golden_dict(name)
         out, gv, gl, ga = _run_op(d, torch.float32)
@@ -418,9 +415,9 @@ def test_forward_slab_kernel_forced(monkeypatch):
 
 
 
-def test_backward_slab_kernel_forced(monkeypatch):
-    """MSDA_BWD_SLAB=1 forces the slab variant of the backward gather pass on small shapes."""
-    monkeypatch.setenv("MSDA_BWD_SLAB", "1")
+def test_backward_resident_slab_kernel_forced(monkeypatch):
+    """MSDA_BWD_RS=1 forces the resident-slab gather pass on small shapes."""
+    monkeypatch.setenv("MSDA_BWD_RS", "1")
     for name in ("op_devis_small", "op_batched_im2col", "op_out_of_range", "op_many_levels", "op_cfg1"):
         g, d = _golden_dict(name)
         out, gv, gl, ga = _run_op(d, torch.float32)
@@ -437,19 +434,21 @@ def test_backward_slab_kernel_forced(monkeypatch):
             assert _maxabs(a, b) <= 2e-5 * max(1.0, np.abs(b).max())
 
 
-@pytest.mark.parametrize("route", ["points", "intervals", "atomic", "generic", "direct_levels", "no_workspace"])
+@pytest.mark.parametrize("route", ["points", "intervals", "lds_atomics", "atomic", "generic", "direct_levels", "no_workspace"])
 def test_grad_value_is_overwritten(route, monkeypatch):
     """ABI v4: grad_value need not be zeroed -- every backward route overwrites (or zero-fills) all of it,
     including pixel rows of `value` that belong to no level (spatial_shapes not tiling [0, S))."""
     from devis_amd import _native
     if route == "intervals":
         monkeypatch.setenv("MSDA_BWD_CULL", "2")
+    if route == "lds_atomics":
+        monkeypatch.setenv("MSDA_SCATTER_OWN", "0")
     if route == "atomic":
         monkeypatch.setenv("MSDA_BWD_MODE", "atomic")
     if route == "generic":
         monkeypatch.setenv("MSDA_FORCE_GENERIC", "1")
     if route == "direct_levels":
-        monkeypatch.setenv("MSDA_SCATTER_LDS_KB", "2")          # no level row fits: float-atomic branch
+        monkeypatch.setenv("MSDA_SCATTER_LDS_KB", "2")          # LDS-atomic scatter, no level row fits: float-atomic branch
     rng = np.random.default_rng(5)
     shapes = [(9, 7), (5, 4), (3, 2)]
     d = make_inputs(5, 3, 8, 32, 41, shapes, 4)
@@ -485,9 +484,9 @@ def test_head_major_value_layout(route, monkeypatch):
     from devis_amd import _native
     from devis_amd.functions import MSDeformAttnFunction
     if route == "tile":
-        monkeypatch.setenv("MSDA_FWD_SLAB", "0"); monkeypatch.setenv("MSDA_BWD_SLAB", "0")
+        monkeypatch.setenv("MSDA_FWD_RS", "0"); monkeypatch.setenv("MSDA_BWD_RS", "0")
     if route == "default":
-        monkeypatch.setenv("MSDA_FWD_SLAB", "1"); monkeypatch.setenv("MSDA_BWD_SLAB", "1")
+        monkeypatch.setenv("MSDA_FWD_RS", "1"); monkeypatch.setenv("MSDA_BWD_RS", "1")
     if route == "atomic":
         monkeypatch.setenv("MSDA_BWD_MODE", "atomic")
     if route == "generic":
