@@ -44,7 +44,7 @@ size_t tile_lds_bytes(int rpw, int nvl, bool bwd, bool intervals = false)
 // msda_reload_knobs() after changing a knob.
 struct Knobs {
     int fwd_rs = -1, fwd_rs_nt = 0;     // resident-slab forward: -1 auto, 0 off, 1 force; tiles per wave (0 = auto)
-    int bwd_rs = -1;                    // resident-slab gather pass: -1 auto, 0 off, 1 force
+    int bwd_rs = -1, bwd_rs_tpw = 0;    // resident-slab gather pass: -1 auto, 0 off, 1 force; tiles per wave (0 = auto)
     int bwd_atomic = 0;                 // MSDA_BWD_MODE=atomic: one-kernel backward with global atomics
     int bwd_phases = 3;                 // 1 = gather pass only, 2 = scatter pass only, 3 = both
     int bwd_cull = 1;                   // 0: no culling structure, 2: (min, max) intervals instead of per-point records
@@ -68,7 +68,7 @@ void load_knobs()
     Knobs k;
     if (env_int("MSDA_ENABLE_HOOKS", 0) == 1) {
         k.fwd_rs = env_int("MSDA_FWD_RS", k.fwd_rs); k.fwd_rs_nt = env_int("MSDA_FWD_RS_NT", k.fwd_rs_nt);
-        k.bwd_rs = env_int("MSDA_BWD_RS", k.bwd_rs);
+        k.bwd_rs = env_int("MSDA_BWD_RS", k.bwd_rs); k.bwd_rs_tpw = env_int("MSDA_BWD_RS_TPW", k.bwd_rs_tpw);
         const char *mode = getenv("MSDA_BWD_MODE");
         k.bwd_atomic = (mode && !strcmp(mode, "atomic")) ? 1 : 0;
         k.bwd_phases = env_int("MSDA_BWD_PHASES", k.bwd_phases);
@@ -159,13 +159,13 @@ long long host_pixels_below(const Params &p, int l0)
 }
 
 // Tiles per wave of the resident-slab kernels = how many workgroups share one (clip, head).  Every workgroup of a
-// pair gathers the non-resident levels from the same maps, and what an XCD's 4 MiB L2 keeps of them decides the
-// kernels' speed: take the LARGEST workgroups (least slab staging) whose pairs in flight per
-// XCD still fit `l2_budget`, else the smallest.  Measured on the round-2 kernels, 16 / 32 clips of the DeVIS decoder
-// shape, 4 / 2 / 1 tiles per wave: forward fp32 (460 KiB per map) 0.440 / 0.441 / 0.473 and 0.754 / 0.800 / 0.915 ms,
-// bf16 (230 KiB) 0.343 / 0.372 / 0.395 ms; gather pass fp32 4 vs 2 tiles: 0.547 vs 0.524 ms.  Hence 8 MiB for the
-// forward (4 tiles per wave for fp32 too: equal at 16 clips, -6 % at 32) and 4 MiB for the gather pass, whose extra
-// streams (grad_out rows, 309 MB of results) compete for the same L2.
+// pair gathers the non-resident levels from the same maps, and both kernels are bound by how fast a CU's vector-memory
+// path returns those scattered lines, i.e. by what an XCD's 4 MiB L2 keeps of the maps: take the
+// LARGEST workgroups (least slab staging) whose pairs in flight per XCD keep the non-resident levels within
+// `l2_budget`, else the smallest.  Measured on the round-3 kernels, 16 clips of the DeVIS decoder shape (same box),
+// 1 / 2 / 4 tiles per wave: fp32 (460 KiB per level-0 map) forward 0.337 / 0.364 / -- ms, gather pass 0.423 / 0.471 /
+// 0.560; bf16 (230 KiB, two heads per 128-byte line) forward -- / 0.246 / 0.238, gather pass 0.363 / 0.326 / 0.312.
+// Hence a budget of 2 MiB for 4-byte types and 4 MiB for 2-byte types.
 int rs_tiles_per_wave(const Params &p, int tiles_per_clip, long long outside_bytes, bool force, long long l2_budget)
 {
     const int64_t clips = p.groups / p.frames;
@@ -176,8 +176,7 @@ int rs_tiles_per_wave(const Params &p, int tiles_per_clip, long long outside_byt
         if (!force && clips * p.M * parts < device_cus()) continue;          // must fill the chip
         pick = cand;
         const long long pairs = (cus_per_xcd + parts - 1) / parts;
-        // (beyond 4 MiB only with at least two workgroups per CU: measured equal-or-worse with exactly one)
-        if (pairs * outside_bytes <= (4ll << 20) || (pairs * outside_bytes <= l2_budget && clips * p.M * parts >= 2 * device_cus())) break;
+        if (pairs * outside_bytes <= l2_budget) break;
     }
     return pick;
 }
@@ -233,13 +232,14 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
     const int rs_row = 32 * esz;                                  // bytes of one pixel of one head
     const bool rs_ok = rs_fits(p, esz);
     const int l0_host = rs_ok ? host_first_slab_level(p, (kRsSlabBytes - kRsSlack) / rs_row) : p.L;
+    const long long l2_budget = esz == 4 ? (2ll << 20) : (4ll << 20);        // see rs_tiles_per_wave
 
     if (!bwd) {
         if (rs_ok) {
             // resident-slab forward: up to NT * 16 tiles of 16 rows per workgroup, so that the per-frame slab staging is
             // amortised; tiles per wave (NT) and workgroups per (clip, head) (parts): see rs_tiles_per_wave
             const int mode = knobs().fwd_rs;                               // -1 auto, 0 off, 1 force
-            int nt = rs_tiles_per_wave(p, rs_tiles_per_clip, host_pixels_below(p, l0_host) * rs_row, mode == 1, 8ll << 20);
+            int nt = rs_tiles_per_wave(p, rs_tiles_per_clip, host_pixels_below(p, l0_host) * rs_row, mode == 1, l2_budget);
             // the slab must hold at least the last level.  (Since the whole-row loads / stores of the points and gradients
             // the kernel wins for every dtype as soon as ANY level fits -- 800x1333, levels 2-3 resident.)
             if (mode != 1 && l0_host > p.L - 1) nt = 0;
@@ -265,7 +265,8 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
         if (rs_ok && (p.cull_points || !p.bbox)) {
             // resident-slab gather pass: same applicability rule as the forward
             const int mode = knobs().bwd_rs;
-            const int tpw = rs_tiles_per_wave(p, rs_tiles_per_clip, host_pixels_below(p, l0_host) * rs_row, mode == 1, 4ll << 20);
+            int tpw = rs_tiles_per_wave(p, rs_tiles_per_clip, host_pixels_below(p, l0_host) * rs_row, mode == 1, l2_budget);
+            if (knobs().bwd_rs_tpw > 0) tpw = knobs().bwd_rs_tpw;
             const int parts = tpw ? (rs_tiles_per_clip + tpw * kRsWaves - 1) / (tpw * kRsWaves) : 1;       // (L2: see the forward)
             const bool want = mode == 1 || (mode == -1 && tpw && l0_host <= p.L - 1);
             if (want && clips * p.M * parts <= 0x7fffffffLL) {

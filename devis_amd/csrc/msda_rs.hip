@@ -5,124 +5,83 @@ namespace msda {
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// "resident-slab" kernels (round 2): levels 1..L-1 of one source frame live in LDS, tap records in registers
+// "resident-slab" kernels: levels l0..L-1 of one source frame live in LDS, everything per point in registers
 // ------------------------------------------------------------------------------------------------
-// The slab kernels above keep 70 KiB of per-wave tap records in LDS, which leaves room for levels 2-3 only
-// (50 % of the taps); everything else crosses the L1 path at ~25 B/clk/CU.  Here the records never touch
-// LDS, so ~156 KiB of the 160 are slab (levels 1-3 of the DeVIS pyramids: 75 % of the taps):
+// ~156 KiB of a CU's 160 KiB of LDS are slab (levels 1-3 of the DeVIS pyramids: 75 % of the taps), staged by LDS-DMA:
 //   * a 1024-thread workgroup owns (clip, head, a run of up to NT*16 row tiles); its waves keep the accumulators
 //     of NT tiles in registers while the workgroup walks the clip's SOURCE FRAMES; per frame the slab
-//     value[frame, levels >= l0, head, :] is staged by LDS-DMA (once per NT*16 tiles instead of once per 16),
-//     then every wave runs, for each of its tiles, the slots of that tile that read the frame;
+//     value[frame, levels >= l0, head, :] is staged once, then every wave runs, for each of its tiles, the slots of
+//     that tile that read the frame (slot masks [T, T] built once in LDS: no frame-table chasing);
 //   * a row (query, head) is served by ONE QUAD: 16 rows per wave, lane c of the quad holding channels
-//     [4c, 4c+4) of both halves of the row (D = 32).  Lane c also fetches point (g0 + c) of the row and turns it
-//     into "point data" (fractions, attention weight, top-left pixel, validity bits).  In step R the quad's
-//     lanes read lane R's data through quad_perm DPP operands folded into the consuming VALU instruction
-//     (v_and/v_add/v_fmac/v_mul ..._dpp: no LDS crossbar), each lane deriving the address and weight of ITS
-//     corner (lane & 3); the four corners of the point are then read with 16-byte loads whose addresses and
-//     weights come from lanes 0..3 of the quad, again by DPP.  (Measured, scripts/ubench/valu_rate.hip: a DPP
-//     operand makes a VALU instruction half rate -- 4.3 vs 2.3 clk per wave64 instruction -- so a weight is
-//     moved once per corner with v_mov_b32_dpp and then feeds 8 plain v_fmac_f32: that is why a row is a quad
-//     with 8 channels per lane and not 8 lanes with 4.)
+//     [4c, 4c+4) of both halves of the row (D = 32; 2-byte types: channels [8c, 8c+8)).  Lane c also owns point
+//     (g0 + c) of the row's current group of four points and turns it into four corner records (rs_geometry); in step R
+//     the quad reads lane R's records through quad_perm DPP operands (no LDS crossbar) and loads the four corners with
+//     16-byte loads.  (Measured, scripts/ubench/valu_rate.hip: a DPP operand makes a VALU instruction half rate, so a
+//     weight is moved once per corner with v_mov_b32_dpp and then feeds 8 plain FMAs: that is why a row is a quad with
+//     8 channels per lane and not 8 lanes with 4.)
 //   * quads alternate which 64-byte half of a 128-byte row they read first, which halves the LDS bank conflicts
 //     of the 16-lane ds_read_b128 groups (4 quads = 4 half rows on 4 different 16-bank quarters when row
 //     parities differ);
 //   * a corner outside the map reads a zero row kept in LDS (slab levels) or an out-of-range buffer offset
 //     (other levels: buffer loads return 0 without touching memory), so a non-finite value at an unrelated
 //     pixel can never leak into a row that does not sample it.
+#ifndef MSDA_RS_PIPE
+#define MSDA_RS_PIPE 1       // software-pipelined level-0 corners (0: the plain group loop only; A/B builds)
+#endif
 template <typename T> constexpr int rs_row_bytes() { return 32 * (int)sizeof(T); }
 
-// The 8 channels a lane holds of one pixel row whose (this lane's) slice starts at LDS byte address `a` / buffer byte
-// offset `a`: 4-byte types -- [4c, 4c+4) of both 64-byte halves, the second half at a ^ 64 (LDS) or a + delta2
-// (memory); 2-byte types -- the 8 contiguous channels [8c, 8c+8) = ONE 16-byte load.
+// A pixel row slice as it comes out of the load -- 2 x 16 bytes (4-byte types: channels [4c, 4c+4) of both
+// 64-byte halves) or 16 bytes (2-byte types: channels [8c, 8c+8)) -- and its conversion to the lane's 8 fp32 channels,
+// as two steps, so that a row in flight costs its raw registers only.  The LDS byte address is used AS the address (the
+// slab starts at LDS address 0: no base to add); the second half of a 4-byte-type row is at a + delta2 (= a ^ 64 for
+// the lane's own first-half choice).
+template <typename T> struct RsRaw { u32x4 q[sizeof(T) == 4 ? 2 : 1]; };
+
 template <typename T, bool SLAB>
-__device__ __forceinline__ void rs_load_row8(const unsigned char *lds_raw, __amdgpu_buffer_rsrc_t rsrc, int a, int delta2,
-                                             float (&v)[8])
+__device__ __forceinline__ RsRaw<T> rs_issue_row(__amdgpu_buffer_rsrc_t rsrc, int a, int delta2)
 {
-    if constexpr (sizeof(T) == 4) {
-        if constexpr (SLAB) {
-            const float4 q1 = *reinterpret_cast<const float4 *>(lds_raw + a);
-            const float4 q2 = *reinterpret_cast<const float4 *>(lds_raw + (a ^ 64));
-            v[0] = q1.x; v[1] = q1.y; v[2] = q1.z; v[3] = q1.w; v[4] = q2.x; v[5] = q2.y; v[6] = q2.z; v[7] = q2.w;
-        } else {
-            const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, a, 0, 0);
-            const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, a + delta2, 0, 0);
-            v[0] = __uint_as_float(q1.x); v[1] = __uint_as_float(q1.y); v[2] = __uint_as_float(q1.z); v[3] = __uint_as_float(q1.w);
-            v[4] = __uint_as_float(q2.x); v[5] = __uint_as_float(q2.y); v[6] = __uint_as_float(q2.z); v[7] = __uint_as_float(q2.w);
-        }
+    typedef __attribute__((address_space(3))) const u32x4 *lds_u4;
+    RsRaw<T> r;
+    if constexpr (SLAB) {
+        r.q[0] = *(lds_u4)(uintptr_t)(unsigned)a;
+        if constexpr (sizeof(T) == 4) r.q[1] = *(lds_u4)(uintptr_t)(unsigned)(a + delta2);
     } else {
-        u32x4 q;
-        if constexpr (SLAB) q = *reinterpret_cast<const u32x4 *>(lds_raw + a);
-        else q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, a, 0, 0);
-        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+        r.q[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, a, 0, 0);
+        if constexpr (sizeof(T) == 4) r.q[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, a + delta2, 0, 0);
+    }
+    return r;
+}
+
+template <typename T>
+__device__ __forceinline__ void rs_fma_row(const RsRaw<T> &r, float w, float (&acc)[8])
+{
+    float v[8];
+    if constexpr (sizeof(T) == 4) {
+        v[0] = __uint_as_float(r.q[0].x); v[1] = __uint_as_float(r.q[0].y); v[2] = __uint_as_float(r.q[0].z); v[3] = __uint_as_float(r.q[0].w);
+        v[4] = __uint_as_float(r.q[1].x); v[5] = __uint_as_float(r.q[1].y); v[6] = __uint_as_float(r.q[1].z); v[7] = __uint_as_float(r.q[1].w);
+    } else {
+        unpack_raw(static_cast<const T *>(nullptr), r.q[0], v);
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if constexpr (sizeof(T) == 2 && std::is_same<T, bf16_t>::value) {
-                v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-            } else {
-                const float2 f = __half22float2(*reinterpret_cast<const __half2 *>(&w[i]));
-                v[2 * i] = f.x; v[2 * i + 1] = f.y;
-            }
-        }
+    for (int c = 0; c < 8; ++c) acc[c] = fmaf(w, v[c], acc[c]);
+}
+
+// <g, row> over the lane's 8 channels
+template <typename T>
+__device__ __forceinline__ float rs_dot_row(const RsRaw<T> &r, const float (&g)[8])
+{
+    float v[8];
+    if constexpr (sizeof(T) == 4) {
+        v[0] = __uint_as_float(r.q[0].x); v[1] = __uint_as_float(r.q[0].y); v[2] = __uint_as_float(r.q[0].z); v[3] = __uint_as_float(r.q[0].w);
+        v[4] = __uint_as_float(r.q[1].x); v[5] = __uint_as_float(r.q[1].y); v[6] = __uint_as_float(r.q[1].z); v[7] = __uint_as_float(r.q[1].w);
+    } else {
+        unpack_raw(static_cast<const T *>(nullptr), r.q[0], v);
     }
+    float acc = g[0] * v[0];
+#pragma unroll
+    for (int c = 1; c < 8; ++c) acc = fmaf(g[c], v[c], acc);
+    return acc;
 }
-
-#define MSDA_QP(s) "quad_perm:[" #s "," #s "," #s "," #s "] row_mask:0xf bank_mask:0xf"
-
-// dst = quad_lane_R(src) <op> other, R a compile-time constant
-#define MSDA_DEF_QUAD_OP(name, ctype, mnem)                                                                \
-    template <int R> __device__ __forceinline__ ctype name(ctype src, ctype other)                         \
-    {                                                                                                      \
-        ctype r;                                                                                           \
-        if constexpr (R == 0) asm(mnem " %0, %1, %2 " MSDA_QP(0) : "=v"(r) : "v"(src), "v"(other));       \
-        else if constexpr (R == 1) asm(mnem " %0, %1, %2 " MSDA_QP(1) : "=v"(r) : "v"(src), "v"(other));  \
-        else if constexpr (R == 2) asm(mnem " %0, %1, %2 " MSDA_QP(2) : "=v"(r) : "v"(src), "v"(other));  \
-        else asm(mnem " %0, %1, %2 " MSDA_QP(3) : "=v"(r) : "v"(src), "v"(other));                        \
-        return r;                                                                                          \
-    }
-MSDA_DEF_QUAD_OP(quad_and, int, "v_and_b32_dpp")
-MSDA_DEF_QUAD_OP(quad_add, int, "v_add_u32_dpp")
-MSDA_DEF_QUAD_OP(quad_mul, float, "v_mul_f32_dpp")
-#undef MSDA_DEF_QUAD_OP
-
-// acc += quad_lane_R(src) * other
-template <int R> __device__ __forceinline__ void quad_fmac(float &acc, float src, float other)
-{
-    if constexpr (R == 0) asm("v_fmac_f32_dpp %0, %1, %2 " MSDA_QP(0) : "+v"(acc) : "v"(src), "v"(other));
-    else if constexpr (R == 1) asm("v_fmac_f32_dpp %0, %1, %2 " MSDA_QP(1) : "+v"(acc) : "v"(src), "v"(other));
-    else if constexpr (R == 2) asm("v_fmac_f32_dpp %0, %1, %2 " MSDA_QP(2) : "+v"(acc) : "v"(src), "v"(other));
-    else asm("v_fmac_f32_dpp %0, %1, %2 " MSDA_QP(3) : "+v"(acc) : "v"(src), "v"(other));
-}
-
-// A VGPR written by a VALU instruction may be read through DPP only two wait states later; inline asm is
-// invisible to the compiler's hazard recogniser, so values about to be read that way pass through a fence.
-__device__ __forceinline__ void dpp_fence(float &a, float &b, float &c, int &d, int &e)
-{
-    asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
-}
-
-// lanes 0..3 of the quad hold the records of corners 0..3: their addresses (+ this lane's offset) and weights
-__device__ __forceinline__ void quad_corner_records(int addr, float w, int lane_off, int (&A)[4], float (&W)[4])
-{
-    asm volatile("s_nop 1\n"
-                 "v_add_u32_dpp %0, %8, %9 " MSDA_QP(0) "\n v_add_u32_dpp %1, %8, %9 " MSDA_QP(1) "\n"
-                 "v_add_u32_dpp %2, %8, %9 " MSDA_QP(2) "\n v_add_u32_dpp %3, %8, %9 " MSDA_QP(3) "\n"
-                 "v_mov_b32_dpp %4, %10 " MSDA_QP(0) "\n v_mov_b32_dpp %5, %10 " MSDA_QP(1) "\n"
-                 "v_mov_b32_dpp %6, %10 " MSDA_QP(2) "\n v_mov_b32_dpp %7, %10 " MSDA_QP(3)
-                 : "=&v"(A[0]), "=&v"(A[1]), "=&v"(A[2]), "=&v"(A[3]), "=&v"(W[0]), "=&v"(W[1]), "=&v"(W[2]), "=&v"(W[3])
-                 : "v"(addr), "v"(lane_off), "v"(w));
-}
-
-
-// Per-lane constants of the corner a lane serves inside its quad (corner = lane & 3: bit 0 = x+1, bit 1 = y+1).
-struct RsLane {
-    int vmask, dymask, dx;                  // validity bit of the corner in Wb; (y+1 ? 0xffffff : 0); x+1
-    int off1, delta2;                       // byte offset of the lane's first 16-byte slice inside a pixel row; second = first + delta2
-    float fy0, fys, fx0, fxs;               // corner weight = (fy0 + fys * lh) * (fx0 + fxs * lw)
-};
-
-// What the lane that fetched a point shows to its quad.
-struct RsPoint { float lh, lw, a; int pbase, Wb; };     // Wb = W | validity bits << 24
 
 // levels >= l0 of source frame f (head m) -> LDS slab, 16 bytes per lane by LDS-DMA (8 lanes per pixel)
 template <typename T>
@@ -142,30 +101,6 @@ __device__ __forceinline__ void rs_stage_slab(const Params &p, T *slab, int clip
 #endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// Point data of THIS lane's own point (x, y, a) at level `lvl` of source frame f: cuh:285-288 (pixel coords,
-// range test), cuh:38-53 (floor, fractions), cuh:56-80 (per-corner validity).  Levels of the slab are addressed
-// by their pixel index inside the slab, the others by their pixel index inside the clip.
-__device__ __forceinline__ RsPoint rs_point(float x, float y, float a, int lvl, int l0, int fS,
-                                            const int *s_H, const int *s_W, const int *s_lsi, const int *s_sst)
-{
-    const int H = s_H[lvl], W = s_W[lvl];
-    const int base = lvl >= l0 ? s_sst[lvl] : fS + s_lsi[lvl];
-    const float h_im = __fsub_rn(__fmul_rn(y, (float)H), 0.5f);
-    const float w_im = __fsub_rn(__fmul_rn(x, (float)W), 0.5f);
-    const bool rng = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;     // false for NaN
-    const float hf = floorf(h_im), wf = floorf(w_im);
-    const int yl = rng ? (int)hf : 0, xl = rng ? (int)wf : 0;
-    RsPoint r;
-    r.lh = rng ? h_im - hf : 0.f;
-    r.lw = rng ? w_im - wf : 0.f;
-    r.a = rng ? a : 0.f;
-    const int vy0 = yl >= 0, vy1 = yl + 1 <= H - 1, vx0 = xl >= 0, vx1 = xl + 1 <= W - 1;
-    const int bits = rng ? ((vy0 & vx0) | ((vy0 & vx1) << 1) | ((vy1 & vx0) << 2) | ((vy1 & vx1) << 3)) : 0;
-    r.pbase = base + yl * W + xl;
-    r.Wb = W | (bits << 24);
-    return r;
 }
 
 // The shared front of the resident-slab kernels: LDS carve, level tables, slot masks, tile geometry.
@@ -267,6 +202,82 @@ __device__ __forceinline__ void load_slot_points(const T *loc, const T *aw, int6
     quad_transpose4(xs, cor); quad_transpose4(ys, cor); quad_transpose4(as, cor);
 }
 
+// ---- forward ------------------------------------------------------------------------------------------------------
+// One quad = one row, 16 rows per wave tile, slab = levels >= l0 of one source frame (geometry: see the head of this
+// file).  Round 3 changes against the round-2 kernel, each from a measurement:
+//   * PER-LANE CORNER RECORDS: lane c of a quad turns ITS point into the four corner records (LDS / buffer byte address
+//     with the out-of-map substitution, weight x attention) with plain VALU instructions; a step then only broadcasts
+//     lane R's eight values to the quad (v_add_u32_dpp with the lane's slice offset, v_mov_b32_dpp).  Round 2 derived
+//     each corner in the lane of the same number with six DPP-operand instructions per step and then broadcast all four:
+//     16.5 VALU instructions per corner, now 7 (forward 0.430 -> 0.369 ms on the bench workload, same box).
+//   * ABLATIONS (timing-only builds, profiles/r03_*): without the level-0 (memory) corners the kernel takes 0.154 ms,
+//     without the slab (LDS) corners 0.377 ms = the time of the full kernel (0.374): the LDS / VALU side is completely
+//     hidden behind the level-0 gathers, i.e. behind the rate at which a CU's vector-memory path returns scattered 128-byte
+//     lines that miss the L1 (86 k lines per CU and launch at ~420 clk average L2 round trip).  A software-pipelined
+//     variant that kept 4-8 level-0 loads in flight per lane across the LDS steps was therefore no faster (0.380 ms)
+//     and is not kept; what helps is a smaller L2 working set (fewer (clip, head) pairs in flight per XCD: 1 tile per
+//     wave 0.345 ms against 0.374 with 2), which is what the host's choice of `parts` now optimises.
+struct RsRec { int a[4]; float w[4]; };      // this lane's point: byte address (without the lane's slice offset) and weight of corners 0..3
+
+// The lane's own point at level `lvl` of source frame f: cuh:285-288 (pixel coords, range test), cuh:38-53 (floor,
+// fractions), cuh:56-80 (per-corner validity).  Corners outside the map (or of a point outside the range) get the zero
+// row of the slab / an out-of-range buffer offset: their loads return zeros.
+struct RsGeom {
+    float lh, lw, a;        // fractions and attention weight (all 0 for a point outside the range)
+    int H, W, yl, bits;     // level shape, top tap row, validity bits of corners 0..3 (0: point skipped)
+    int adr[4];             // byte address of each corner WITHOUT the lane's slice offset
+};
+
+template <int ROWSH>
+__device__ __forceinline__ RsGeom rs_geometry(float x, float y, float a, int lvl, int l0, int fS, const RsShared &sh, int pixB)
+{
+    RsGeom g;
+    g.H = sh.H[lvl]; g.W = sh.W[lvl];
+    const int H = g.H, W = g.W;
+    const bool slab = lvl >= l0;
+    const int base = slab ? sh.sst[lvl] : fS + sh.lsi[lvl];
+    const float h_im = __fsub_rn(__fmul_rn(y, (float)H), 0.5f);
+    const float w_im = __fsub_rn(__fmul_rn(x, (float)W), 0.5f);
+    const bool rng = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;     // false for NaN
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const int yl = rng ? (int)hf : 0, xl = rng ? (int)wf : 0;
+    g.yl = yl;
+    g.lh = rng ? h_im - hf : 0.f; g.lw = rng ? w_im - wf : 0.f; g.a = rng ? a : 0.f;
+    const bool vy0 = rng && yl >= 0, vy1 = rng && yl + 1 <= H - 1, vx0 = xl >= 0, vx1 = xl + 1 <= W - 1;
+    const bool ok[4] = {vy0 && vx0, vy0 && vx1, vy1 && vx0, vy1 && vx1};
+    g.bits = (ok[0] ? 1 : 0) | (ok[1] ? 2 : 0) | (ok[2] ? 4 : 0) | (ok[3] ? 8 : 0);
+    const int p00 = base + yl * W + xl;
+    const int pix[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+    const int none = slab ? sh.zero_off : (int)0x80000000u;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        g.adr[s] = ok[s] ? (slab ? (pix[s] << ROWSH) : (int)((unsigned)pix[s] * (unsigned)pixB)) : none;
+    return g;
+}
+
+// forward: corner addresses + weights (bilinear weight x attention weight)
+template <int ROWSH>
+__device__ __forceinline__ RsRec rs_records(float x, float y, float a, int lvl, int l0, int fS, const RsShared &sh, int pixB)
+{
+    const RsGeom g = rs_geometry<ROWSH>(x, y, a, lvl, l0, fS, sh, pixB);
+    const float hh = 1.f - g.lh, hw = 1.f - g.lw;
+    RsRec r;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) r.a[s] = g.adr[s];
+    r.w[0] = g.a * (hh * hw); r.w[1] = g.a * (hh * g.lw); r.w[2] = g.a * (g.lh * hw); r.w[3] = g.a * (g.lh * g.lw);
+    return r;
+}
+
+// lane R's value of `v`, for every lane of the quad (R a compile-time constant)
+template <int R> __device__ __forceinline__ int quad_bcast(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, R | (R << 2) | (R << 4) | (R << 6), 0xf, 0xf, true);
+}
+template <int R> __device__ __forceinline__ float quad_bcast(float v)
+{
+    return __int_as_float(quad_bcast<R>(__float_as_int(v)));
+}
+
 template <typename T, int NT>
 __global__ void __launch_bounds__(kRsThreads)
 msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
@@ -303,13 +314,9 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
     };
 
     const int j = lane / 4, cor = lane & 3, hsw = j & 1;
-    RsLane ln;
-    ln.vmask = 1 << (24 + cor); ln.dymask = (cor & 2) ? 0xffffff : 0; ln.dx = cor & 1;
-    ln.off1 = kHalf ? cor * 16 : cor * 16 + hsw * 64; ln.delta2 = hsw ? -64 : 64;
-    ln.fy0 = (cor & 2) ? 0.f : 1.f; ln.fys = (cor & 2) ? 1.f : -1.f;
-    ln.fx0 = (cor & 1) ? 0.f : 1.f; ln.fxs = (cor & 1) ? 1.f : -1.f;
+    // byte offset of the lane's first 16-byte slice inside a pixel row; 4-byte types: the second slice at ^64 (LDS) / + delta2
+    const int off1 = kHalf ? cor * 16 : cor * 16 + hsw * 64, delta2 = hsw ? -64 : 64;
     const int pixB = p.v_pix * (int)sizeof(T);
-    // buffer resource over value[clip, :, m, :] (stride 0 = raw, num_records in bytes): out-of-range -> 0
     const char *vbase = reinterpret_cast<const char *>(static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head);
     const unsigned vbytes = (unsigned)(((int64_t)p.frames * p.S - 1) * pixB + ROWB);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -324,7 +331,9 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
 
     for (int f = 0; f < p.frames; ++f) {
         __syncthreads();                                   // every wave is done with the previous slab
+#if !defined(MSDA_RS_EXP) || MSDA_RS_EXP != 3
         if (l0 < L) rs_stage_slab<T>(p, slab, clip, m, f, sh.px0, sh.npx, wave, lane);
+#endif
         __syncthreads();
         const int fS = f * p.S;
 #pragma unroll 1
@@ -343,6 +352,37 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                     for (int c = 0; c < 8; ++c) wacc[c] = acc[K][c];
                 }
             });
+            // one corner: the lane's 8 channels of the row at byte address A, times W
+            auto corner = [&](auto Sc, int A, float W) {      // (A by value: the experiments below may change it)
+                constexpr bool SLAB = decltype(Sc)::value;
+#if defined(MSDA_RS_EXP)          // timing experiments (wrong results): 2 = no LDS reads, 1 = no memory corners,
+                                  // 4 = memory corners read one 16-byte slice instead of two, 5 = ... from one 32 KiB window
+                if constexpr (SLAB && MSDA_RS_EXP == 2) { wacc[0] += W * (float)A; return; }
+                if constexpr (!SLAB && MSDA_RS_EXP == 1) { wacc[0] += W * (float)A; return; }
+#if defined(__HIP_DEVICE_COMPILE__)
+                if constexpr (!SLAB && MSDA_RS_EXP == 4) {
+                    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, A, 0, 0);
+                    wacc[0] = fmaf(W, __uint_as_float(q.x), wacc[0]); wacc[1] = fmaf(W, __uint_as_float(q.y), wacc[1]);
+                    wacc[2] = fmaf(W, __uint_as_float(q.z), wacc[2]); wacc[3] = fmaf(W, __uint_as_float(q.w), wacc[3]);
+                    return;
+                }
+#endif
+                if constexpr (!SLAB && MSDA_RS_EXP == 5) A &= 0x7fff;
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+                const RsRaw<T> raw = rs_issue_row<T, SLAB>(rsrc, A, delta2);
+                rs_fma_row<T>(raw, W, wacc);
+#endif
+                // corner by corner: the next corner's loads are not hoisted above these FMAs (measured in round 2:
+                // eight loads in flight per wave only queue up in the LDS / TA pipes)
+                asm volatile("" ::: "memory");
+            };
+            // one step = point R of the group, for the 16 rows of the wave: lane R's records go to the whole quad
+            auto step = [&](auto Rc, auto Sc, const RsRec &rec) {
+                constexpr int R = decltype(Rc)::value;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) corner(Sc, quad_bcast<R>(rec.a[s]) + off1, quad_bcast<R>(rec.w[s]));
+            };
 #pragma unroll 1
             while (todo) {                                     // sl = -1: the tile's current-frame points
                 const int sl = (int)__builtin_ctz(todo) - 1;
@@ -358,58 +398,82 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                 const bool wide = p.wide_loads && P == 4 && npts == 16;           // (uniform) see load_slot_points
                 float xs[4], ys[4], as[4];
                 if (wide) load_slot_points<T>(loc, aw, idx0, cor, live, xs, ys, as);
-#pragma unroll 1
-                for (int g0 = 0; g0 < npts; g0 += 4) {
-                    const int kk = g0 + cor;
-                    float x = -10.f, y = -10.f, a = 0.f;       // far outside every map
-                    if (wide) {
-                        x = get4(xs, g0 >> 2); y = get4(ys, g0 >> 2); a = get4(as, g0 >> 2);
-                    } else if (live && kk < npts) {
-                        load_xy(loc + 2 * (idx0 + kk), x, y);
-                        a = Store<T>::get(aw + idx0 + kk);
-                    }
-                    const int lvl = min((int)(((unsigned)kk * invP) >> 16), L - 1);
-                    RsPoint pt = rs_point(x, y, a, lvl, l0, fS, sh.H, sh.W, sh.lsi, sh.sst);
-                    dpp_fence(pt.lh, pt.lw, pt.a, pt.pbase, pt.Wb);
-                    // one step = one point of the 16 rows: this lane's corner record, then the four corners
-                    auto step = [&](auto Rc, auto Sc) {
-                        constexpr int R = decltype(Rc)::value;
-                        constexpr bool SLAB = decltype(Sc)::value;
-                        const int vb = quad_and<R>(pt.Wb, ln.vmask);
-                        const int tw = quad_and<R>(pt.Wb, ln.dymask);
-                        const int pix = quad_add<R>(pt.pbase, ln.dx) + tw;
-                        int addr = SLAB ? (pix << ROWSH) : (int)((unsigned)pix * (unsigned)pixB);
-                        addr = vb ? addr : (SLAB ? sh.zero_off : (int)0x80000000u);
-                        float wy = ln.fy0, wx = ln.fx0;
-                        quad_fmac<R>(wy, pt.lh, ln.fys);
-                        quad_fmac<R>(wx, pt.lw, ln.fxs);
-                        const float w = quad_mul<R>(pt.a, wy * wx);
-                        int A[4];
-                        float W[4];
-                        quad_corner_records(addr, w, ln.off1, A, W);
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            float v[8];
+#if MSDA_RS_PIPE
+                if (wide && l0 == 1) {
+                    // 4 levels x 4 points, levels < l0 outside the slab.  Work units are corner PAIRS: 8 * l0 memory pairs (4
+                    // buffer loads each) ride along the 8 * (4 - l0) LDS pairs -- one memory pair is consumed, and the next
+                    // issued, after every third (l0 = 1) or every (l0 = 2) LDS pair
+                    auto pipelined = [&](auto L0c) {
+                        constexpr int L0 = decltype(L0c)::value, NM = 8 * L0, NL = 8 * (4 - L0), PERIOD = NL / NM;
+                        RsRec rm[L0];
+                        RsRaw<T> mv[2];                        // the memory pair in flight
+                        // (the "+v" pins below are empty asm statements: they tie a value to a point of the instruction stream --
+                        // after the FMAs that produced wacc, before the address arithmetic / loads that use it -- so that the
+                        // compiler neither computes all records of a slot up front nor lets eight loads pile up in registers)
+                        auto issue = [&](auto Jc) {
+                            constexpr int J = decltype(Jc)::value, G = J / 8, R = (J % 8) / 2, S0 = 2 * (J % 2);
+                            if constexpr (J % 8 == 0) {
+                                asm volatile("" : "+v"(xs[G]), "+v"(ys[G]), "+v"(as[G]) : "v"(wacc[0]));
+                                rm[G] = rs_records<ROWSH>(xs[G], ys[G], as[G], G, l0, fS, sh, pixB);
+                            }
+                            int a0 = quad_bcast<R>(rm[G].a[S0]) + off1, a1 = quad_bcast<R>(rm[G].a[S0 + 1]) + off1;
+                            asm volatile("" : "+v"(a0), "+v"(a1) : "v"(wacc[7]));
 #if defined(__HIP_DEVICE_COMPILE__)
-                            rs_load_row8<T, SLAB>(lds_raw, rsrc, A[s], ln.delta2, v);
+                            mv[0] = rs_issue_row<T, false>(rsrc, a0, delta2);
+                            mv[1] = rs_issue_row<T, false>(rsrc, a1, delta2);
 #endif
-#pragma unroll
-                            for (int c = 0; c < 8; ++c) wacc[c] = fmaf(W[s], v[c], wacc[c]);
-                            // corner by corner: the next corner's loads are not hoisted above these FMAs (measured: 0.466 ->
-                            // 0.430 ms; eight loads in flight per wave only queue up in the LDS / TA pipes)
-                            asm volatile("" ::: "memory");
-                        }
-                    };
-                    if (g0 >= first_slab_pt) {                 // the whole group reads the slab (uniform)
-                        static_for<4>([&](auto Rc) { if (g0 + decltype(Rc)::value < npts) step(Rc, std::true_type{}); });
-                    } else if (g0 + 3 < first_slab_pt) {       // the whole group reads memory
-                        static_for<4>([&](auto Rc) { if (g0 + decltype(Rc)::value < npts) step(Rc, std::false_type{}); });
-                    } else {
-                        static_for<4>([&](auto Rc) {
-                            constexpr int R = decltype(Rc)::value;
-                            if (g0 + R >= npts) return;
-                            if (g0 + R >= first_slab_pt) step(Rc, std::true_type{}); else step(Rc, std::false_type{});
+                        };
+                        auto consume = [&](auto Jc) {
+                            constexpr int J = decltype(Jc)::value, G = J / 8, R = (J % 8) / 2, S0 = 2 * (J % 2);
+                            const float w0 = quad_bcast<R>(rm[G].w[S0]), w1 = quad_bcast<R>(rm[G].w[S0 + 1]);
+                            rs_fma_row<T>(mv[0], w0, wacc);
+                            rs_fma_row<T>(mv[1], w1, wacc);
+                        };
+                        issue(std::integral_constant<int, 0>{});
+                        static_for<4 - L0>([&](auto Gc) {
+                            constexpr int GL = decltype(Gc)::value + L0;       // a level of the slab
+                            asm volatile("" : "+v"(xs[GL]), "+v"(ys[GL]), "+v"(as[GL]) : "v"(wacc[0]));
+                            const RsRec rl = rs_records<ROWSH>(xs[GL], ys[GL], as[GL], GL, l0, fS, sh, pixB);
+                            static_for<8>([&](auto Hc) {
+                                constexpr int R = decltype(Hc)::value / 2, S0 = 2 * (decltype(Hc)::value % 2);
+                                constexpr int HS = (GL - L0) * 8 + decltype(Hc)::value;      // LDS pair index
+                                corner(std::true_type{}, quad_bcast<R>(rl.a[S0]) + off1, quad_bcast<R>(rl.w[S0]));
+                                corner(std::true_type{}, quad_bcast<R>(rl.a[S0 + 1]) + off1, quad_bcast<R>(rl.w[S0 + 1]));
+                                if constexpr ((HS + 1) % PERIOD == 0) {
+                                    constexpr int J = (HS + 1) / PERIOD - 1;
+                                    consume(std::integral_constant<int, J>{});
+                                    if constexpr (J + 1 < NM) issue(std::integral_constant<int, J + 1>{});
+                                }
+                            });
                         });
+                    };
+                    pipelined(std::integral_constant<int, 1>{});
+                } else
+#endif
+                {
+#pragma unroll 1
+                    for (int g0 = 0; g0 < npts; g0 += 4) {
+                        const int kk = g0 + cor;
+                        float x = -10.f, y = -10.f, a = 0.f;       // far outside every map
+                        if (wide) {
+                            x = get4(xs, g0 >> 2); y = get4(ys, g0 >> 2); a = get4(as, g0 >> 2);
+                        } else if (live && kk < npts) {
+                            load_xy(loc + 2 * (idx0 + kk), x, y);
+                            a = Store<T>::get(aw + idx0 + kk);
+                        }
+                        const int lvl = min((int)(((unsigned)kk * invP) >> 16), L - 1);
+                        const RsRec rec = rs_records<ROWSH>(x, y, a, lvl, l0, fS, sh, pixB);
+                        if (g0 >= first_slab_pt) {                 // the whole group reads the slab (uniform)
+                            static_for<4>([&](auto Rc) { if (g0 + decltype(Rc)::value < npts) step(Rc, std::true_type{}, rec); });
+                        } else if (g0 + 3 < first_slab_pt) {       // the whole group reads memory
+                            static_for<4>([&](auto Rc) { if (g0 + decltype(Rc)::value < npts) step(Rc, std::false_type{}, rec); });
+                        } else {
+                            static_for<4>([&](auto Rc) {
+                                constexpr int R = decltype(Rc)::value;
+                                if (g0 + R >= npts) return;
+                                if (g0 + R >= first_slab_pt) step(Rc, std::true_type{}, rec); else step(Rc, std::false_type{}, rec);
+                            });
+                        }
                     }
                 }
             }
@@ -434,8 +498,8 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                 Store<T>::store(o + cor * 8, acc[K]);       // channels [8c, 8c+8): one 16-byte store
             } else {
                 const float a1[4] = {acc[K][0], acc[K][1], acc[K][2], acc[K][3]}, a2[4] = {acc[K][4], acc[K][5], acc[K][6], acc[K][7]};
-                Store<T>::store(o + ln.off1 / 4, a1);
-                Store<T>::store(o + (ln.off1 + ln.delta2) / 4, a2);
+                Store<T>::store(o + off1 / 4, a1);
+                Store<T>::store(o + (off1 + delta2) / 4, a2);
             }
         }
     });
@@ -448,14 +512,6 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
 // lane R of the quad keeps the dots of point R, and after the group's four points every lane finishes ITS point and
 // stores its (grad_x, grad_y, grad_attn) directly: the 4 points of a group are 32 + 16 contiguous bytes per row.
 // Also leaves the per-point culling records (top tap row as int16) the scatter pass reads.
-__device__ __forceinline__ void quad_corner_addrs(int addr, int lane_off, int (&A)[4])
-{
-    asm volatile("s_nop 1\n"
-                 "v_add_u32_dpp %0, %4, %5 " MSDA_QP(0) "\n v_add_u32_dpp %1, %4, %5 " MSDA_QP(1) "\n"
-                 "v_add_u32_dpp %2, %4, %5 " MSDA_QP(2) "\n v_add_u32_dpp %3, %4, %5 " MSDA_QP(3)
-                 : "=&v"(A[0]), "=&v"(A[1]), "=&v"(A[2]), "=&v"(A[3]) : "v"(addr), "v"(lane_off));
-}
-
 // d[k] <- sum of d[k] over the four lanes of the quad (all lanes get the total)
 __device__ __forceinline__ void quad_sum4(float (&d)[4])
 {
@@ -497,10 +553,8 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
     const int tile_lo = part * tpw + wave, tile_hi = min((part + 1) * tpw, tiles_per_clip);
 
     const int j = lane / 4, cor = lane & 3, hsw = j & 1;
-    RsLane ln;
-    ln.vmask = 1 << (24 + cor); ln.dymask = (cor & 2) ? 0xffffff : 0; ln.dx = cor & 1;
-    ln.off1 = kHalf ? cor * 16 : cor * 16 + hsw * 64; ln.delta2 = hsw ? -64 : 64;
-    ln.fy0 = ln.fys = ln.fx0 = ln.fxs = 0.f;      // (corner weights are not needed for the dots)
+    // byte offset of the lane's first 16-byte slice inside a pixel row; 4-byte types: the second slice at + delta2
+    const int off1 = kHalf ? cor * 16 : cor * 16 + hsw * 64, delta2 = hsw ? -64 : 64;
     const int pixB = p.v_pix * (int)sizeof(T);
     const char *vbase = reinterpret_cast<const char *>(static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head);
     const unsigned vbytes = (unsigned)(((int64_t)p.frames * p.S - 1) * pixB + ROWB);
@@ -531,8 +585,8 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                 if constexpr (kHalf) {
                     Store<T>::load(go + cor * 8, g);
                 } else {
-                    const float4 g1 = *reinterpret_cast<const float4 *>(go + ln.off1 / 4);
-                    const float4 g2 = *reinterpret_cast<const float4 *>(go + (ln.off1 + ln.delta2) / 4);
+                    const float4 g1 = *reinterpret_cast<const float4 *>(go + off1 / 4);
+                    const float4 g2 = *reinterpret_cast<const float4 *>(go + (off1 + delta2) / 4);
                     g[0] = g1.x; g[1] = g1.y; g[2] = g1.z; g[3] = g1.w; g[4] = g2.x; g[5] = g2.y; g[6] = g2.z; g[7] = g2.w;
                 }
             }
@@ -562,8 +616,84 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                 const bool wide_ld = p.wide_loads && P == 4 && npts == 16;
                 float xs[4], ys[4], as[4];
                 if (wide_ld) load_slot_points<T>(loc, aw, idx0, cor, live, xs, ys, as);
+                // every lane finishes its own point (cuh:123-158 on the reduced dots k[]; dots of corners outside the map are 0:
+                // their loads returned zeros)
+                auto finish = [&](const RsGeom &pt, const float (&k)[4], float &gx, float &gy, float &g_aw) {
+                    const float lh = pt.lh, lw = pt.lw, hh = 1.f - lh, hw = 1.f - lw;
+                    g_aw = (hh * hw) * k[0] + (hh * lw) * k[1] + (lh * hw) * k[2] + (lh * lw) * k[3];
+                    const float g_w = hh * (k[1] - k[0]) + lh * (k[3] - k[2]);
+                    const float g_h = hw * (k[2] - k[0]) + lw * (k[3] - k[1]);
+                    gx = (float)pt.W * g_w * pt.a; gy = (float)pt.H * g_h * pt.a;
+                };
+                bool done = false;
+#if MSDA_RS_PIPE
+                if (wide && wide_ld && l0 == 1) {
+                    // 4 levels x 4 points, level 0 outside the slab: its 8 corner PAIRS (4 buffer loads each) ride along the 24
+                    // LDS pairs of levels 1-3, one consumed -- and the next issued -- after every third LDS pair, so that a wave
+                    // overlaps its own L2 round trips with its own slab work (see the forward)
+                    const RsGeom gm = rs_geometry<ROWSH>(xs[0], ys[0], as[0], 0, l0, fS, sh, pixB);
+                    wr[0] = gm.bits ? min(gm.yl, 32767) : kNoRow16;
+                    float km[4] = {0.f, 0.f, 0.f, 0.f}, dm[4];          // dots of this lane's level-0 point; of the point in flight
+                    RsRaw<T> mv[2];
+                    auto issue = [&](auto Jc) {
+                        constexpr int J = decltype(Jc)::value, R = J / 2, S0 = 2 * (J % 2);
+                        int a0 = quad_bcast<R>(gm.adr[S0]) + off1, a1 = quad_bcast<R>(gm.adr[S0 + 1]) + off1;
+                        const float pin = wa[0];
+                        asm volatile("" : "+v"(a0), "+v"(a1) : "v"(pin));        // (ties the loads to this point of the stream)
+#if defined(__HIP_DEVICE_COMPILE__)
+                        mv[0] = rs_issue_row<T, false>(rsrc, a0, delta2);
+                        mv[1] = rs_issue_row<T, false>(rsrc, a1, delta2);
+#endif
+                    };
+                    auto consume = [&](auto Jc) {
+                        constexpr int J = decltype(Jc)::value, R = J / 2, S0 = 2 * (J % 2);
+                        dm[S0] = rs_dot_row<T>(mv[0], g); dm[S0 + 1] = rs_dot_row<T>(mv[1], g);
+                        if constexpr (S0 == 2) {
+                            quad_sum4(dm);
+                            const bool me = cor == R;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) km[u] = me ? dm[u] : km[u];
+                        }
+                    };
+                    issue(std::integral_constant<int, 0>{});
+                    static_for<3>([&](auto Gc) {
+                        constexpr int GL = decltype(Gc)::value + 1;            // a level of the slab
+                        const float pin = wa[0];
+                        asm volatile("" : "+v"(xs[GL]), "+v"(ys[GL]), "+v"(as[GL]) : "v"(pin));
+                        const RsGeom gl = rs_geometry<ROWSH>(xs[GL], ys[GL], as[GL], GL, l0, fS, sh, pixB);
+                        wr[GL] = gl.bits ? min(gl.yl, 32767) : kNoRow16;
+                        float kl[4] = {0.f, 0.f, 0.f, 0.f}, d[4];
+                        static_for<8>([&](auto Hc) {
+                            constexpr int R = decltype(Hc)::value / 2, S0 = 2 * (decltype(Hc)::value % 2);
+                            constexpr int HS = (GL - 1) * 8 + decltype(Hc)::value;       // LDS pair index
+#pragma unroll
+                            for (int s = S0; s < S0 + 2; ++s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                                const RsRaw<T> raw = rs_issue_row<T, true>(rsrc, quad_bcast<R>(gl.adr[s]) + off1, delta2);
+                                d[s] = rs_dot_row<T>(raw, g);
+#endif
+                                asm volatile("" ::: "memory");
+                            }
+                            if constexpr (S0 == 2) {
+                                quad_sum4(d);
+                                const bool me = cor == R;
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) kl[u] = me ? d[u] : kl[u];
+                            }
+                            if constexpr ((HS + 1) % 3 == 0) {
+                                constexpr int J = (HS + 1) / 3 - 1;
+                                consume(std::integral_constant<int, J>{});
+                                if constexpr (J + 1 < 8) issue(std::integral_constant<int, J + 1>{});
+                            }
+                        });
+                        finish(gl, kl, wx[GL], wy[GL], wa[GL]);
+                    });
+                    finish(gm, km, wx[0], wy[0], wa[0]);
+                    done = true;
+                }
+#endif
 #pragma unroll 1
-                for (int g0 = 0; g0 < npts; g0 += 4) {
+                for (int g0 = 0; g0 < (done ? 0 : npts); g0 += 4) {
                     const int kk = g0 + cor;
                     const bool mine = live && kk < npts;
                     float x = -10.f, y = -10.f, a = 0.f;       // far outside every map
@@ -574,22 +704,9 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                         a = Store<T>::get(aw + idx0 + kk);
                     }
                     const int lvl = min((int)(((unsigned)kk * invP) >> 16), L - 1);
-                    // own point: fractions, validity, top-left pixel (as rs_point) + what the gradients need
-                    const int H = sh.H[lvl], W = sh.W[lvl];
-                    const int base = lvl >= l0 ? sh.sst[lvl] : fS + sh.lsi[lvl];
-                    const float h_im = __fsub_rn(__fmul_rn(y, (float)H), 0.5f);
-                    const float w_im = __fsub_rn(__fmul_rn(x, (float)W), 0.5f);
-                    const bool rng = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-                    const float hf = floorf(h_im), wf = floorf(w_im);
-                    const int yl = rng ? (int)hf : 0, xl = rng ? (int)wf : 0;
-                    RsPoint pt;
-                    pt.lh = rng ? h_im - hf : 0.f;
-                    pt.lw = rng ? w_im - wf : 0.f;
-                    pt.a = rng ? a : 0.f;
-                    const int vy0 = yl >= 0, vy1 = yl + 1 <= H - 1, vx0 = xl >= 0, vx1 = xl + 1 <= W - 1;
-                    const int bits = rng ? ((vy0 & vx0) | ((vy0 & vx1) << 1) | ((vy1 & vx0) << 2) | ((vy1 & vx1) << 3)) : 0;
-                    pt.pbase = base + yl * W + xl;
-                    pt.Wb = W | (bits << 24);
+                    // own point: corner addresses, fractions, validity (rs_geometry) -- the quad reads lane R's addresses in step R
+                    const RsGeom pt = rs_geometry<ROWSH>(x, y, a, lvl, l0, fS, sh, pixB);
+                    const int yl = pt.yl, bits = pt.bits;
                     if (wide) set4(wr, g0 >> 2, bits ? min(yl, 32767) : kNoRow16);
                     if (records && mine && !wide) {      // the point's top tap row, for the scatter's band test
                         const int pin = kk - lvl * P;
@@ -598,30 +715,19 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                         if (pin == 0)
                             for (int u = P; u < 4; ++u) rec[u] = (short)kNoRow16;
                     }
-                    dpp_fence(pt.lh, pt.lw, pt.a, pt.pbase, pt.Wb);
                     float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f;      // the dots of THIS lane's point
                     auto step = [&](auto Rc, auto Sc) {
                         constexpr int R = decltype(Rc)::value;
                         constexpr bool SLAB = decltype(Sc)::value;
-                        const int vb = quad_and<R>(pt.Wb, ln.vmask);
-                        const int tw = quad_and<R>(pt.Wb, ln.dymask);
-                        const int pix = quad_add<R>(pt.pbase, ln.dx) + tw;
-                        int addr = SLAB ? (pix << ROWSH) : (int)((unsigned)pix * (unsigned)pixB);
-                        addr = vb ? addr : (SLAB ? sh.zero_off : (int)0x80000000u);
-                        int A[4];
-                        quad_corner_addrs(addr, ln.off1, A);
                         float d[4];
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
-                            float v[8];
 #if defined(__HIP_DEVICE_COMPILE__)
-                            rs_load_row8<T, SLAB>(lds_raw, rsrc, A[s], ln.delta2, v);
+                            const RsRaw<T> raw = rs_issue_row<T, SLAB>(rsrc, quad_bcast<R>(pt.adr[s]) + off1, delta2);
+                            d[s] = rs_dot_row<T>(raw, g);
 #endif
-                            // (measured: issuing all eight loads of the point ahead of the dots is SLOWER, 0.63 -> 0.67 ms)
-                            float acc = g[0] * v[0];
-#pragma unroll
-                            for (int c = 1; c < 8; ++c) acc = fmaf(g[c], v[c], acc);
-                            d[s] = acc;
+                            // (corner by corner; measured in round 2: all eight loads of a point ahead of the dots is slower)
+                            asm volatile("" ::: "memory");
                         }
                         quad_sum4(d);
                         const bool me = cor == R;
@@ -638,14 +744,10 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                             if (g0 + R >= first_slab_pt) step(Rc, std::true_type{}); else step(Rc, std::false_type{});
                         });
                     }
-                    // every lane finishes its own point (cuh:123-158 on the reduced dots; dots of corners outside
-                    // the map are 0: their loads returned zeros)
                     {
-                        const float lh = pt.lh, lw = pt.lw, hh = 1.f - lh, hw = 1.f - lw;
-                        const float g_aw = (hh * hw) * k0 + (hh * lw) * k1 + (lh * hw) * k2 + (lh * lw) * k3;
-                        const float g_w = hh * (k1 - k0) + lh * (k3 - k2);
-                        const float g_h = hw * (k2 - k0) + lw * (k3 - k1);
-                        const float gx = (float)W * g_w * pt.a, gy = (float)H * g_h * pt.a;
+                        const float kq[4] = {k0, k1, k2, k3};
+                        float gx, gy, g_aw;
+                        finish(pt, kq, gx, gy, g_aw);
                         if (wide) {
                             set4(wx, g0 >> 2, gx); set4(wy, g0 >> 2, gy); set4(wa, g0 >> 2, g_aw);
                         } else if (mine) {
@@ -690,9 +792,9 @@ int fwd_rs(const Params &p, int parts, unsigned grid, hipStream_t stream, const 
 {
     static LdsGrant granted;
     const size_t total = (size_t)kRsSlabBytes + kRsTailBytes;
-    if (const int rc = grant_lds(reinterpret_cast<const void *>(&msda_fwd_rs_kernel<T, NT>), total, granted,
-                                 "the resident-slab forward kernel")) return rc;
-    hipLaunchKernelGGL((msda_fwd_rs_kernel<T, NT>), dim3(grid), dim3(kRsThreads), total, stream, p, kRsSlabBytes, parts);
+    const auto kern = &msda_fwd_rs_kernel<T, NT>;
+    if (const int rc = grant_lds(reinterpret_cast<const void *>(kern), total, granted, "the resident-slab forward kernel")) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kRsThreads), total, stream, p, kRsSlabBytes, parts);
     return check_launch(what);
 }
 
