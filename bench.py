@@ -137,12 +137,13 @@ def kernel_name(route, what):
     return "msda_%s(%s)" % (what, route)
 
 
-def algorithmic_bytes(args, e):
+def algorithmic_bytes(args, e, gv_bytes=4):
     """Per launch over ONE clip (DESIGN.md 'algorithmic bytes'): every tensor a kernel
     must touch counted once -- value read once (not once per gathered corner), (x, y, weight) per
     sampling point, one row per query.  The backward is two kernels: the gather pass reads value,
     grad_out, loc/attn and writes grad_loc/grad_attn; the scatter pass reads loc/attn and grad_out and
-    writes grad_value once (fp32; accumulation happens in LDS, so there is no read-modify-write traffic)."""
+    writes grad_value once (fp32, or the 16-bit storage type where the library writes it directly; accumulation happens
+    in registers / LDS, so there is no read-modify-write traffic)."""
     T, q, M, D, P = args.frames, args.queries, 8, 32, 4
     shapes = PYRAMIDS[args.pyramid]
     L, W = len(shapes), T - 1
@@ -151,7 +152,7 @@ def algorithmic_bytes(args, e):
     points = T * q * M * (L * P + W * L * P)
     return {"fwd": T * S * C * e + points * 3 * e + T * q * C * e,
             "bwd_gather": T * S * C * e + T * q * C * e + points * 3 * e + points * 3 * e,
-            "bwd_scatter": points * 3 * e + T * q * C * e + T * S * C * 4}
+            "bwd_scatter": points * 3 * e + T * q * C * e + T * S * C * gv_bytes}
 
 
 def _event_ms(fn, reps, warm=3):
@@ -267,10 +268,10 @@ def other_configs(args, device):
             pts = N * Lq * M * L * P
             alg = {"fwd": N * S * M * D * e + pts * 3 * e + N * Lq * M * D * e,
                    "gather": N * S * M * D * e + N * Lq * M * D * e + pts * 6 * e,
-                   "scatter": pts * 3 * e + N * Lq * M * D * e + N * S * M * D * 4}
+                   "scatter": pts * 3 * e + N * Lq * M * D * e + N * S * M * D * (4 if _native.grad_value_dtype(leaves[0], c["shapes"], Lq, L, P) == torch.float32 else e)}
             dv = [x.detach() for x in leaves]
             out = torch.empty((N, Lq, M * D), dtype=dtype, device=device)
-            gv = torch.empty(c["value"].shape, dtype=_native.acc_dtype(dtype), device=device)
+            gv = torch.empty(c["value"].shape, dtype=_native.grad_value_dtype(dv[0], c["shapes"], Lq, L, P), device=device)
             gl, ga = torch.empty_like(c["loc"]), torch.empty_like(c["aw"])
             ws = _native.bwd_workspace(device, N, Lq, M, L)
             t = {"fwd": _event_ms(lambda: _native.forward(dv[0], c["shapes"], c["lsi"], dv[1], dv[2], out), reps)}
@@ -285,7 +286,7 @@ def other_configs(args, device):
                     load = _native.load()
                     rc = load.msda_backward(_native.dtype_code(dtype), dv[0].data_ptr(), c["shapes"].data_ptr(), c["lsi"].data_ptr(),
                                             dv[1].data_ptr(), dv[2].data_ptr(), c["grad_out"].data_ptr(), N, S, M, D, L, Lq, P,
-                                            gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), ws.numel() * 4, None,
+                                            gv.data_ptr(), _native.dtype_code(gv.dtype), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), ws.numel() * 4, None,
                                             _native.shapes_hint(c["shapes"]), torch.cuda.current_stream().cuda_stream)
                     assert rc == 0, load.msda_last_error()
                 t[key] = _event_ms(bwd, reps)
@@ -453,7 +454,7 @@ def main():
         from devis_amd import _native
         stream = torch.cuda.current_stream()
         out = torch.empty((args.clips * T, q, M * D), dtype=dtype, device=device)
-        acc = _native.acc_dtype(dtype)
+        acc = _native.grad_value_dtype(b["value"], b["shapes"], q, L, P, clips=args.clips, window=W, Pt=P)   # fp32, or the 16-bit storage type
         gv = torch.zeros(b["value"].shape, dtype=acc, device=device)
         gl_c, ga_c = torch.empty_like(b["loc_c"]), torch.empty_like(b["aw_c"])
         gl_t, ga_t = torch.empty_like(b["loc_t"]), torch.empty_like(b["aw_t"])
@@ -496,7 +497,7 @@ def main():
         os.environ.pop("MSDA_ENABLE_HOOKS")
         _native.reload_knobs()
         e = b["value"].element_size()
-        ab = algorithmic_bytes(args, e)
+        ab = algorithmic_bytes(args, e, gv.element_size())
         kernels = {
             fwd_name: (fwd_ms, fwd_med, ab["fwd"]),
             gat_name + " (grad_loc/grad_attn gather pass)": (gat_ms, gat_med, ab["bwd_gather"]),

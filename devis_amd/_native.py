@@ -11,7 +11,7 @@ import torch
 
 from . import build as _build
 
-MSDA_ABI_VERSION = 9
+MSDA_ABI_VERSION = 10
 BWD_WORKSPACE_BYTES = 64
 _DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.float16: 3}
 
@@ -19,7 +19,7 @@ _DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.floa
 EXPORTED_SYMBOLS = (
     "msda_version", "msda_last_error", "msda_forward", "msda_backward",
     "msda_temporal_forward", "msda_temporal_backward", "msda_backward_workspace_bytes",
-    "msda_prep_forward", "msda_prep_backward", "msda_reload_knobs", "msda_last_route", "msda_mask_rows",
+    "msda_prep_forward", "msda_prep_backward", "msda_reload_knobs", "msda_last_route", "msda_mask_rows", "msda_grad_value_dtype",
 )
 
 _lib = None
@@ -53,13 +53,15 @@ def load():
         lib.msda_forward.restype = _ci
         lib.msda_forward.argtypes = [_ci] + [_vp] * 5 + [_ci] * 7 + [_vp, _vp, _vp, _vp]
         lib.msda_backward.restype = _ci
-        lib.msda_backward.argtypes = [_ci] + [_vp] * 6 + [_ci] * 7 + [_vp] * 4 + [ctypes.c_longlong, _vp, _vp, _vp]
+        lib.msda_backward.argtypes = [_ci] + [_vp] * 6 + [_ci] * 7 + [_vp, _ci] + [_vp] * 3 + [ctypes.c_longlong, _vp, _vp, _vp]
+        lib.msda_grad_value_dtype.restype = _ci
+        lib.msda_grad_value_dtype.argtypes = [_ci] * 11 + [_vp]
         lib.msda_backward_workspace_bytes.restype = ctypes.c_longlong
         lib.msda_backward_workspace_bytes.argtypes = [_ci] * 4
         lib.msda_temporal_forward.restype = _ci
         lib.msda_temporal_forward.argtypes = [_ci] + [_vp] * 8 + [_ci] * 10 + [_vp, _vp, _vp, _vp]
         lib.msda_temporal_backward.restype = _ci
-        lib.msda_temporal_backward.argtypes = [_ci] + [_vp] * 9 + [_ci] * 10 + [_vp] * 6 + [ctypes.c_longlong, _vp, _vp, _vp]
+        lib.msda_temporal_backward.argtypes = [_ci] + [_vp] * 9 + [_ci] * 10 + [_vp, _ci] + [_vp] * 5 + [ctypes.c_longlong, _vp, _vp, _vp]
         lib.msda_prep_forward.restype = _ci
         lib.msda_prep_forward.argtypes = [_ci] + [_vp] * 7 + [ctypes.c_longlong] + [_ci] * 6 + [ctypes.c_longlong] + [_vp] * 5
         lib.msda_last_route.restype = ctypes.c_char_p
@@ -95,8 +97,24 @@ def dtype_code(dtype):
 
 
 def acc_dtype(dtype):
-    """dtype of the grad_value accumulation buffer (include/msda.h)."""
+    """Arithmetic type of a storage dtype: what grad_value buffers hold unless :func:`grad_value_dtype` allows the storage type."""
     return torch.float64 if dtype == torch.float64 else torch.float32
+
+
+_CODE_DTYPE = {v: k for k, v in _DTYPE_CODE.items()}
+
+
+def grad_value_dtype(value, shapes, Lq, L, Pc, clips=None, window=0, Pt=1):
+    """torch dtype the grad_value buffer of a backward call on ``value [G, S, M, D]`` should have (include/msda.h
+    msda_grad_value_dtype): the 16-bit storage type itself when the owner-computes scatter will write it -- no fp32
+    buffer and no conversion pass -- else the arithmetic type."""
+    G, S, M, D = value.shape
+    clips = G if clips is None else clips
+    if value.dtype not in (torch.bfloat16, torch.float16) or G == 0 or clips == 0:
+        return acc_dtype(value.dtype)
+    code = load().msda_grad_value_dtype(dtype_code(value.dtype), clips, G // clips, window, S, M, D, L, Lq, Pc, Pt,
+                                        shapes_hint(shapes))
+    return _CODE_DTYPE[code]
 
 
 def _check(rc, what):
@@ -179,7 +197,7 @@ def backward(value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_a
         ws = bwd_workspace(value.device, N, Lq, M, L)
         rc = load().msda_backward(dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(aw),
                                   _p(grad_out), N, S, M, D, L, Lq, P,
-                                  _p(grad_value), _p(grad_loc), _p(grad_aw), _p(ws), ws.numel() * 4,
+                                  _p(grad_value), dtype_code(grad_value.dtype), _p(grad_loc), _p(grad_aw), _p(ws), ws.numel() * 4,
                                   value_strides(value), shapes_hint(shapes), _stream(value))
     _check(rc, "msda_backward")
 
@@ -210,7 +228,7 @@ def temporal_backward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, grad_o
         rc = load().msda_temporal_backward(
             dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(ftab), _p(loc_c), _p(aw_c),
             _p(loc_t), _p(aw_t), _p(grad_out), clips, frames, window, S, M, D, L, Lq, Pc, Pt,
-            _p(grad_value), _p(gloc_c), _p(gaw_c), _p(gloc_t), _p(gaw_t), _p(ws), ws.numel() * 4,
+            _p(grad_value), dtype_code(grad_value.dtype), _p(gloc_c), _p(gaw_c), _p(gloc_t), _p(gaw_t), _p(ws), ws.numel() * 4,
             value_strides(value, frames), shapes_hint(shapes), _stream(value))
     _check(rc, "msda_temporal_backward")
 

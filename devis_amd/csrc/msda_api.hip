@@ -219,6 +219,23 @@ bool rs_fits(const Params &p, int esz)
            pmax * pmax * p.L < 65536;         // the kernels take a point's level as (k * ceil(2^16 / P)) >> 16
 }
 
+// grad_value may be written in the 16-bit STORAGE type (include/msda.h, msda_grad_value_dtype) when the owner-computes
+// scatter will produce it: that kernel overwrites every pixel exactly once from fp32 registers.  Every other route
+// accumulates into grad_value (LDS-atomic flush aside, float atomics) and needs the arithmetic type.  Levels wider than a
+// band take that kernel's float-atomic branch, so the host copy of the shapes must be there and say they do not occur.
+bool storage_typed_grad_value_ok(int dtype, const Params &p)
+{
+    if (dtype != MSDA_BF16 && dtype != MSDA_F16) return false;
+    if (knobs().force_generic || knobs().bwd_cull == 2) return false;
+    if (!owner_scatter_applicable(p, 2) || !p.shapes_host) return false;
+    for (int l = 0; l < p.L; ++l)
+        if (p.shapes_host[2 * l + 1] > kOwnPix || p.shapes_host[2 * l + 1] <= 0) return false;
+    // the shape conditions of fast_path_takes (pointer alignment is checked at the call: a mismatch is an error there)
+    if (p.D % 8 || (int64_t)p.frames * p.S * p.M * p.D >= 0x7fffffffLL) return false;
+    if (tile_lds_bytes(kWave / (p.D / 8), p.LA + p.LB, true) > 60 * 1024) return false;
+    return true;
+}
+
 // Launches the forward, or the backward's gather pass + scatter, on the tile / resident-slab / scatter kernels.
 int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
 {
@@ -252,6 +269,7 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
         return launch_fwd_tile(dtype, G, p, (unsigned)blocks, lds, stream);
     }
     if (!scatter_applicable(p)) {
+        if (p.gv_storage) return fail(MSDA_ERR_ARG, "msda backward: this call needs grad_value in the arithmetic type (see msda_grad_value_dtype)%s");
         if (hipMemsetAsync(p.grad_value, 0, (size_t)p.groups * p.S * p.M * p.D * sizeof(float), stream) != hipSuccess)
             return fail(MSDA_ERR_HIP, "msda backward: hipMemsetAsync(grad_value) failed%s");
         return launch_bwd_tile(dtype, G, true, p, (unsigned)blocks, lds, stream);
@@ -289,13 +307,14 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
     grid -= grid % 8;                            // multiple of the XCD count: item % M stays put
     if (owner_scatter_applicable(p, esz) && (p.cull_points || !p.bbox)) {
         // owner-computes scatter: no float atomics; pixels outside its bands are zero-filled first
-        rc = launch_zero_unowned(p, kOwnPix * p.D, stream);
+        rc = launch_zero_unowned(p, kOwnPix * p.D, p.gv_storage ? 2 : 4, stream);
         if (rc) return rc;
-        return launch_scatter_grp(dtype, p, grid, knobs().scatter_dbg & 255, stream);
+        return launch_scatter_grp(dtype, p.gv_storage != 0, p, grid, knobs().scatter_dbg & 255, stream);
     }
+    if (p.gv_storage) return fail(MSDA_ERR_ARG, "msda backward: this call needs grad_value in the arithmetic type (see msda_grad_value_dtype)%s");
     // LDS-atomic scatter: 144 KiB of 8-byte accumulators per workgroup
     const int cap_bytes = knobs().scatter_lds_kb * 1024;
-    rc = launch_zero_unowned(p, cap_bytes / 8, stream);
+    rc = launch_zero_unowned(p, cap_bytes / 8, 4, stream);
     if (rc) return rc;
     return launch_scatter_lds(dtype, G, p, grid, cap_bytes, knobs().scatter_dbg, stream);
 }
@@ -338,7 +357,20 @@ int run(int dtype, const Params &p_in, bool bwd, hipStream_t stream)
                    (knobs().dbg & 128) == 0;                  // (measurement: MSDA_DBG=128 keeps the narrow loads)
     if (p.groups == 0 || p.Lq == 0) return MSDA_OK;
     if (!knobs().force_generic && fast_path_takes(dtype, p, bwd)) return launch_fast(dtype, p, bwd, stream);
+    if (p.gv_storage) return fail(MSDA_ERR_ARG, "msda backward: this call needs grad_value in the arithmetic type (see msda_grad_value_dtype)%s");
     return launch_generic(dtype, p, bwd, stream);
+}
+
+// `grad_value_dtype` of the backward entry points: the arithmetic type, or the 16-bit storage type where allowed.
+int set_grad_value_dtype(int dtype, int grad_value_dtype, Params &p)
+{
+    const int arith = dtype == MSDA_F64 ? MSDA_F64 : MSDA_F32;
+    p.gv_storage = 0;
+    if (grad_value_dtype == arith) return MSDA_OK;
+    if (grad_value_dtype != dtype || !storage_typed_grad_value_ok(dtype, p))
+        return fail(MSDA_ERR_ARG, "msda backward: grad_value_dtype must be what msda_grad_value_dtype returns for this call%s");
+    p.gv_storage = 1;
+    return MSDA_OK;
 }
 
 int check_common(const void *value, const int64_t *shapes, const int64_t *lsi, int groups, int S,
@@ -362,11 +394,11 @@ int set_value_strides(Params &p, const int64_t *vs)
     return MSDA_OK;
 }
 
-int zero_grad_value(int dtype, void *grad_value, int groups, int S, int M, int D, void *stream)
+int zero_grad_value(int grad_value_dtype, void *grad_value, int groups, int S, int M, int D, void *stream)
 {
-    if (dtype < MSDA_F32 || dtype > MSDA_F16) return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
+    if (grad_value_dtype < MSDA_F32 || grad_value_dtype > MSDA_F16) return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
     if (!grad_value) return fail(MSDA_ERR_ARG, "msda backward: null grad_value%s");
-    const size_t bytes = (size_t)groups * S * M * D * (dtype == MSDA_F64 ? sizeof(double) : sizeof(float));
+    const size_t bytes = (size_t)groups * S * M * D * (size_t)elem_bytes(grad_value_dtype);
     if (hipMemsetAsync(grad_value, 0, bytes, static_cast<hipStream_t>(stream)) != hipSuccess)
         return fail(MSDA_ERR_HIP, "msda backward: hipMemsetAsync(grad_value) failed%s");
     return MSDA_OK;
@@ -427,6 +459,23 @@ long long msda_backward_workspace_bytes(int batch, int num_query, int num_heads,
 
 const char *msda_last_error(void) { return g_err; }
 
+int msda_grad_value_dtype(int dtype, int clips, int frames, int window, int spatial_size, int num_heads, int channels,
+                          int num_levels, int num_query, int num_curr_point, int num_temp_point,
+                          const int64_t *spatial_shapes_host)
+{
+    const int arith = dtype == MSDA_F64 ? MSDA_F64 : MSDA_F32;
+    if (clips <= 0 || frames <= 0 || window < 0 || spatial_size <= 0 || num_heads <= 0 || channels <= 0 || num_levels <= 0 ||
+        num_query <= 0 || num_curr_point <= 0)
+        return arith;
+    Params p;
+    memset(&p, 0, sizeof(p));
+    p.groups = clips * frames; p.frames = frames; p.window = window;
+    p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
+    p.LA = num_levels; p.PA = num_curr_point; p.LB = window * num_levels; p.PB = window > 0 ? num_temp_point : 1;
+    p.shapes_host = spatial_shapes_host;
+    return storage_typed_grad_value_ok(dtype, p) ? dtype : arith;
+}
+
 int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,
                  const int64_t *level_start_index, const void *sampling_loc, const void *attn_weight,
                  int batch, int spatial_size, int num_heads, int channels, int num_levels,
@@ -458,7 +507,7 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
                   const void *attn_weight, const void *grad_out,
                   int batch, int spatial_size, int num_heads, int channels, int num_levels,
                   int num_query, int num_point,
-                  void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
+                  void *grad_value, int grad_value_dtype, void *grad_sampling_loc, void *grad_attn_weight,
                   void *workspace, long long workspace_bytes, const int64_t *value_strides,
                   const int64_t *spatial_shapes_host, void *stream)
 {
@@ -467,7 +516,7 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
                           channels, num_levels, num_query);
     if (rc) return rc;
     if (batch == 0) return MSDA_OK;
-    if (num_query == 0) return zero_grad_value(dtype, grad_value, batch, spatial_size, num_heads, channels, stream);
+    if (num_query == 0) return zero_grad_value(grad_value_dtype, grad_value, batch, spatial_size, num_heads, channels, stream);
     if (!sampling_loc || !attn_weight || !grad_out || !grad_value || !grad_sampling_loc ||
         !grad_attn_weight || num_point <= 0)
         return fail(MSDA_ERR_ARG, "msda_backward: null pointer or non-positive num_point%s");
@@ -482,6 +531,8 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
     p.LA = num_levels; p.PA = num_point; p.LB = 0; p.PB = 1;
     p.shapes_host = spatial_shapes_host;
     rc = set_value_strides(p, value_strides);
+    if (rc) return rc;
+    rc = set_grad_value_dtype(dtype, grad_value_dtype, p);
     if (rc) return rc;
     return run(dtype, p, true, static_cast<hipStream_t>(stream));
 }
@@ -525,7 +576,7 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
                            int clips, int frames, int window, int spatial_size, int num_heads,
                            int channels, int num_levels, int num_query,
                            int num_curr_point, int num_temp_point,
-                           void *grad_value, void *grad_loc_curr, void *grad_aw_curr,
+                           void *grad_value, int grad_value_dtype, void *grad_loc_curr, void *grad_aw_curr,
                            void *grad_loc_temp, void *grad_aw_temp, void *workspace, long long workspace_bytes,
                            const int64_t *value_strides, const int64_t *spatial_shapes_host, void *stream)
 {
@@ -537,7 +588,7 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
         return fail(MSDA_ERR_ARG, "msda_temporal_backward: bad frames/window/points%s");
     if (clips == 0) return MSDA_OK;
     if (num_query == 0)
-        return zero_grad_value(dtype, grad_value, clips * frames, spatial_size, num_heads, channels, stream);
+        return zero_grad_value(grad_value_dtype, grad_value, clips * frames, spatial_size, num_heads, channels, stream);
     if (!loc_curr || !aw_curr || !grad_out || !grad_value || !grad_loc_curr || !grad_aw_curr ||
         (window > 0 && (!frame_table || !loc_temp || !aw_temp || !grad_loc_temp || !grad_aw_temp)))
         return fail(MSDA_ERR_ARG, "msda_temporal_backward: null pointer argument%s");
@@ -554,6 +605,8 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
     p.LB = window * num_levels; p.PB = window > 0 ? num_temp_point : 1;
     p.shapes_host = spatial_shapes_host;
     rc = set_value_strides(p, value_strides);
+    if (rc) return rc;
+    rc = set_grad_value_dtype(dtype, grad_value_dtype, p);
     if (rc) return rc;
     return run(dtype, p, true, static_cast<hipStream_t>(stream));
 }

@@ -249,6 +249,7 @@ struct Params {
     int wide_stores;            // bwd: the four gradient arrays are 16-byte aligned (resident-slab gather pass: whole-row stores)
     int wide_loads;             // loc / attn arrays are 16-byte aligned (resident-slab kernels: whole-row loads)
     int dbg;                    // measurement hooks (MSDA_DBG env), 0 in production
+    int gv_storage;             // bwd: grad_value is in the STORAGE type (16-bit), not the arithmetic type (owner-computes scatter only)
 };
 
 struct Level { int H, W, start, pad; };   // start = first pixel of the level inside the CLIP slab
@@ -420,10 +421,10 @@ int launch_bwd_tile(int dtype, int G, bool atomics, const Params &p, unsigned bl
 int launch_fwd_rs(int dtype, int nt, const Params &p, int parts, unsigned grid, hipStream_t stream);
 int launch_bwd_rs(int dtype, const Params &p, int parts, unsigned grid, hipStream_t stream);
 // msda_scatter.hip: grad_value
-int launch_zero_unowned(const Params &p, int cap_slots, hipStream_t stream);
+int launch_zero_unowned(const Params &p, int cap_slots, int grad_value_elem_bytes, hipStream_t stream);
 int launch_cull_summary(const Params &p, hipStream_t stream);
 int launch_scatter_lds(int dtype, int G, const Params &p, unsigned grid, int cap_bytes, int dbg, hipStream_t stream);
-int launch_scatter_grp(int dtype, const Params &p, unsigned grid, int dbg, hipStream_t stream);
+int launch_scatter_grp(int dtype, bool storage_typed_grad_value, const Params &p, unsigned grid, int dbg, hipStream_t stream);
 // msda_generic.hip: any-shape kernels, the modules' fused pre-op pass, the padding-mask pass
 int launch_generic(int dtype, const Params &p, bool bwd, hipStream_t stream);
 int launch_prep(int dtype, const PrepParams &p, bool bwd, hipStream_t stream);

@@ -449,16 +449,21 @@ constexpr unsigned kOwnNil = 0xffffffffu;
 // entries are one 128-byte block, so the row of an entry at LDS address A is (A - entries) >> 7.
 constexpr int kGrpList = 3 * kOwnThreads;       // survivor list entries (groups)
 template <typename T> constexpr int grp_chunk() { return sizeof(T) == 4 ? MSDA_GRP_F32 : MSDA_GRP_16; }       // groups per chunk
+// (rows are staged as fp32 for every storage type: 128 bytes per group)
 template <typename T> constexpr int grp_lds_bytes()
 {
-    return grp_chunk<T>() * 32 * (int)sizeof(T) + 32 + 16 * grp_chunk<T>() * 8 + kOwnPix * 4 + kGrpList * 4;
+    return grp_chunk<T>() * 128 + 32 + 16 * grp_chunk<T>() * 8 + kOwnPix * 4 + kGrpList * 4;
 }
 
-template <typename T>
+// T = storage type of loc / attn / grad_out; GV = type of grad_value as written (float, or T: include/msda.h grad_value_dtype).
+// The grad_out rows are staged in LDS as FP32 whatever T is: a 16-bit row would have to be unpacked once per list entry in
+// the walk (16 entries read each row: measured 0.29 ms of walk for bf16 against 0.185 for fp32 on the bench workload),
+// now it is converted once, on its way in (4-byte types keep the LDS-DMA; 2-byte types go through registers).
+template <typename T, typename GV>
 __global__ void __launch_bounds__(kOwnThreads)
 msda_bwd_value_grp_kernel(const Params p, int dbg)
 {
-    constexpr int D = 32, kRowB = D * (int)sizeof(T);          // bytes of one staged grad_out row
+    constexpr int D = 32, kRowB = D * 4;                        // bytes of one staged grad_out row (fp32)
     constexpr int kOwnChunk = grp_chunk<T>();                   // groups per chunk
     constexpr int kPasses = (4 * kOwnChunk + kOwnThreads - 1) / kOwnThreads;
     constexpr bool kHalf = sizeof(T) == 2;
@@ -505,8 +510,8 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
     // channels [4c, 4c+4) of both 64-byte halves of the row (odd quads read the second half first: LDS banks, as
     // in the forward); 2-byte types: the 8 channels [8c, 8c+8) = one 16-byte slice of the 64-byte row.
     const int Q = tid / 4, cq = tid & 3, hsw = Q & 1;
-    const int off1 = kHalf ? cq * 16 : cq * 16 + hsw * 64;
-    const int ch1 = kHalf ? cq * 8 : off1 / 4, ch2 = kHalf ? cq * 8 + 4 : (off1 ^ 64) / 4;     // channels of acc[0..3] / acc[4..7]
+    const int off1 = cq * 16 + hsw * 64;
+    const int ch1 = off1 / 4, ch2 = (off1 ^ 64) / 4;           // channels of acc[0..3] / acc[4..7]
     const unsigned ents_lds = lds_addr(ents);
 
     for (int64_t it = blockIdx.x;; it += gridDim.x) {
@@ -553,8 +558,8 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         int sfs = 0;
         while (npix > 0 && (npix << (sfs + 1)) <= kOwnQuads && sfs < 4) ++sfs;
         const int SF = 1 << sfs, nvpix = npix << sfs;
-        float *gmap = static_cast<float *>(p.grad_value) +
-                      (((int64_t)clip * p.frames + f) * p.S + s_lsi[l]) * MD + m * D;     // pixel (0, 0) of the level, head m
+        GV *gmap = static_cast<GV *>(p.grad_value) +
+                   (((int64_t)clip * p.frames + f) * p.S + s_lsi[l]) * MD + m * D;        // pixel (0, 0) of the level, head m
 
         // sources that read frame f: the current-frame points of frame f, then every temporal slot (t, w) with
         // frame_table[t, w] == f; per source the first culling-table entry, first loc/attn element, first query row
@@ -609,13 +614,16 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                 }
             }
         };
-        // ---- grad_out rows -> LDS, one per GROUP: wave w stages rows [RPWV w, RPWV (w + 1)) of the chunk
+        // ---- grad_out rows -> LDS (fp32), one per GROUP: wave w stages rows [RPWV w, RPWV (w + 1)) of the chunk.  4-byte types:
+        // LDS-DMA, 8 lanes x 16 bytes per row.  2-byte types: 4 lanes x 16 bytes per row into registers (stage_rows), converted
+        // and written as 2 x 16 bytes per lane once they have landed (stage_rows_finish, before the chunk's barrier).
+        constexpr int RPWV = kOwnChunk / (kOwnThreads / kWave);   // rows per wave
+        constexpr int LPR = kHalf ? 4 : 8, HPI = kWave / LPR;     // lanes per row, rows per instruction
+        static_assert(kOwnChunk % (kOwnThreads / kWave) == 0 && RPWV % HPI == 0, "rows per wave");
+        u32x4 raw_rows[kHalf ? RPWV / HPI : 1];
         auto stage_rows = [&](int base, int n) {
             if (direct || (dbg & 4)) return;
-            constexpr int LPR = kRowB / 16, HPI = kWave / LPR;      // lanes per row, rows per instruction
             const T *go = static_cast<const T *>(p.grad_out) + m * D + (lane % LPR) * (16 / (int)sizeof(T));
-            constexpr int RPWV = kOwnChunk / (kOwnThreads / kWave);   // rows per wave
-            static_assert(kOwnChunk % (kOwnThreads / kWave) == 0 && RPWV % HPI == 0, "rows per wave");
 #pragma unroll
             for (int i = 0; i < RPWV / HPI; ++i) {
                 const int r0w = wave * RPWV + HPI * i;
@@ -623,11 +631,31 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                     const unsigned e = list[base + min(r0w + lane / LPR, n - 1)];
                     const int qr = s_src_q0[e >> 26] + (int)(e & 0x3fffffu);
                     const T *gp = go + (int64_t)qr * MD;
+                    if constexpr (kHalf) {
+                        raw_rows[i] = *reinterpret_cast<const u32x4 *>(gp);
+                    } else {
 #if defined(__HIP_DEVICE_COMPILE__)
-                    __builtin_amdgcn_global_load_lds(gp, (__attribute__((address_space(3))) void *)(rows + r0w * kRowB), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds(gp, (__attribute__((address_space(3))) void *)(rows + r0w * kRowB), 16, 0, 0);
 #else
-                    (void)gp;
+                        (void)gp;
 #endif
+                    }
+                }
+            }
+        };
+        auto stage_rows_finish = [&](int n) {
+            if constexpr (kHalf) {
+                if (direct || (dbg & 4)) return;
+#pragma unroll
+                for (int i = 0; i < RPWV / HPI; ++i) {
+                    const int r0w = wave * RPWV + HPI * i;
+                    if (r0w < n) {
+                        float v[8];
+                        unpack_raw(static_cast<const T *>(nullptr), raw_rows[i], v);
+                        float4 *dst = reinterpret_cast<float4 *>(rows + (r0w + lane / LPR) * kRowB + (lane % LPR) * 32);
+                        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+                        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+                    }
                 }
             }
         };
@@ -652,8 +680,10 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         if (own[c]) {
-                            float *dst = gmap + (int64_t)(pix00 + dpix[c]) * MD;
-                            for (int ch = 0; ch < D; ++ch) atomic_accumulate(dst + ch, wgt[c] * Store<T>::get(gr + ch));
+                            if constexpr (std::is_same<GV, float>::value) {      // (host: levels wider than a band only with fp32 grad_value)
+                                float *dst = gmap + (int64_t)(pix00 + dpix[c]) * MD;
+                                for (int ch = 0; ch < D; ++ch) atomic_accumulate(dst + ch, wgt[c] * Store<T>::get(gr + ch));
+                            }
                         }
                 } else if (!(dbg & 2)) {
 #pragma unroll
@@ -678,14 +708,9 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                     const uint2 en = *reinterpret_cast<const uint2 *>(lds_raw + (e - lds_addr(lds_raw)));
                     const float w = __uint_as_float(en.x);
                     const unsigned char *r = rows + ((e - ents_lds) >> 7) * kRowB;
-                    float v[8];
-                    if constexpr (kHalf) {
-                        Store<T>::load(reinterpret_cast<const T *>(r + off1), v);
-                    } else {
-                        const float4 v1 = *reinterpret_cast<const float4 *>(r + off1);
-                        const float4 v2 = *reinterpret_cast<const float4 *>(r + (off1 ^ 64));
-                        v[0] = v1.x; v[1] = v1.y; v[2] = v1.z; v[3] = v1.w; v[4] = v2.x; v[5] = v2.y; v[6] = v2.z; v[7] = v2.w;
-                    }
+                    const float4 v1 = *reinterpret_cast<const float4 *>(r + off1);
+                    const float4 v2 = *reinterpret_cast<const float4 *>(r + (off1 ^ 64));
+                    const float v[8] = {v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
 #pragma unroll
                     for (int c = 0; c < 8; ++c) acc[s][c] = fmaf(w, v[c], acc[s][c]);
                     e = en.y;
@@ -712,6 +737,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             for (int j = 0; j < kPasses; ++j)
                 if (j == 0 || n > j * (kOwnThreads / 4)) taps_link(j, hact[j], hx[j], hy[j], ha[j], hq[j]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's rows have landed
+            stage_rows_finish(n);
             __syncthreads();
             if (nn > 0) fetch_chunk(nbase, nn);
             walk();
@@ -815,16 +841,24 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             bcur = bnext;
         }
         // ---- owners store their pixels: grad_value is overwritten, every pixel of the band exactly once
+        auto put4 = [&](GV *dst, float a, float b, float c, float d) {      // 4 consecutive channels, non-temporal
+            if constexpr (std::is_same<GV, float>::value) {
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store((f32x4){a, b, c, d}, reinterpret_cast<f32x4 *>(dst));
+            } else {
+                const float v[4] = {a, b, c, d};
+                SlabStore<GV>::store(dst, v);
+            }
+        };
         if (!direct && SF == 1) {
-            float *gband = gmap + (int64_t)r0 * W * MD;
+            GV *gband = gmap + (int64_t)r0 * W * MD;
 #pragma unroll
             for (int s = 0; s < kOwnSlots; ++s) {
                 const int pix = s * kOwnQuads + Q;
                 if (pix < npix) {
-                    float *o = gband + (int64_t)pix * MD;
-                    typedef float f32x4 __attribute__((ext_vector_type(4)));
-                    __builtin_nontemporal_store((f32x4){acc[s][0], acc[s][1], acc[s][2], acc[s][3]}, reinterpret_cast<f32x4 *>(o + ch1));
-                    __builtin_nontemporal_store((f32x4){acc[s][4], acc[s][5], acc[s][6], acc[s][7]}, reinterpret_cast<f32x4 *>(o + ch2));
+                    GV *o = gband + (int64_t)pix * MD;
+                    put4(o + ch1, acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
+                    put4(o + ch2, acc[s][4], acc[s][5], acc[s][6], acc[s][7]);
                 }
             }
         } else if (!direct) {
@@ -836,7 +870,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                 *reinterpret_cast<float4 *>(part + Q * D + ch2) = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
             }
             __syncthreads();
-            float *gband = gmap + (int64_t)r0 * W * MD;
+            GV *gband = gmap + (int64_t)r0 * W * MD;
             for (int i = tid; i < npix * (D / 4); i += kOwnThreads) {
                 const int pix = i / (D / 4), c4 = (i - pix * (D / 4)) * 4;
                 float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -844,7 +878,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                     const float4 t4 = *reinterpret_cast<const float4 *>(part + ((pix << sfs) + u) * D + c4);
                     sum.x += t4.x; sum.y += t4.y; sum.z += t4.z; sum.w += t4.w;
                 }
-                *reinterpret_cast<float4 *>(gband + (int64_t)pix * MD + c4) = sum;
+                put4(gband + (int64_t)pix * MD + c4, sum.x, sum.y, sum.z, sum.w);
             }
         }
         __syncthreads();
@@ -855,7 +889,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
 // do not own -- levels that take the float-atomic branch, or rows of `value` outside every level when
 // spatial_shapes does not tile [0, S) -- are zero-filled here, so that callers need not memset grad_value.
 __global__ void __launch_bounds__(256)
-msda_zero_unowned_kernel(const Params p, int cap_slots)
+msda_zero_unowned_kernel(const Params p, int cap_slots, int gv_bytes)
 {
     const int MD = p.M * p.D;
     const int64_t total = (int64_t)p.groups * p.S;
@@ -867,8 +901,9 @@ msda_zero_unowned_kernel(const Params p, int cap_slots)
             if (s >= start && s < start + H * W) { owned = cap_slots / max((int64_t)1, W * p.D) > 0; break; }
         }
         if (owned) continue;
-        float *dst = static_cast<float *>(p.grad_value) + idx * MD;
-        for (int c = 0; c < MD; ++c) dst[c] = 0.f;
+        // (grad_value elements are 4 or 2 bytes: include/msda.h grad_value_dtype; MD * gv_bytes is a multiple of 4)
+        unsigned *dst = reinterpret_cast<unsigned *>(static_cast<char *>(p.grad_value) + idx * MD * gv_bytes);
+        for (int c = 0; c < MD * gv_bytes / 4; ++c) dst[c] = 0u;
     }
 }
 
@@ -898,23 +933,25 @@ int scatter_lds_g(int G, const Params &p, unsigned grid, int cap_bytes, int dbg,
     }
 }
 
-template <typename T>
+template <typename T, typename GV>
 int scatter_grp(const Params &p, unsigned grid, int dbg, hipStream_t stream)
 {
     static LdsGrant granted;
-    if (const int rc = grant_lds(reinterpret_cast<const void *>(&msda_bwd_value_grp_kernel<T>), (size_t)grp_lds_bytes<T>(), granted,
+    const auto kern = &msda_bwd_value_grp_kernel<T, GV>;
+    if (const int rc = grant_lds(reinterpret_cast<const void *>(kern), (size_t)grp_lds_bytes<T>(), granted,
                                  "the group-granular owner-computes scatter kernel")) return rc;
-    hipLaunchKernelGGL((msda_bwd_value_grp_kernel<T>), dim3(grid), dim3(kOwnThreads), (size_t)grp_lds_bytes<T>(), stream, p, dbg);
-    return check_launch("msda backward (owner-computes scatter kernel, group-granular)");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kOwnThreads), (size_t)grp_lds_bytes<T>(), stream, p, dbg);
+    return check_launch(std::is_same<GV, float>::value ? "msda backward (owner-computes scatter kernel, group-granular)"
+                                                       : "msda backward (owner-computes scatter kernel, group-granular, grad_value in the storage type)");
 }
 
 }  // namespace
 
-int launch_zero_unowned(const Params &p, int cap_slots, hipStream_t stream)
+int launch_zero_unowned(const Params &p, int cap_slots, int grad_value_elem_bytes, hipStream_t stream)
 {
     const int64_t rows = (int64_t)p.groups * p.S;
     const unsigned zb = (unsigned)((rows + 255) / 256 < 16384 ? (rows + 255) / 256 : 16384);
-    hipLaunchKernelGGL(msda_zero_unowned_kernel, dim3(zb), dim3(256), 0, stream, p, cap_slots);
+    hipLaunchKernelGGL(msda_zero_unowned_kernel, dim3(zb), dim3(256), 0, stream, p, cap_slots, grad_value_elem_bytes);
     return check_launch("msda backward (zero-fill of pixels outside the bands)");
 }
 
@@ -936,12 +973,12 @@ int launch_scatter_lds(int dtype, int G, const Params &p, unsigned grid, int cap
     }
 }
 
-int launch_scatter_grp(int dtype, const Params &p, unsigned grid, int dbg, hipStream_t stream)
+int launch_scatter_grp(int dtype, bool storage_typed, const Params &p, unsigned grid, int dbg, hipStream_t stream)
 {
     switch (dtype) {
-        case MSDA_F32: return scatter_grp<float>(p, grid, dbg, stream);
-        case MSDA_BF16: return scatter_grp<bf16_t>(p, grid, dbg, stream);
-        case MSDA_F16: return scatter_grp<f16_t>(p, grid, dbg, stream);
+        case MSDA_F32: return scatter_grp<float, float>(p, grid, dbg, stream);
+        case MSDA_BF16: return storage_typed ? scatter_grp<bf16_t, bf16_t>(p, grid, dbg, stream) : scatter_grp<bf16_t, float>(p, grid, dbg, stream);
+        case MSDA_F16: return storage_typed ? scatter_grp<f16_t, f16_t>(p, grid, dbg, stream) : scatter_grp<f16_t, float>(p, grid, dbg, stream);
         default: return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
     }
 }

@@ -97,14 +97,15 @@ class MSDeformAttnFunction(Function):
         value, shapes, lsi, loc, aw = ctx.saved_tensors
         grad_output = grad_output.contiguous()
         N = value.shape[0]
-        acc = _native.acc_dtype(value.dtype)
-        # all three are fully written by the library (ABI v4: no zeros_like as in cu:121; skipped points -> 0)
+        # all three are fully written by the library (ABI v4: no zeros_like as in cu:121; skipped points -> 0).  16-bit
+        # storage: grad_value comes back in the storage type where the library can write it so (ABI v10), else in fp32
         live = N > 0 and loc.shape[1] > 0
+        step = _im2col_step(N, ctx.im2col_step) if live else 0
+        acc = _native.grad_value_dtype(value[:step], shapes, loc.shape[1], loc.shape[3], loc.shape[4]) if live else value.dtype
         grad_value = (torch.empty if live else torch.zeros)(value.shape, dtype=acc, device=value.device)
         grad_loc = torch.empty_like(loc)
         grad_aw = torch.empty_like(aw)
         if live:
-            step = _im2col_step(N, ctx.im2col_step)
             for n in range(0, N, step):
                 _native.backward(value[n:n + step], shapes, lsi, loc[n:n + step], aw[n:n + step],
                                  grad_output[n:n + step], grad_value[n:n + step],
@@ -167,7 +168,9 @@ class MSDeformAttnTemporalFunction(Function):
     def backward(ctx, grad_output):
         value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t = ctx.saved_tensors
         grad_output = grad_output.contiguous()
-        acc = _native.acc_dtype(value.dtype)
+        W = ftab.shape[1]
+        acc = _native.grad_value_dtype(value, shapes, loc_c.shape[1], loc_c.shape[3], loc_c.shape[4], clips=ctx.clips,
+                                       window=W, Pt=loc_t.shape[4])
         grad_value = torch.empty(value.shape, dtype=acc, device=value.device)      # overwritten (ABI v4)
         gloc_c, gaw_c = torch.empty_like(loc_c), torch.empty_like(aw_c)
         gloc_t, gaw_t = torch.empty_like(loc_t), torch.empty_like(aw_t)

@@ -17,14 +17,16 @@
  *     backward on an autograd worker -- as in the reference).  The only process-wide state is caches
  *     keyed by HIP device id (compute-unit count, per-kernel LDS opt-in) and the test knobs below;
  *   - test / measurement knobs are environment variables (MSDA_FWD_SLAB, MSDA_BWD_MODE, ...; listed in
- *     devis_amd/csrc/msda_hip.hip at `struct Knobs`).  They are IGNORED unless MSDA_ENABLE_HOOKS=1, and
+ *     devis_amd/csrc/msda_api.hip at `struct Knobs`).  They are IGNORED unless MSDA_ENABLE_HOOKS=1, and
  *     are read once -- at the first call or when msda_reload_knobs() is called -- never on the launch path;
  *   - return value: MSDA_OK (0) or a negative msda_status; on failure msda_last_error() returns a
  *     thread-local message.  Unlike the reference (errors only printf'd,
  *     ms_deform_im2col_cuda.cuh:948-952,1321-1325) launch failures ARE reported;
  *   - `dtype` names the storage type of value / sampling_loc / attn_weight / out / grad_out /
  *     grad_sampling_loc / grad_attn_weight.  Arithmetic is fp32 for f32/bf16/f16 and fp64 for f64.
- *     `grad_value` is ALWAYS in the arithmetic type (float for f32/bf16/f16, double for f64) and is
+ *     `grad_value` is in the arithmetic type (float for f32/bf16/f16, double for f64) -- or, since ABI v10 and only
+ *     where msda_grad_value_dtype() says so, directly in the 16-bit storage type (`grad_value_dtype` of the backward
+ *     entry points: no fp32 buffer, no conversion pass over it afterwards) -- and is
  *     FULLY OVERWRITTEN (ABI v4): it need not be zeroed by the caller.  The reference zero-fills it
  *     (at::zeros_like, ms_deform_attn_cuda.cu:121) because every one of its kernels accumulates with
  *     atomics; here the LDS scatter owns and overwrites whole level-row bands, and the library zero-fills
@@ -55,7 +57,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 9
+#define MSDA_ABI_VERSION 10
 #define MSDA_BWD_WORKSPACE_BYTES 64   /* minimum device scratch of the backward entry points (ticket counters) */
 
 enum msda_dtype { MSDA_F32 = 0, MSDA_F64 = 1, MSDA_BF16 = 2, MSDA_F16 = 3 };
@@ -108,7 +110,8 @@ int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,
  * ms_deformable_col2im_gpu_kernel_* variant, ms_deform_im2col_cuda.cuh:301-920,956-1326).
  *
  *   grad_out          [N, Lq, M*D]         dtype
- *   grad_value        [N, S, M, D]         float (double for MSDA_F64); fully overwritten (need not be zeroed)
+ *   grad_value        [N, S, M, D]         grad_value_dtype: float (double for MSDA_F64), or `dtype` itself where
+ *                                          msda_grad_value_dtype() returns it; fully overwritten (need not be zeroed)
  *   grad_sampling_loc [N, Lq, M, L, P, 2]  dtype, fully overwritten (skipped points get 0)
  *   grad_attn_weight  [N, Lq, M, L, P]     dtype, fully overwritten
  *   workspace         device scratch private to this call until it completes, `workspace_bytes` long.  Its
@@ -126,9 +129,19 @@ int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes,
                   const void *attn_weight, const void *grad_out,
                   int batch, int spatial_size, int num_heads, int channels, int num_levels,
                   int num_query, int num_point,
-                  void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
+                  void *grad_value, int grad_value_dtype, void *grad_sampling_loc, void *grad_attn_weight,
                   void *workspace, long long workspace_bytes, const int64_t *value_strides,
                   const int64_t *spatial_shapes_host, void *stream);
+
+/* The msda_dtype the `grad_value` buffer of a backward call of this shape may have besides the arithmetic type (ABI v10):
+ * `dtype` itself for MSDA_BF16 / MSDA_F16 when the owner-computes scatter will write the gradient (D = 32, at most 4
+ * points per level, ...: it overwrites every pixel once from fp32 registers, so it can round on the way out; every other
+ * route accumulates into grad_value and needs float), else the arithmetic type.  Plain op: clips = batch, frames = 1,
+ * window = 0.  `spatial_shapes_host` as passed to the backward call (NULL: always the arithmetic type; it must be a true
+ * copy of the device tensor).  Passing the arithmetic type to the backward call is always valid. */
+int msda_grad_value_dtype(int dtype, int clips, int frames, int window, int spatial_size, int num_heads, int channels,
+                          int num_levels, int num_query, int num_curr_point, int num_temp_point,
+                          const int64_t *spatial_shapes_host);
 
 /* Bytes of `workspace` that enable every feature of msda_backward / msda_temporal_backward:
  * 64 (ticket counters) + rows * virtual_levels * 8 (per-point culling records) + their summaries over blocks of 64
@@ -167,8 +180,8 @@ int msda_temporal_forward(int dtype, const void *value, const int64_t *spatial_s
                           const int64_t *spatial_shapes_host, void *stream);
 
 /*
- * Fused temporal backward.  grad_value [clips*frames, S, M, D] (float / double, fully overwritten, need
- * not be zeroed): contributions of the current-frame and of every temporal slot land in it directly,
+ * Fused temporal backward.  grad_value [clips*frames, S, M, D] (grad_value_dtype as for msda_backward; fully
+ * overwritten, need not be zeroed): contributions of the current-frame and of every temporal slot land in it directly,
  * replacing the reference's index_put-add backward of value[temporal_frames].
  * The four grad_loc / grad_aw outputs have the shapes of their inputs and are fully overwritten.
  * `workspace`: as for msda_backward.
@@ -180,7 +193,7 @@ int msda_temporal_backward(int dtype, const void *value, const int64_t *spatial_
                            int clips, int frames, int window, int spatial_size, int num_heads,
                            int channels, int num_levels, int num_query,
                            int num_curr_point, int num_temp_point,
-                           void *grad_value, void *grad_loc_curr, void *grad_aw_curr,
+                           void *grad_value, int grad_value_dtype, void *grad_loc_curr, void *grad_aw_curr,
                            void *grad_loc_temp, void *grad_aw_temp, void *workspace, long long workspace_bytes,
                            const int64_t *value_strides, const int64_t *spatial_shapes_host, void *stream);
 

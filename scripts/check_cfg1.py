@@ -22,7 +22,7 @@ def run(env, dtype=torch.bfloat16, shapes=bench.PYRAMIDS["B"], N=8, reps=6):
         ws[:16].zero_()
         rc = _native.load().msda_backward(_native.dtype_code(dtype), c["value"].data_ptr(), c["shapes"].data_ptr(), c["lsi"].data_ptr(),
                                           c["loc"].data_ptr(), c["aw"].data_ptr(), c["grad_out"].data_ptr(), N, S, M, D, L, Lq, P,
-                                          gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), ws.numel() * 4, None,
+                                          gv.data_ptr(), _native.dtype_code(gv.dtype), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), ws.numel() * 4, None,
                                           _native.shapes_hint(c["shapes"]), torch.cuda.current_stream().cuda_stream)
         assert rc == 0
     for ph, key in (("1", "gather"), ("2", "scatter")):

@@ -295,7 +295,7 @@ def test_backward_without_workspace_static_schedule():
     lib = _native.load()
     rc = lib.msda_backward(0, t["value"].data_ptr(), t["shapes"].data_ptr(), t["lsi"].data_ptr(), t["loc"].data_ptr(),
                            t["aw"].data_ptr(), t["grad_out"].float().contiguous().data_ptr(), N, S, M, D, L, Lq, P,
-                           gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), None, 0, None, None,
+                           gv.data_ptr(), 0, gl.data_ptr(), ga.data_ptr(), None, 0, None, None,
                            torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     torch.cuda.synchronize()
@@ -464,7 +464,7 @@ def test_grad_value_is_overwritten(route, monkeypatch):
         N, S, M, D = v.shape
         _, Lq, _, L, P, _ = loc.shape
         rc = _native.load().msda_backward(0, v.data_ptr(), t["shapes"].data_ptr(), t["lsi"].data_ptr(), loc.data_ptr(),
-                                          aw.data_ptr(), go.data_ptr(), N, S, M, D, L, Lq, P, gv.data_ptr(),
+                                          aw.data_ptr(), go.data_ptr(), N, S, M, D, L, Lq, P, gv.data_ptr(), 0,
                                           gl.data_ptr(), ga.data_ptr(), None, 0, None, None,
                                           torch.cuda.current_stream().cuda_stream)
         assert rc == 0
@@ -581,3 +581,39 @@ def test_long_candidate_range_block_summaries(local):
     assert _maxabs(gv, ref32[1]) <= 1e-4 * max(1.0, np.abs(ref[1]).max())
     assert _maxabs(gl, ref32[2]) <= 1e-4 * max(1.0, np.abs(ref32[2]).max())
     assert _maxabs(ga, ref32[3]) <= 1e-4 * max(1.0, np.abs(ref[3]).max())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3)], ids=["bf16", "f16"])
+def test_grad_value_in_the_storage_type(dtype, tol, monkeypatch):
+    """ABI v10: for 16-bit storage the owner-computes scatter writes grad_value directly in the storage type
+    (msda_grad_value_dtype says where); the result equals the fp32 buffer of the same call rounded once.  Where another
+    route produces grad_value (D = 64 here, or the LDS-atomic scatter) the query answers fp32, and a storage-typed buffer
+    is refused instead of being filled wrongly."""
+    from devis_amd import _native
+    d = round_to(make_inputs(31, 2, 8, 32, 77, [(12, 20), (6, 10), (3, 5)], 4, "wide", np.float64, value_scale=1.0), dtype)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in d.items()}
+    v, loc, aw, go = (t[k].to(dtype) for k in ("value", "loc", "aw", "grad_out"))
+    assert _native.grad_value_dtype(v, t["shapes"], 77, 3, 4) == dtype
+    ref = oracle_fwd_bwd(d, np.float64)
+    outs = {}
+    for gdt in (torch.float32, dtype):
+        gv = torch.full(v.shape, float("nan"), dtype=gdt, device=DEV)
+        gl, ga = torch.empty_like(loc), torch.empty_like(aw)
+        _native.backward(v, t["shapes"], t["lsi"], loc, aw, go, gv, gl, ga)
+        torch.cuda.synchronize()
+        assert ("storage type" in _native.last_route()) == (gdt == dtype), _native.last_route()
+        outs[gdt] = gv
+        assert _maxabs(gv.double().cpu().numpy(), ref[1]) <= tol * max(1.0, np.abs(ref[1]).max())
+    # the same sums (up to the order of a pixel's terms, which is list order: the last bits of an fp32 sum vary from run to
+    # run), rounded once on the way out: within one unit of the storage type's last place
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    a, b = outs[torch.float32].double(), outs[dtype].double()
+    assert float(((a - b).abs() - ulp * a.abs()).max()) <= 1e-6
+    # other routes: fp32 only
+    v64 = torch.zeros((2, v.shape[1], 4, 64), dtype=dtype, device=DEV)
+    assert _native.grad_value_dtype(v64, t["shapes"], 77, 3, 4) == torch.float32
+    monkeypatch.setenv("MSDA_SCATTER_OWN", "0")
+    assert _native.grad_value_dtype(v, t["shapes"], 77, 3, 4) == torch.float32
+    gv = torch.empty(v.shape, dtype=dtype, device=DEV)
+    with pytest.raises(RuntimeError, match="grad_value"):
+        _native.backward(v, t["shapes"], t["lsi"], loc, aw, go, gv, torch.empty_like(loc), torch.empty_like(aw))
