@@ -67,6 +67,61 @@ class _AllGatherRows(Function):
         return mine, None
 
 
+class _StartGatherRows(Function):
+    """:class:`_AllGatherRows` with the collective left IN FLIGHT: forward issues the all-gather with ``async_op=True`` (RCCL
+    runs it on its own stream) and parks the work handle in ``pending``; the gathered tensor must not be read before
+    :class:`_FinishGatherRows` has waited on the handle.  backward: reduce-scatter (sum), as in :class:`_AllGatherRows`."""
+
+    @staticmethod
+    def forward(ctx, chunk, group, pending):
+        ctx.group = group
+        world = dist.get_world_size(group)
+        chunk = chunk.contiguous()
+        out = chunk.new_empty((world * chunk.shape[0],) + tuple(chunk.shape[1:]))
+        pending.append(dist.all_gather_into_tensor(out, chunk, group=group, async_op=True))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        return _AllGatherRows.backward(ctx, grad) + (None,)
+
+
+class _FinishGatherRows(Function):
+    """Identity that makes the current stream wait for the all-gather :class:`_StartGatherRows` started."""
+
+    @staticmethod
+    def forward(ctx, full, pending):
+        while pending:
+            pending.pop().wait()
+        return full.view_as(full)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad, None
+
+
+class PendingValue:
+    """The all-gather of one layer's ``value`` in flight (see :func:`start_gather_value`)."""
+
+    def __init__(self, full, pending, n_frames, spatial_size):
+        self._full, self._pending, self._shape = full, pending, (n_frames, spatial_size)
+
+    def wait(self):
+        """The full ``[T, S, M, D]`` tensor, valid on the current stream from here on; differentiable."""
+        full = _FinishGatherRows.apply(self._full, self._pending)
+        T, S = self._shape
+        return full[: T * S].reshape((T, S) + tuple(full.shape[1:]))
+
+
+def start_gather_value(value_chunk, n_frames, spatial_size, group=None):
+    """Issue the all-gather of :func:`gather_value` WITHOUT waiting for it: whatever the caller enqueues next on its
+    stream -- the layer's query-side GEMM and the fused pre-op pass (softmax + sampling locations), which do not
+    depend on ``value`` -- runs while the shards travel over xGMI.  ``.wait()`` on the result returns the tensor."""
+    pending = []
+    full = _StartGatherRows.apply(value_chunk, group, pending)
+    return PendingValue(full, pending, n_frames, spatial_size)
+
+
 def gather_value(value_chunk, n_frames, spatial_size, group=None):
     """value_chunk: this rank's [chunk, M, D] rows of the flattened [T*S, M, D] value tensor (chunk =
     padded_chunk(T*S, world); the last rank's tail rows beyond T*S are padding).  Returns the full
@@ -78,9 +133,16 @@ def gather_value(value_chunk, n_frames, spatial_size, group=None):
 def sharded_temporal_attention(value_chunk, n_frames, spatial_size, spatial_shapes, level_start_index,
                                frame_table, loc_curr, aw_curr, loc_temp, aw_temp, group=None):
     """Mode 2 for one clip.  value_chunk: this rank's rows of the flattened value (see gather_value);
-    loc_*/aw_* hold this rank's query range of every frame ([T, Lq_local, M, ...]).  Returns this rank's
-    output rows [T, Lq_local, M*D].  One all-gather forward, one reduce-scatter backward."""
-    value = gather_value(value_chunk, n_frames, spatial_size, group)
+    loc_*/aw_* hold this rank's query range of every frame ([T, Lq_local, M, ...]) -- tensors, or ONE callable that
+    produces the four of them (``loc_curr``; the others None): it is called while the all-gather is in flight, so the
+    layer's query-side GEMM and pre-op pass overlap the collective.  Returns this rank's output rows
+    [T, Lq_local, M*D].  One all-gather forward, one reduce-scatter backward."""
+    if callable(loc_curr):
+        pending = start_gather_value(value_chunk, n_frames, spatial_size, group)
+        loc_curr, aw_curr, loc_temp, aw_temp = loc_curr()
+        value = pending.wait()
+    else:
+        value = gather_value(value_chunk, n_frames, spatial_size, group)
     return MSDeformAttnTemporalFunction.apply(value.contiguous(), spatial_shapes, level_start_index,
                                               frame_table, loc_curr.contiguous(), aw_curr.contiguous(),
                                               loc_temp.contiguous(), aw_temp.contiguous(), 1)

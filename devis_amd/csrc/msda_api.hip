@@ -52,6 +52,7 @@ struct Knobs {
     int scatter_lds_kb = 144, scatter_dbg = 0;
     int scatter_own = -1;               // owner-computes scatter: -1 auto, 0 off (the LDS-atomic scatter instead)
     int force_generic = 0;
+    int gv_storage = 1;                 // 0: msda_grad_value_dtype always answers the arithmetic type (A/B measurements)
     int dbg = 0;
 };
 Knobs g_knobs;
@@ -78,6 +79,7 @@ void load_knobs()
         k.scatter_dbg = env_int("MSDA_SCATTER_DBG", k.scatter_dbg);
         k.scatter_own = env_int("MSDA_SCATTER_OWN", k.scatter_own);
         k.force_generic = env_int("MSDA_FORCE_GENERIC", 0) == 1;
+        k.gv_storage = env_int("MSDA_GV_STORAGE", k.gv_storage);
         k.dbg = env_int("MSDA_DBG", 0);
     }
     g_knobs = k;
@@ -226,7 +228,7 @@ bool rs_fits(const Params &p, int esz)
 bool storage_typed_grad_value_ok(int dtype, const Params &p)
 {
     if (dtype != MSDA_BF16 && dtype != MSDA_F16) return false;
-    if (knobs().force_generic || knobs().bwd_cull == 2) return false;
+    if (knobs().force_generic || knobs().bwd_cull == 2 || !knobs().gv_storage) return false;
     if (!owner_scatter_applicable(p, 2) || !p.shapes_host) return false;
     for (int l = 0; l < p.L; ++l)
         if (p.shapes_host[2 * l + 1] > kOwnPix || p.shapes_host[2 * l + 1] <= 0) return false;

@@ -142,6 +142,7 @@ template <> struct Store<double> {
 template <typename T> struct SlabStore : Store<T> {};
 template <> struct SlabStore<bf16_t> {
     static constexpr int VEC = 4;
+    __device__ static bf16_t cvt(float v) { return __float2bfloat16(v); }
     __device__ static float get(const bf16_t *p) { return __bfloat162float(*p); }
     __device__ static void put(bf16_t *p, float v) { *p = __float2bfloat16(v); }
     __device__ static void load(const bf16_t *p, float (&v)[4]) {
@@ -162,6 +163,7 @@ template <> struct SlabStore<bf16_t> {
 };
 template <> struct SlabStore<f16_t> {
     static constexpr int VEC = 4;
+    __device__ static f16_t cvt(float v) { return __float2half(v); }
     __device__ static float get(const f16_t *p) { return __half2float(*p); }
     __device__ static void put(f16_t *p, float v) { *p = __float2half(v); }
     __device__ static void load(const f16_t *p, float (&v)[4]) {

@@ -36,8 +36,14 @@ def main():
     from helpers import make_temporal_inputs, temporal_reference
     from devis_amd import clip_parallel as cp
 
-    T, W, M, D, Lq = 3, 2, 4, 8, 11
-    d = make_temporal_inputs(9, T, W, M, D, Lq, [(6, 5), (3, 3)], 3, 2, dtype=np.float64)
+    case = sys.argv[2] if len(sys.argv) > 2 else "small"
+    if case == "cfg3":      # BASELINE configs[3]: the T = 6 decoder clip (frames do not divide 8 ranks), connect-all window
+        from helpers import PYR_A
+        T, W, M, D, Lq = 6, 5, 8, 32, 75
+        d = make_temporal_inputs(9, T, W, M, D, Lq, PYR_A, 4, 4, dtype=np.float64)
+    else:
+        T, W, M, D, Lq = 3, 2, 4, 8, 11
+        d = make_temporal_inputs(9, T, W, M, D, Lq, [(6, 5), (3, 3)], 3, 2, dtype=np.float64)
     ref = temporal_reference(*(d[k] for k in ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t",
                                               "aw_t", "grad_out")))
     S = d["value"].shape[1]
@@ -58,6 +64,11 @@ def main():
     out = cp.sharded_temporal_attention(v_chunk, T, S, shapes, lsi, ftab, lc, ac, lt, at)
     go = torch.from_numpy(np.ascontiguousarray(d["grad_out"][:, q0:q1])).to(device, dt)
     gv, glc, gac, glt, gat = torch.autograd.grad(out, (v_chunk, lc, ac, lt, at), go)
+    # the overlapped form (all-gather in flight while the sampling tensors are produced): same results, same gradients
+    out2 = cp.sharded_temporal_attention(v_chunk, T, S, shapes, lsi, ftab, lambda: (lc * 1.0, ac * 1.0, lt * 1.0, at * 1.0),
+                                         None, None, None)
+    g2 = torch.autograd.grad(out2, (v_chunk, lc, ac, lt, at), go)
+    assert torch.equal(out2, out) and all(torch.equal(a, b) for a, b in zip(g2, (gv, glc, gac, glt, gat))), "overlapped form differs"
 
     def close(a, b, what):
         err = float(np.abs(a.detach().cpu().numpy() - b).max())

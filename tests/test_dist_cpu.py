@@ -18,11 +18,11 @@ def _free_port():
     return port
 
 
-def _launch(world, backend, timeout=240):
+def _launch(world, backend, timeout=240, case="small"):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "dist_worker.py"), backend]
+           os.path.join(ROOT, "tests", "dist_worker.py"), backend, case]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     for k in range(world):
@@ -32,6 +32,13 @@ def _launch(world, backend, timeout=240):
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_clip_gloo(world):
     _launch(world, "gloo")
+
+
+def test_sharded_clip_gloo_world8_decoder_clip_shape():
+    """BASELINE configs[3] as far as it runs without the 8-GPU node: 8 ranks, the T = 6 decoder clip on the 360x640
+    pyramid (frames do not divide the ranks: the cut is on pixel rows and queries), connect-all window, M = 8 x D = 32;
+    plain and overlapped all-gather; every rank's outputs and gradients against the oracle."""
+    _launch(8, "gloo", timeout=600, case="cfg3")
 
 
 def test_shard_range_properties():
