@@ -225,6 +225,24 @@ def other_configs(args, device):
     ms, fms = _event_ms(step, 30, 10), _event_ms(fwd, 30, 10)
     res["single_clip_latency"] = {"workload": "cfg3, ONE clip (T=%d x %d queries), fused call, f32" % (args.frames, args.queries),
                                   "fwd_bwd_ms": round(ms, 4), "fwd_ms": round(fms, 4), "M_queries_per_s": round(rows / ms / 1e3, 3)}
+    # (i-b) the same call captured in a HIP graph and replayed: the library only enqueues work (no allocation of its own, no
+    # synchronisation), so forward + backward of a clip is capturable; replay shows the GPU-side floor of the call
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        gms = _event_ms(graph.replay, 30, 10)
+        res["single_clip_graph"] = {"workload": "the same call (fwd + bwd of ONE clip) captured in a HIP graph, replayed",
+                                    "fwd_bwd_ms": round(gms, 4), "M_queries_per_s": round(rows / gms / 1e3, 3)}
+        del graph
+    except Exception as exc:       # (reported, never fatal for the headline)
+        res["single_clip_graph"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     # (ii) the headline batch with clustered locations (what a trained decoder produces)
     step, fwd, rows = fused_case(args.clips, "clustered", torch.float32)
     ms = _event_ms(step, 10)
@@ -423,30 +441,44 @@ def main():
     # head slot per pixel row, functions.project_value): reported beside the headline, never as `value`
     padded_line = None
     if args.value_layout == "dense" and args.pattern == "fused" and args.mode == "clip-parallel":
+        # INTERLEAVED blocks (A-B-A-B, medians) so that clock / thermal drift inside the run cannot favour either layout:
+        # dense = what `value` above reports (the reference's tensor), padded = what devis_amd's value_proj writes
         dense_value = b["value"]
         buf = torch.zeros((dense_value.shape[0], S, M + 1, D), dtype=dtype, device=device)
         buf[:, :, :M] = dense_value.detach()
-        b["value"] = buf[:, :, :M].requires_grad_(True)
-        leaves[0] = b["value"]
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        el = time.perf_counter() - t0
+        padded_value = buf[:, :, :M].requires_grad_(True)
+        block = max(2, args.steps // 8)
+
+        def timed_block(v):
+            b["value"] = v
+            leaves[0] = v
+            step(); step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(block):
+                step()
+            barrier()
+            return (time.perf_counter() - t0) / block
+
+        times = {"dense": [], "padded": []}
+        for _ in range(4):
+            times["dense"].append(timed_block(dense_value))
+            times["padded"].append(timed_block(padded_value))
+        med = {k: sorted(v)[len(v) // 2] for k, v in times.items()}
         if world > 1:
             import torch.distributed as dist
-            tt = torch.tensor([el], device=device, dtype=torch.float64)
+            tt = torch.tensor([med["dense"], med["padded"]], device=device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = tt.item()
+            med = {"dense": tt[0].item(), "padded": tt[1].item()}
         padded_line = {"layout": "value rows padded by one head slot (what devis_amd's value_proj writes)",
-                       "ms_per_step": round(el / args.steps * 1e3, 4),
-                       "value": round(rows_per_step / (el / args.steps) / 1e6, 3), "unit": "M-queries/s"}
+                       "method": "4 interleaved blocks of %d steps per layout, medians" % block,
+                       "ms_per_step": round(med["padded"] * 1e3, 4),
+                       "value": round(rows_per_step / med["padded"] / 1e6, 3),
+                       "dense_ms_per_step_same_method": round(med["dense"] * 1e3, 4),
+                       "dense_value_same_method": round(rows_per_step / med["dense"] / 1e6, 3), "unit": "M-queries/s"}
         b["value"] = dense_value
         leaves[0] = dense_value
-        del buf
+        del buf, padded_value
 
     # ---- per-kernel durations with HIP events on the launch stream (fused pattern only) ----------
     roofline, extra = None, {}
@@ -506,15 +538,17 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k][0])
         d_ms, _, d_bytes = kernels[dom]
         ach = d_bytes * args.clips / (d_ms * 1e-3) / 1e9
-        # HBM traffic cannot be counted from inside this process; when the run is the profiled
-        # configuration, quote the committed rocprofv3 PMC result (profiles/hbm_traffic.json), else null
+        # HBM traffic cannot be counted from inside this process (PMC counters need rocprofv3 around it); quote the committed
+        # rocprofv3 result (profiles/hbm_traffic.json) when it was made on this configuration AND from the very kernel sources
+        # of this build (content hash of devis_amd/csrc), else null
         traffic, traffic_src = None, None
         try:
+            from devis_amd import build as _b
             prof = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
             w = prof["workload"]
             if (w["clips"], w["frames"], w["queries"], w["pyramid"], w["dtype"], w["locs"], w["pattern"]) == \
                     (args.clips, args.frames, args.queries, args.pyramid, args.dtype, args.locs, args.pattern) \
-                    and args.value_layout == "dense":
+                    and args.value_layout == "dense" and prof.get("source_hash") == _b._source_hash():
                 k = prof["kernels"][dom.split(" ")[0]]
                 traffic = k["fetch_bytes"] + k["write_bytes"]
                 traffic_src = prof.get("source", "profiles/hbm_traffic.json")

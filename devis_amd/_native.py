@@ -127,6 +127,23 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(device):
+    """Context in which `device` is the current HIP device: a no-op when it already is (the usual case: one process
+    per GPU) -- torch.cuda.device() costs two device switches per call otherwise."""
+    return _NO_SWITCH if device.index == torch.cuda.current_device() else torch.cuda.device(device)
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -174,7 +191,7 @@ def shapes_hint(shapes):
 def forward(value, shapes, lsi, loc, aw, out):
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = loc.shape
-    with torch.cuda.device(value.device):
+    with _on(value.device):
         rc = load().msda_forward(dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(aw),
                                  N, S, M, D, L, Lq, P, _p(out), value_strides(value), shapes_hint(shapes), _stream(value))
     _check(rc, "msda_forward")
@@ -193,7 +210,7 @@ def bwd_workspace(device, batch, num_query, num_heads, virtual_levels):
 def backward(value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_aw):
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = loc.shape
-    with torch.cuda.device(value.device):
+    with _on(value.device):
         ws = bwd_workspace(value.device, N, Lq, M, L)
         rc = load().msda_backward(dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(aw),
                                   _p(grad_out), N, S, M, D, L, Lq, P,
@@ -208,7 +225,7 @@ def temporal_forward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, clips, 
     _, Lq, _, L, Pc, _ = loc_c.shape
     window = ftab.shape[1] if ftab is not None else 0
     Pt = loc_t.shape[4] if window else 1
-    with torch.cuda.device(value.device):
+    with _on(value.device):
         rc = load().msda_temporal_forward(
             dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(ftab), _p(loc_c), _p(aw_c),
             _p(loc_t), _p(aw_t), clips, frames, window, S, M, D, L, Lq, Pc, Pt, _p(out),
@@ -223,7 +240,7 @@ def temporal_backward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, grad_o
     _, Lq, _, L, Pc, _ = loc_c.shape
     window = ftab.shape[1] if ftab is not None else 0
     Pt = loc_t.shape[4] if window else 1
-    with torch.cuda.device(value.device):
+    with _on(value.device):
         ws = workspace if workspace is not None else bwd_workspace(value.device, G, Lq, M, L * (1 + window))
         rc = load().msda_temporal_backward(
             dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(ftab), _p(loc_c), _p(aw_c),
@@ -235,7 +252,7 @@ def temporal_backward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, grad_o
 
 def prep_forward(off_c, off_t, logit_c, logit_t, ref_c, ref_t, shapes, rows, M, L, W, Pc, Pt, loc_c, loc_t, aw_c, aw_t, ld=0):
     """msda_prep_forward (include/msda.h): joint softmax + sampling locations in one pass."""
-    with torch.cuda.device(off_c.device):
+    with _on(off_c.device):
         rc = load().msda_prep_forward(dtype_code(off_c.dtype), _p(off_c), _p(off_t), _p(logit_c), _p(logit_t), _p(ref_c),
                                       _p(ref_t), _p(shapes), rows, M, L, W, Pc, Pt, ref_c.shape[-1], ld,
                                       _p(loc_c), _p(loc_t), _p(aw_c), _p(aw_t), _stream(off_c))
@@ -244,7 +261,7 @@ def prep_forward(off_c, off_t, logit_c, logit_t, ref_c, ref_t, shapes, rows, M, 
 
 def prep_backward(gloc_c, gloc_t, gaw_c, gaw_t, aw_c, aw_t, ref_c, ref_t, shapes, rows, M, L, W, Pc, Pt,
                   goff_c, goff_t, glogit_c, glogit_t, ld=0):
-    with torch.cuda.device(gloc_c.device):
+    with _on(gloc_c.device):
         rc = load().msda_prep_backward(dtype_code(gloc_c.dtype), _p(gloc_c), _p(gloc_t), _p(gaw_c), _p(gaw_t), _p(aw_c),
                                        _p(aw_t), _p(ref_c), _p(ref_t), _p(shapes), rows, M, L, W, Pc, Pt, ref_c.shape[-1], ld,
                                        _p(goff_c), _p(goff_t), _p(glogit_c), _p(glogit_t), _stream(gloc_c))
@@ -261,7 +278,7 @@ def mask_rows(rows, mask, row_elems):
         raise ValueError("mask_rows: rows must be a 2-D view with contiguous rows")
     if not (mask.dtype == torch.bool and mask.device == rows.device and mask.is_contiguous() and mask.numel() == rows.shape[0]):
         raise ValueError("mask_rows: padding mask must be a contiguous bool tensor with one entry per row, on the rows' device")
-    with torch.cuda.device(rows.device):
+    with _on(rows.device):
         rc = load().msda_mask_rows(dtype_code(rows.dtype), _p(rows), _p(mask), rows.shape[0], row_elems,
                                    rows.stride(0) if rows.shape[0] > 1 else max(row_elems, rows.stride(0)), _stream(rows))
     _check(rc, "msda_mask_rows")

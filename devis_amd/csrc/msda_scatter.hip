@@ -546,6 +546,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             l = 0;
             while (l + 1 < L && s_first[l + 1] <= part) ++l;
         }
+        if ((dbg >> 5) != 0 && l != (dbg >> 5) - 1) continue;       // (measurement: MSDA_SCATTER_DBG = 32 * (level + 1): that level only)
         const int H = s_H[l], W = s_W[l], R = s_R[l];
         const bool direct = (R == 0);
         const int r0 = direct ? 0 : (part - s_first[l]) * R;

@@ -53,6 +53,24 @@ def _offset_bias(n_heads, mid_shape, n_points):
     return per_head.expand((n_heads,) + tuple(mid_shape) + (n_points, 2)).reshape(-1)
 
 
+def _fused_linear_params(module, linears):
+    """Weight / bias of several Linears on the same input as ONE [sum(out), in] matrix (a single GEMM forward, one dgrad
+    and one wgrad GEMM backward).  While autograd is recording (training) the concatenation is part of the graph, so the
+    gradients flow back to the individual parameters; without grad (inference: the call DeVIS's tracker times,
+    tracker.py:320-323) the concatenated tensors are cached on the module and rebuilt only when a parameter changed
+    (``_version``) or moved (``data_ptr`` / dtype)."""
+    params = [q for lin in linears for q in (lin.weight, lin.bias)]
+    if torch.is_grad_enabled() and any(q.requires_grad for q in params):
+        return torch.cat([l.weight for l in linears]), torch.cat([l.bias for l in linears])
+    key = tuple((q.data_ptr(), q._version, q.dtype) for q in params)
+    cached = module.__dict__.get("_fused_params")
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            cached = (key, torch.cat([l.weight for l in linears]), torch.cat([l.bias for l in linears]))
+        module.__dict__["_fused_params"] = cached
+    return cached[1], cached[2]
+
+
 def _normalizer(spatial_shapes):
     """(W_l, H_l) per level: divides pixel offsets into normalised coordinates (ref :113-114)."""
     return torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
@@ -132,8 +150,7 @@ class MSDeformAttn(nn.Module):
         if self.fused_prep and query.is_cuda:
             # softmax + location arithmetic in one pass (SURVEY f-2); same numbers as the branch below
             R = N * Len_q
-            y = F.linear(query.reshape(R, -1), torch.cat([self.sampling_offsets.weight, self.attention_weights.weight]),
-                         torch.cat([self.sampling_offsets.bias, self.attention_weights.bias]))
+            y = F.linear(query.reshape(R, -1), *_fused_linear_params(self, (self.sampling_offsets, self.attention_weights)))
             locations, _, weights, _ = MSDeformPrepFusedFunction.apply(
                 y, reference_points.reshape(R, L, reference_points.shape[-1]), None, input_spatial_shapes,
                 M, L, 0, P, 1)
@@ -238,7 +255,7 @@ class TemporalMSDeformAttnBase(nn.Module):
         # its output as column slices and returns one gradient matrix, so their backward is one dgrad + one wgrad
         lins = (self.sampling_offsets, self.temporal_sampling_offsets, self.attention_weights,
                 self.temporal_attention_weights)
-        y = F.linear(query.reshape(R, -1), torch.cat([l.weight for l in lins]), torch.cat([l.bias for l in lins]))
+        y = F.linear(query.reshape(R, -1), *_fused_linear_params(self, lins))
         loc_c, loc_t, w_c, w_t = MSDeformPrepFusedFunction.apply(
             y, ref_curr.reshape(R, L, d), ref_temp.expand(T, Len_q, W * L, d).reshape(R, W * L, d), shapes,
             M, L, W, Pc, Pt)

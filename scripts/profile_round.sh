@@ -14,7 +14,11 @@ f=$(find "$O/kt" -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" "$O/kernel_stats.csv"
 rm -rf "$O/kt"
 cd "$R"
-bash scripts/pmc_passes.sh "$O/pmc" scripts/step_only.py scripts/pmc_groups_hbm.txt
-cp "$O/pmc/summary.txt" "$O/pmc_hbm.txt" 2>/dev/null
-rm -rf "$O/pmc"
+for grp in hbm sq mem; do
+  bash scripts/pmc_passes.sh "$O/pmc" scripts/step_only.py scripts/pmc_groups_$grp.txt
+  cp "$O/pmc/summary.txt" "$O/pmc_$grp.txt" 2>/dev/null
+  rm -rf "$O/pmc"
+done
+# profiles/hbm_traffic.json for this very build (bench.py quotes it only while the kernel sources are unchanged)
+python3 scripts/make_hbm_traffic.py "$O/pmc_hbm.txt" > /dev/null && cp profiles/hbm_traffic.json "$O/hbm_traffic.json"
 tail -c 400 "$O/bench.json"; echo; head -12 "$O/kernel_stats.csv"; cat "$O/pmc_hbm.txt"

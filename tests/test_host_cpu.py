@@ -252,3 +252,21 @@ def test_frame_table_rejects_out_of_range_offsets():
                 [torch.tensor([-1, -2 * T]) for _ in range(T)]):           # wraps more than once
         with pytest.raises(IndexError):
             TemporalMSDeformAttnBase._frame_table(bad, T, torch.device("cpu"))
+
+
+def test_fused_linear_parameters_are_cached_only_outside_autograd():
+    """the concatenated query-side Linear parameters are rebuilt per call while autograd records
+    (their gradients must reach the individual Linears) and cached per parameter version otherwise."""
+    from devis_amd.modules import MSDeformAttn
+    from devis_amd.modules.ms_deform_attn import _fused_linear_params
+    mod = MSDeformAttn(32, 2, 4, 3)
+    lins = (mod.sampling_offsets, mod.attention_weights)
+    w1, b1 = _fused_linear_params(mod, lins)
+    assert w1.requires_grad and w1.shape == (4 * 2 * 3 * 3, 32)
+    with torch.no_grad():
+        w2, b2 = _fused_linear_params(mod, lins)
+        w3, b3 = _fused_linear_params(mod, lins)
+        assert w2 is w3 and b2 is b3 and not w2.requires_grad and torch.equal(w2, w1.detach())
+        mod.attention_weights.bias.add_(1.0)                     # a parameter changes in place: new version -> rebuilt
+        w4, b4 = _fused_linear_params(mod, lins)
+        assert b4 is not b2 and torch.equal(b4[-mod.attention_weights.bias.numel():], mod.attention_weights.bias)
