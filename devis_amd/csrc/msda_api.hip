@@ -266,7 +266,7 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             if (force_nt == 1 || force_nt == 2 || force_nt == 4) nt = force_nt;
             const int parts = nt ? (rs_tiles_per_clip + kRsWaves * nt - 1) / (kRsWaves * nt) : 0;
             if (mode != 0 && nt && clips * p.M * parts <= 0x7fffffffLL)
-                return launch_fwd_rs(dtype, nt, p, parts, (unsigned)(clips * p.M * parts), stream);
+                return launch_fwd_rs(dtype, nt, l0_host, p, parts, (unsigned)(clips * p.M * parts), stream);
         }
         return launch_fwd_tile(dtype, G, p, (unsigned)blocks, lds, stream);
     }
@@ -290,7 +290,7 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             const int parts = tpw ? (rs_tiles_per_clip + tpw * kRsWaves - 1) / (tpw * kRsWaves) : 1;       // (L2: see the forward)
             const bool want = mode == 1 || (mode == -1 && tpw && l0_host <= p.L - 1);
             if (want && clips * p.M * parts <= 0x7fffffffLL) {
-                rc = launch_bwd_rs(dtype, p, parts, (unsigned)(clips * p.M * parts), stream);
+                rc = launch_bwd_rs(dtype, l0_host, p, parts, (unsigned)(clips * p.M * parts), stream);
                 if (rc) return rc;
                 done = true;
             }

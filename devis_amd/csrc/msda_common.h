@@ -419,9 +419,11 @@ int grant_lds(const void *kernel, size_t bytes, LdsGrant &granted, const char *w
 // msda_tile.hip: G = D / (16 / sizeof(T)) lanes per row, one wave per workgroup
 int launch_fwd_tile(int dtype, int G, const Params &p, unsigned blocks, size_t lds, hipStream_t stream);
 int launch_bwd_tile(int dtype, int G, bool atomics, const Params &p, unsigned blocks, size_t lds, hipStream_t stream);
-// msda_rs.hip: resident-slab kernels (D = 32); nt = tiles per wave of the forward (1, 2, 4)
-int launch_fwd_rs(int dtype, int nt, const Params &p, int parts, unsigned grid, hipStream_t stream);
-int launch_bwd_rs(int dtype, const Params &p, int parts, unsigned grid, hipStream_t stream);
+// msda_rs.hip: resident-slab kernels (D = 32); nt = tiles per wave of the forward (1, 2, 4); first_slab_level = the host's
+// guess of the first pyramid level inside the slab (1 or 2: picks the kernel whose software-pipelined slot body is compiled
+// for it -- speed only: a kernel whose device-side level differs falls back to its plain loop)
+int launch_fwd_rs(int dtype, int nt, int first_slab_level, const Params &p, int parts, unsigned grid, hipStream_t stream);
+int launch_bwd_rs(int dtype, int first_slab_level, const Params &p, int parts, unsigned grid, hipStream_t stream);
 // msda_scatter.hip: grad_value
 int launch_zero_unowned(const Params &p, int cap_slots, int grad_value_elem_bytes, hipStream_t stream);
 int launch_cull_summary(const Params &p, hipStream_t stream);

@@ -278,7 +278,7 @@ template <int R> __device__ __forceinline__ float quad_bcast(float v)
     return __int_as_float(quad_bcast<R>(__float_as_int(v)));
 }
 
-template <typename T, int NT>
+template <typename T, int NT, int PL0>       // PL0: the first slab level the software-pipelined slot body is compiled for (1 or 2)
 __global__ void __launch_bounds__(kRsThreads)
 msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
 {
@@ -399,7 +399,7 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                 float xs[4], ys[4], as[4];
                 if (wide) load_slot_points<T>(loc, aw, idx0, cor, live, xs, ys, as);
 #if MSDA_RS_PIPE
-                if (wide && l0 == 1) {
+                if (wide && l0 == PL0) {
                     // 4 levels x 4 points, levels < l0 outside the slab.  Work units are corner PAIRS: 8 * l0 memory pairs (4
                     // buffer loads each) ride along the 8 * (4 - l0) LDS pairs -- one memory pair is consumed, and the next
                     // issued, after every third (l0 = 1) or every (l0 = 2) LDS pair
@@ -447,7 +447,7 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                             });
                         });
                     };
-                    pipelined(std::integral_constant<int, 1>{});
+                    pipelined(std::integral_constant<int, PL0>{});
                 } else
 #endif
                 {
@@ -528,7 +528,7 @@ __device__ __forceinline__ void quad_sum4(float (&d)[4])
                  : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
 }
 
-template <typename T>
+template <typename T, int PL0>
 __global__ void __launch_bounds__(kRsThreads)
 msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
 {
@@ -627,17 +627,27 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                 };
                 bool done = false;
 #if MSDA_RS_PIPE
-                if (wide && wide_ld && l0 == 1) {
-                    // 4 levels x 4 points, level 0 outside the slab: its 8 corner PAIRS (4 buffer loads each) ride along the 24
-                    // LDS pairs of levels 1-3, one consumed -- and the next issued -- after every third LDS pair, so that a wave
-                    // overlaps its own L2 round trips with its own slab work (see the forward)
-                    const RsGeom gm = rs_geometry<ROWSH>(xs[0], ys[0], as[0], 0, l0, fS, sh, pixB);
-                    wr[0] = gm.bits ? min(gm.yl, 32767) : kNoRow16;
-                    float km[4] = {0.f, 0.f, 0.f, 0.f}, dm[4];          // dots of this lane's level-0 point; of the point in flight
+                if (wide && wide_ld && l0 == PL0) {
+                    // 4 levels x 4 points, levels < l0 outside the slab: their 8 * l0 corner PAIRS (4 buffer loads each) ride along
+                    // the 8 * (4 - l0) LDS pairs, one consumed -- and the next issued -- after every third (l0 = 1) or every
+                    // (l0 = 2) LDS pair, so that a wave overlaps its own L2 round trips with its own slab work (see the forward)
+                    constexpr int L0 = PL0, NM = 8 * L0, NL = 8 * (4 - L0), PERIOD = NL / NM;
+                    RsGeom gm[L0];
+                    float km[L0][4], dm[4];          // dots of this lane's points of the memory levels; of the point in flight
+#pragma unroll
+                    for (int G = 0; G < L0; ++G)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) km[G][u] = 0.f;
                     RsRaw<T> mv[2];
                     auto issue = [&](auto Jc) {
-                        constexpr int J = decltype(Jc)::value, R = J / 2, S0 = 2 * (J % 2);
-                        int a0 = quad_bcast<R>(gm.adr[S0]) + off1, a1 = quad_bcast<R>(gm.adr[S0 + 1]) + off1;
+                        constexpr int J = decltype(Jc)::value, G = J / 8, R = (J % 8) / 2, S0 = 2 * (J % 2);
+                        if constexpr (J % 8 == 0) {
+                            const float pin = wa[0];
+                            asm volatile("" : "+v"(xs[G]), "+v"(ys[G]), "+v"(as[G]) : "v"(pin));
+                            gm[G] = rs_geometry<ROWSH>(xs[G], ys[G], as[G], G, l0, fS, sh, pixB);
+                            wr[G] = gm[G].bits ? min(gm[G].yl, 32767) : kNoRow16;
+                        }
+                        int a0 = quad_bcast<R>(gm[G].adr[S0]) + off1, a1 = quad_bcast<R>(gm[G].adr[S0 + 1]) + off1;
                         const float pin = wa[0];
                         asm volatile("" : "+v"(a0), "+v"(a1) : "v"(pin));        // (ties the loads to this point of the stream)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -646,18 +656,18 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
 #endif
                     };
                     auto consume = [&](auto Jc) {
-                        constexpr int J = decltype(Jc)::value, R = J / 2, S0 = 2 * (J % 2);
+                        constexpr int J = decltype(Jc)::value, G = J / 8, R = (J % 8) / 2, S0 = 2 * (J % 2);
                         dm[S0] = rs_dot_row<T>(mv[0], g); dm[S0 + 1] = rs_dot_row<T>(mv[1], g);
                         if constexpr (S0 == 2) {
                             quad_sum4(dm);
                             const bool me = cor == R;
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) km[u] = me ? dm[u] : km[u];
+                            for (int u = 0; u < 4; ++u) km[G][u] = me ? dm[u] : km[G][u];
                         }
                     };
                     issue(std::integral_constant<int, 0>{});
-                    static_for<3>([&](auto Gc) {
-                        constexpr int GL = decltype(Gc)::value + 1;            // a level of the slab
+                    static_for<4 - L0>([&](auto Gc) {
+                        constexpr int GL = decltype(Gc)::value + L0;           // a level of the slab
                         const float pin = wa[0];
                         asm volatile("" : "+v"(xs[GL]), "+v"(ys[GL]), "+v"(as[GL]) : "v"(pin));
                         const RsGeom gl = rs_geometry<ROWSH>(xs[GL], ys[GL], as[GL], GL, l0, fS, sh, pixB);
@@ -665,7 +675,7 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                         float kl[4] = {0.f, 0.f, 0.f, 0.f}, d[4];
                         static_for<8>([&](auto Hc) {
                             constexpr int R = decltype(Hc)::value / 2, S0 = 2 * (decltype(Hc)::value % 2);
-                            constexpr int HS = (GL - 1) * 8 + decltype(Hc)::value;       // LDS pair index
+                            constexpr int HS = (GL - L0) * 8 + decltype(Hc)::value;      // LDS pair index
 #pragma unroll
                             for (int s = S0; s < S0 + 2; ++s) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -680,15 +690,16 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
 #pragma unroll
                                 for (int u = 0; u < 4; ++u) kl[u] = me ? d[u] : kl[u];
                             }
-                            if constexpr ((HS + 1) % 3 == 0) {
-                                constexpr int J = (HS + 1) / 3 - 1;
+                            if constexpr ((HS + 1) % PERIOD == 0) {
+                                constexpr int J = (HS + 1) / PERIOD - 1;
                                 consume(std::integral_constant<int, J>{});
-                                if constexpr (J + 1 < 8) issue(std::integral_constant<int, J + 1>{});
+                                if constexpr (J + 1 < NM) issue(std::integral_constant<int, J + 1>{});
                             }
                         });
                         finish(gl, kl, wx[GL], wy[GL], wa[GL]);
                     });
-                    finish(gm, km, wx[0], wy[0], wa[0]);
+#pragma unroll
+                    for (int G = 0; G < L0; ++G) finish(gm[G], km[G], wx[G], wy[G], wa[G]);
                     done = true;
                 }
 #endif
@@ -787,56 +798,68 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
     }
 }
 
-template <typename T, int NT>
+template <typename T, int NT, int PL0>
 int fwd_rs(const Params &p, int parts, unsigned grid, hipStream_t stream, const char *what)
 {
     static LdsGrant granted;
     const size_t total = (size_t)kRsSlabBytes + kRsTailBytes;
-    const auto kern = &msda_fwd_rs_kernel<T, NT>;
+    const auto kern = &msda_fwd_rs_kernel<T, NT, PL0>;
     if (const int rc = grant_lds(reinterpret_cast<const void *>(kern), total, granted, "the resident-slab forward kernel")) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kRsThreads), total, stream, p, kRsSlabBytes, parts);
     return check_launch(what);
 }
 
-template <typename T>
+template <typename T, int PL0>
 int fwd_rs_nt(int nt, const Params &p, int parts, unsigned grid, hipStream_t stream)
 {
     switch (nt) {
-        case 4: return fwd_rs<T, 4>(p, parts, grid, stream, "msda forward (resident-slab kernel, 4 tiles per wave)");
-        case 2: return fwd_rs<T, 2>(p, parts, grid, stream, "msda forward (resident-slab kernel, 2 tiles per wave)");
-        default: return fwd_rs<T, 1>(p, parts, grid, stream, "msda forward (resident-slab kernel, 1 tiles per wave)");
+        case 4: return fwd_rs<T, 4, PL0>(p, parts, grid, stream, "msda forward (resident-slab kernel, 4 tiles per wave)");
+        case 2: return fwd_rs<T, 2, PL0>(p, parts, grid, stream, "msda forward (resident-slab kernel, 2 tiles per wave)");
+        default: return fwd_rs<T, 1, PL0>(p, parts, grid, stream, "msda forward (resident-slab kernel, 1 tiles per wave)");
     }
 }
 
 template <typename T>
+int fwd_rs_l0(int nt, int pl0, const Params &p, int parts, unsigned grid, hipStream_t stream)
+{
+    return pl0 == 2 ? fwd_rs_nt<T, 2>(nt, p, parts, grid, stream) : fwd_rs_nt<T, 1>(nt, p, parts, grid, stream);
+}
+
+template <typename T, int PL0>
 int bwd_rs(const Params &p, int parts, unsigned grid, hipStream_t stream)
 {
     static LdsGrant granted;
     const size_t total = (size_t)kRsSlabBytes + kRsTailBytes;
-    if (const int rc = grant_lds(reinterpret_cast<const void *>(&msda_bwd_rs_kernel<T>), total, granted,
-                                 "the resident-slab gather-pass kernel")) return rc;
-    hipLaunchKernelGGL((msda_bwd_rs_kernel<T>), dim3(grid), dim3(kRsThreads), total, stream, p, kRsSlabBytes, parts);
+    const auto kern = &msda_bwd_rs_kernel<T, PL0>;
+    if (const int rc = grant_lds(reinterpret_cast<const void *>(kern), total, granted, "the resident-slab gather-pass kernel")) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kRsThreads), total, stream, p, kRsSlabBytes, parts);
     return check_launch("msda backward (resident-slab kernel, grad_loc/grad_attn)");
+}
+
+template <typename T>
+int bwd_rs_l0(int pl0, const Params &p, int parts, unsigned grid, hipStream_t stream)
+{
+    return pl0 == 2 ? bwd_rs<T, 2>(p, parts, grid, stream) : bwd_rs<T, 1>(p, parts, grid, stream);
 }
 
 }  // namespace
 
-int launch_fwd_rs(int dtype, int nt, const Params &p, int parts, unsigned grid, hipStream_t stream)
+int launch_fwd_rs(int dtype, int nt, int first_slab_level, const Params &p, int parts, unsigned grid, hipStream_t stream)
 {
     switch (dtype) {
-        case MSDA_F32: return fwd_rs_nt<float>(nt, p, parts, grid, stream);
-        case MSDA_BF16: return fwd_rs_nt<bf16_t>(nt, p, parts, grid, stream);
-        case MSDA_F16: return fwd_rs_nt<f16_t>(nt, p, parts, grid, stream);
+        case MSDA_F32: return fwd_rs_l0<float>(nt, first_slab_level, p, parts, grid, stream);
+        case MSDA_BF16: return fwd_rs_l0<bf16_t>(nt, first_slab_level, p, parts, grid, stream);
+        case MSDA_F16: return fwd_rs_l0<f16_t>(nt, first_slab_level, p, parts, grid, stream);
         default: return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
     }
 }
 
-int launch_bwd_rs(int dtype, const Params &p, int parts, unsigned grid, hipStream_t stream)
+int launch_bwd_rs(int dtype, int first_slab_level, const Params &p, int parts, unsigned grid, hipStream_t stream)
 {
     switch (dtype) {
-        case MSDA_F32: return bwd_rs<float>(p, parts, grid, stream);
-        case MSDA_BF16: return bwd_rs<bf16_t>(p, parts, grid, stream);
-        case MSDA_F16: return bwd_rs<f16_t>(p, parts, grid, stream);
+        case MSDA_F32: return bwd_rs_l0<float>(first_slab_level, p, parts, grid, stream);
+        case MSDA_BF16: return bwd_rs_l0<bf16_t>(first_slab_level, p, parts, grid, stream);
+        case MSDA_F16: return bwd_rs_l0<f16_t>(first_slab_level, p, parts, grid, stream);
         default: return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
     }
 }

@@ -35,8 +35,8 @@ def run(env, dtype=torch.bfloat16, shapes=bench.PYRAMIDS["B"], N=8, reps=6):
     return res, routes, out.float().clone(), gl.float().clone()
 
 if __name__ == "__main__":
-    base = None
-    for name, env in (("auto", {}), ("RS forced", {"MSDA_FWD_RS": "1", "MSDA_BWD_RS": "1"})):
+    for name, env in (("auto", {}), ("NT=2/tpw=2", {"MSDA_FWD_RS_NT": "2", "MSDA_BWD_RS_TPW": "2"}), ("NT=1/tpw=1", {"MSDA_FWD_RS_NT": "1", "MSDA_BWD_RS_TPW": "1"}),
+                      ("NT=4/tpw=4", {"MSDA_FWD_RS_NT": "4", "MSDA_BWD_RS_TPW": "4"})):
         for dt in (torch.bfloat16, torch.float32):
             res, routes, out, gl = run(env, dtype=dt)
             print("%-10s %-8s fwd %.4f gather %.4f scatter %.4f ms" % (name, str(dt).split(".")[1], res["fwd"], res["gather"], res["scatter"]), flush=True)
