@@ -193,7 +193,7 @@ bool standard_value_layout(const Params &p)
 bool scatter_applicable(const Params &p)
 {
     if (knobs().bwd_atomic) return false;
-    if (p.L > kScatterMaxLevels || (p.D % 4) != 0) return false;
+    if (p.L > kScatterMaxLevels || (p.D % 4) != 0 || p.D / 4 > kWave || ((p.D / 4) & (p.D / 4 - 1)) != 0) return false;   // D / 4 lanes per hit
     if (1 + p.frames * p.window > kScatterMaxSources || p.Lq >= (1 << 24)) return false;   // survivor-list entry fields
     if (p.window == 0 && p.LA != p.L) return false;
     if ((int64_t)p.groups * p.Lq >= 0x7fffffffLL) return false;       // query rows are 32-bit in the hit records
@@ -318,7 +318,7 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
     const int cap_bytes = knobs().scatter_lds_kb * 1024;
     rc = launch_zero_unowned(p, cap_bytes / 8, 4, stream);
     if (rc) return rc;
-    return launch_scatter_lds(dtype, G, p, grid, cap_bytes, knobs().scatter_dbg, stream);
+    return launch_scatter_lds(dtype, p.D / 4, p, grid, cap_bytes, knobs().scatter_dbg, stream);      // 4 channels per lane
 }
 
 // Shapes the 16-byte-lane kernels take: D a multiple of the lane vector with 64 / G rows per wave, aligned bases,

@@ -53,7 +53,8 @@ template <typename T, int G>
 __global__ void __launch_bounds__(kScatterThreads)
 msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
 {
-    constexpr int VEC = Store<T>::VEC;
+    constexpr int VEC = 4;          // channels per lane, whatever the storage type: G = D / 4 lanes per hit (a lane with the 8
+                                    // channels of a 16-byte 2-byte-type vector carried 32 LDS adds per hit and spilled)
     constexpr int RPW = kWave / G;
     constexpr int kWaves = kScatterThreads / kWave;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];

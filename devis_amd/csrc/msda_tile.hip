@@ -138,7 +138,7 @@ __device__ __forceinline__ void build_chunk(const Params &p, const ChunkRef<T> &
 // NB = sampling points whose 4*NB corner loads are issued back to back before any FMA consumes them
 // (memory-level parallelism per wave); more points in flight cost VGPRs, i.e. waves per SIMD.
 template <typename T, int G, int NB>
-__global__ void __launch_bounds__(kWave, (NB <= 2 && kPch / G <= 2) ? 8 : 4)
+__global__ void __launch_bounds__(kWave, 4)
 msda_fwd_tile_kernel(const Params p)
 {
     constexpr int VEC = Store<T>::VEC;
@@ -438,7 +438,10 @@ msda_bwd_tile_kernel(const Params p)
 template <typename T, int G>
 int fwd_tile(const Params &p, unsigned blocks, size_t lds, hipStream_t stream)
 {
-    hipLaunchKernelGGL((msda_fwd_tile_kernel<T, G, 4>), dim3(blocks), dim3(kWave), lds, stream, p);
+    // points whose 4 * NB corner loads are in flight: 4 for 4-byte types; 2 for 2-byte types, whose lanes hold 8 channels
+    // (4 points x 4 corners x 8 fp32 channels would be the whole register budget)
+    constexpr int NB = sizeof(T) == 4 ? 4 : 2;
+    hipLaunchKernelGGL((msda_fwd_tile_kernel<T, G, NB>), dim3(blocks), dim3(kWave), lds, stream, p);
     return check_launch("msda forward (tile kernel)");
 }
 

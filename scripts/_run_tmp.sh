@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_op_gpu.py tests/test_configs_gpu.py tests/test_fuzz_gpu.py -m gpu -q -x 2>&1 | tail -4 > gpurun_out/r3o_tests.log
-python3 scripts/check_cfg1.py > gpurun_out/r3o_cfg1.log 2>&1
-MSDA_LIB=$PWD/devis_amd/libmsda_exp_nopipe.so python3 scripts/check_cfg1.py > gpurun_out/r3o_cfg1_nopipe.log 2>&1
-cat gpurun_out/r3o_tests.log; grep -v "^ " gpurun_out/r3o_cfg1.log; echo NOPIPE; grep -v "^ " gpurun_out/r3o_cfg1_nopipe.log | head -4
+python -m pytest tests -m gpu -q 2>&1 | tail -4
+python3 bench.py --steps 20 --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); o=d['other_configs']
+print(d['value']); print({k:{a:b for a,b in o[k].items() if a!='workload'} for k in ('single_clip_latency','single_clip_graph','headline_bf16','cfg4_swinl_fp16_decoder_like','cfg4_mask_head_like_fp16')})"

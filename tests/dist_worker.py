@@ -68,7 +68,9 @@ def main():
     out2 = cp.sharded_temporal_attention(v_chunk, T, S, shapes, lsi, ftab, lambda: (lc * 1.0, ac * 1.0, lt * 1.0, at * 1.0),
                                          None, None, None)
     g2 = torch.autograd.grad(out2, (v_chunk, lc, ac, lt, at), go)
-    assert torch.equal(out2, out) and all(torch.equal(a, b) for a, b in zip(g2, (gv, glc, gac, glt, gat))), "overlapped form differs"
+    # (on the GPU the order of a pixel's terms in grad_value is list order and varies from run to run: last-bit differences)
+    same = torch.equal if backend == "gloo" else (lambda a, b: torch.allclose(a, b, rtol=1e-9, atol=1e-12))
+    assert same(out2, out) and all(same(a, b) for a, b in zip(g2, (gv, glc, gac, glt, gat))), "overlapped form differs"
 
     def close(a, b, what):
         err = float(np.abs(a.detach().cpu().numpy() - b).max())
