@@ -1,6 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q 2>&1 | tail -4
-python3 bench.py --steps 20 --no-cpu-baseline 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); o=d['other_configs']
-print(d['value']); print({k:{a:b for a,b in o[k].items() if a!='workload'} for k in ('single_clip_latency','single_clip_graph','headline_bf16','cfg4_swinl_fp16_decoder_like','cfg4_mask_head_like_fp16')})"
+python -m pytest tests/test_op_gpu.py tests/test_configs_gpu.py -m gpu -q -x -k "alternate or overwritten or bench_scale or round2 or golden or storage" 2>&1 | tail -3
+bash scripts/ab_bench.sh devis_amd/libmsda_exp_ch1.so devis_amd/libmsda_hip.so devis_amd/libmsda_exp_ch4.so
+bash scripts/ab_bench.sh devis_amd/libmsda_exp_ch1.so devis_amd/libmsda_hip.so -- --dtype bf16 | head -2
