@@ -243,6 +243,20 @@ def other_configs(args, device):
         del graph
     except Exception as exc:       # (reported, never fatal for the headline)
         res["single_clip_graph"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    # (i-c) ONE encoder-layer call of DeVIS (the dominant cost of the transformer): the queries are the clip's
+    # own pixels (Lq = S per frame, T*S = 28 920 rows -- the point count of the 16-clip decoder batch), connect-all window,
+    # each query sampling around its own position in every frame (devis_transformer.py:94-121, ms_deform_attn.py:435-460)
+    if args.pyramid == "A":
+        saved_q = args.queries
+        args.queries = sum(h * w for h, w in PYRAMIDS[args.pyramid])
+        step_e, fwd_e, rows_e = fused_case(1, "local", torch.float32)
+        args.queries = saved_q
+        ms_e, fms_e = _event_ms(step_e, 10, 3), _event_ms(fwd_e, 10, 3)
+        res["temporal_encoder_layer"] = {"workload": "TemporalMSDeformAttnEncoder call of one clip: T=%d, Lq = S = %d per frame, connect-all, local "
+                                                     "sampling (N(0, (2 px)^2) around the query's own pixel), f32" % (args.frames, rows_e // args.frames),
+                                         "fwd_bwd_ms": round(ms_e, 4), "fwd_ms": round(fms_e, 4), "M_queries_per_s": round(rows_e / ms_e / 1e3, 3)}
+        del step_e, fwd_e
+        torch.cuda.empty_cache()
     # (ii) the headline batch with clustered locations (what a trained decoder produces)
     step, fwd, rows = fused_case(args.clips, "clustered", torch.float32)
     ms = _event_ms(step, 10)
