@@ -243,6 +243,45 @@ def other_configs(args, device):
         del graph
     except Exception as exc:       # (reported, never fatal for the headline)
         res["single_clip_graph"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    # (i-b') the same at MODULE level: TemporalMSDeformAttnDecoder of one clip, forward + backward incl. its Linears -- eager with
+    # the fused single launch, eager in the reference's call pattern (2*T operator calls + T value gathers per layer,
+    # ms_deform_attn.py:325-364), and captured with torch.cuda.make_graphed_callables
+    if args.pyramid == "A":
+        try:
+            from devis_amd.modules import TemporalMSDeformAttnDecoder
+            T_, q_, C_ = args.frames, args.queries, 256
+            gm = torch.Generator(device="cpu").manual_seed(11)
+            shp = torch.tensor(PYRAMIDS[args.pyramid], dtype=torch.int64, device=device)
+            lsi_ = torch.cat((shp.new_zeros(1), shp.prod(1).cumsum(0)[:-1]))
+            S_ = int(shp.prod(1).sum())
+            tsh = shp.repeat(T_ - 1, 1)
+            tlsi = torch.cat((tsh.new_zeros(1), tsh.prod(1).cumsum(0)[:-1]))
+            offs = [torch.tensor([t for t in range(-f, T_ - f) if t != 0], device=device) for f in range(T_)]
+            mod = TemporalMSDeformAttnDecoder(T_, C_, 4, T_ - 1, 8, 4, 4).to(device)
+            with torch.no_grad():
+                for prm in mod.parameters():
+                    prm.copy_(torch.randn(prm.shape, generator=gm).to(device) * 0.05)
+            qry = torch.randn(1, T_ * q_, C_, generator=gm).to(device).requires_grad_(True)
+            refp = (torch.rand(1, T_ * q_, 4, 2, generator=gm) * 0.8 + 0.1).to(device)
+            srcm = torch.randn(T_, S_, C_, generator=gm).to(device).requires_grad_(True)
+            wgt = torch.randn(1, T_ * q_, C_, generator=gm).to(device)
+            call = lambda a, b, c: mod(a, b, c, (shp, tsh), (lsi_, tlsi), offs)[0]
+
+            def mstep(fn=call):
+                torch.autograd.grad((fn(qry, refp, srcm) * wgt).sum(), (qry, srcm))
+            entry = {"workload": "TemporalMSDeformAttnDecoder (C=256, M=8, L=4, K=4) of ONE clip, T=%d x %d queries, forward + backward "
+                                 "incl. value_proj / query-side Linears / output_proj, f32" % (T_, q_)}
+            entry["eager_fused_ms"] = round(_event_ms(mstep, 20, 5), 4)
+            mod.fused = False
+            entry["eager_reference_call_pattern_ms"] = round(_event_ms(mstep, 10, 3), 4)
+            mod.fused = True
+            graphed = torch.cuda.make_graphed_callables(call, (qry, refp, srcm))
+            entry["graphed_ms"] = round(_event_ms(lambda: mstep(graphed), 20, 5), 4)
+            res["decoder_layer_module"] = entry
+            del graphed, mod
+        except Exception as exc:
+            res["decoder_layer_module"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        torch.cuda.empty_cache()
     # (i-c) ONE encoder-layer call of DeVIS (the dominant cost of the transformer): the queries are the clip's
     # own pixels (Lq = S per frame, T*S = 28 920 rows -- the point count of the 16-clip decoder batch), connect-all window,
     # each query sampling around its own position in every frame (devis_transformer.py:94-121, ms_deform_attn.py:435-460)
