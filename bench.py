@@ -54,6 +54,10 @@ def parse_args():
     ap.add_argument("--queries", type=int, default=300, help="queries per frame")
     ap.add_argument("--pyramid", choices=sorted(PYRAMIDS), default="A")
     ap.add_argument("--dtype", choices=sorted(DTYPES), default="f32")
+    ap.add_argument("--sampling", choices=["storage", "fp32"], default="storage",
+                    help="dtype of sampling locations / attention weights beside a 16-bit value: storage = the same 16-bit "
+                         "type (the reference's single-dtype contract); fp32 = float32 (ABI v11 MSDA_*_LOC32, what devis_amd's "
+                         "modules feed the op by default)")
     ap.add_argument("--locs", choices=["uniform", "clustered", "local"], default="uniform",
                     help="uniform: rand in [0,1) as the reference test.py; clustered: reference point + "
                          "N(0, (3 px)^2) offsets per level, as a trained decoder produces; local: query i sits on "
@@ -106,9 +110,11 @@ def make_clip_batch(args, device, dtype, seed):
     grad_out = torch.randn(G, q, M * D, generator=g)
     ftab = torch.tensor([[f for f in range(T) if f != t] for t in range(T)], dtype=torch.int32)
     dev = lambda x: x.to(device=device, dtype=dtype).contiguous()
+    ldt = torch.float32 if (getattr(args, "sampling", "storage") == "fp32" and dtype in (torch.bfloat16, torch.float16)) else dtype
+    sam = lambda x: x.to(device=device, dtype=ldt).contiguous()
     return dict(value=dev(value), shapes=shapes.to(device), ftab=ftab.to(device),
                 lsi=torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1])).to(device),
-                loc_c=dev(loc_c), aw_c=dev(aw_c), loc_t=dev(loc_t), aw_t=dev(aw_t),
+                loc_c=sam(loc_c), aw_c=sam(aw_c), loc_t=sam(loc_t), aw_t=sam(aw_t),
                 grad_out=dev(grad_out), dims=(T, q, M, D, L, P, W, S))
 
 
@@ -137,7 +143,7 @@ def kernel_name(route, what):
     return "msda_%s(%s)" % (what, route)
 
 
-def algorithmic_bytes(args, e, gv_bytes=4):
+def algorithmic_bytes(args, e, gv_bytes=4, le=None):
     """Per launch over ONE clip (DESIGN.md 'algorithmic bytes'): every tensor a kernel
     must touch counted once -- value read once (not once per gathered corner), (x, y, weight) per
     sampling point, one row per query.  The backward is two kernels: the gather pass reads value,
@@ -150,9 +156,10 @@ def algorithmic_bytes(args, e, gv_bytes=4):
     S = sum(h * w for h, w in shapes)
     C = M * D
     points = T * q * M * (L * P + W * L * P)
-    return {"fwd": T * S * C * e + points * 3 * e + T * q * C * e,
-            "bwd_gather": T * S * C * e + T * q * C * e + points * 3 * e + points * 3 * e,
-            "bwd_scatter": points * 3 * e + T * q * C * e + T * S * C * gv_bytes}
+    le = le or e        # bytes per sampling-location / attention-weight element (4 beside a 16-bit value with --sampling fp32)
+    return {"fwd": T * S * C * e + points * 3 * le + T * q * C * e,
+            "bwd_gather": T * S * C * e + T * q * C * e + points * 3 * le + points * 3 * le,
+            "bwd_scatter": points * 3 * le + T * q * C * e + T * S * C * gv_bytes}
 
 
 def _event_ms(fn, reps, warm=3):
@@ -201,11 +208,12 @@ def other_configs(args, device):
     from devis_amd.functions import MSDeformAttnFunction, MSDeformAttnTemporalFunction
     res = {}
 
-    def fused_case(clips, locs, dtype):
+    def fused_case(clips, locs, dtype, sampling="storage"):
         class A:
             pass
         a = A()
         a.clips, a.frames, a.queries, a.pyramid, a.locs = clips, args.frames, args.queries, args.pyramid, locs
+        a.sampling = sampling
         b = make_clip_batch(a, device, dtype, seed=4321)
         leaves = [b[k].requires_grad_(True) for k in ("value", "loc_c", "aw_c", "loc_t", "aw_t")]
 
@@ -309,10 +317,12 @@ def other_configs(args, device):
     del step, fwd
     torch.cuda.empty_cache()
     # (iii) the headline batch in the 16-bit storage types (arithmetic stays fp32)
-    for key, dt in (("headline_bf16", torch.bfloat16), ("headline_f16", torch.float16)):
-        step, fwd, rows = fused_case(args.clips, "uniform", dt)
+    for key, dt, sampling in (("headline_bf16", torch.bfloat16, "storage"), ("headline_f16", torch.float16, "storage"),
+                              ("headline_bf16_fp32_sampling", torch.bfloat16, "fp32")):
+        step, fwd, rows = fused_case(args.clips, "uniform", dt, sampling)
         ms, fms = _event_ms(step, 10), _event_ms(fwd, 10)
-        res[key] = {"workload": "headline batch, %s storage" % key.split("_")[1], "fwd_bwd_ms": round(ms, 4), "fwd_ms": round(fms, 4),
+        res[key] = {"workload": "headline batch, %s storage%s" % (key.split("_")[1], ", float32 sampling locations / attention weights "
+                                                                  "(MSDA_BF16_LOC32, the modules' default)" if sampling == "fp32" else ""), "fwd_bwd_ms": round(ms, 4), "fwd_ms": round(fms, 4),
                     "M_queries_per_s": round(rows / ms / 1e3, 3)}
     del step, fwd
 
@@ -582,7 +592,7 @@ def main():
         os.environ.pop("MSDA_ENABLE_HOOKS")
         _native.reload_knobs()
         e = b["value"].element_size()
-        ab = algorithmic_bytes(args, e, gv.element_size())
+        ab = algorithmic_bytes(args, e, gv.element_size(), b["loc_c"].element_size())
         kernels = {
             fwd_name: (fwd_ms, fwd_med, ab["fwd"]),
             gat_name + " (grad_loc/grad_attn gather pass)": (gat_ms, gat_med, ab["bwd_gather"]),
@@ -671,8 +681,9 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "cfg3 DeVIS decoder temporal MSDeformAttn, one layer fwd+bwd: T=%d frames, "
                                    "%d queries/frame, L=4, K=4, C=256 (M=8xD=32), pyramid %s (S=%d), %d clips/GPU/step, "
-                                   "%s call pattern, %s sampling locations, %s value layout"
-                                   % (T, q, args.pyramid, S, args.clips, args.pattern, args.locs, args.value_layout),
+                                   "%s call pattern, %s sampling locations%s, %s value layout"
+                                   % (T, q, args.pyramid, S, args.clips, args.pattern, args.locs,
+                                      " in float32" if (args.sampling == "fp32" and args.dtype != "f32") else "", args.value_layout),
                        "clips_per_gpu": args.clips, "query_rows_per_step": rows_per_step,
                        "parallelism": ("clip-parallel x%d (no data-path collective)" % world) if args.mode == "clip-parallel"
                        else "one clip sharded x%d (all-gather value / reduce-scatter grad_value over RCCL)" % world},

@@ -11,7 +11,7 @@ import torch
 
 from . import build as _build
 
-MSDA_ABI_VERSION = 10
+MSDA_ABI_VERSION = 11
 BWD_WORKSPACE_BYTES = 64
 _DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.float16: 3}
 
@@ -94,6 +94,20 @@ def dtype_code(dtype):
         return _DTYPE_CODE[dtype]
     except KeyError:
         raise RuntimeError("devis_amd: unsupported dtype %s (float32/float64/bfloat16/float16)" % dtype)
+
+
+_LOC32_CODE = {torch.bfloat16: 4, torch.float16: 5}      # include/msda.h MSDA_BF16_LOC32 / MSDA_F16_LOC32
+
+
+def type_code(dtype, loc_dtype):
+    """msda_dtype of a call whose value / out / grad_out are `dtype` and whose sampling_loc / attn_weight (and their
+    gradients) are `loc_dtype`: the same type, or float32 beside a 16-bit `dtype` (ABI v11: unrounded sampling locations)."""
+    if loc_dtype == dtype:
+        return dtype_code(dtype)
+    if loc_dtype == torch.float32 and dtype in _LOC32_CODE:
+        return _LOC32_CODE[dtype]
+    raise RuntimeError("devis_amd: sampling locations / attention weights must have value's dtype (or float32 beside a "
+                       "16-bit value), got %s beside %s" % (loc_dtype, dtype))
 
 
 def acc_dtype(dtype):
@@ -192,7 +206,7 @@ def forward(value, shapes, lsi, loc, aw, out):
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = loc.shape
     with _on(value.device):
-        rc = load().msda_forward(dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(aw),
+        rc = load().msda_forward(type_code(value.dtype, loc.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(aw),
                                  N, S, M, D, L, Lq, P, _p(out), value_strides(value), shapes_hint(shapes), _stream(value))
     _check(rc, "msda_forward")
 
@@ -212,7 +226,7 @@ def backward(value, shapes, lsi, loc, aw, grad_out, grad_value, grad_loc, grad_a
     _, Lq, _, L, P, _ = loc.shape
     with _on(value.device):
         ws = bwd_workspace(value.device, N, Lq, M, L)
-        rc = load().msda_backward(dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(aw),
+        rc = load().msda_backward(type_code(value.dtype, loc.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(aw),
                                   _p(grad_out), N, S, M, D, L, Lq, P,
                                   _p(grad_value), dtype_code(grad_value.dtype), _p(grad_loc), _p(grad_aw), _p(ws), ws.numel() * 4,
                                   value_strides(value), shapes_hint(shapes), _stream(value))
@@ -227,7 +241,7 @@ def temporal_forward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, clips, 
     Pt = loc_t.shape[4] if window else 1
     with _on(value.device):
         rc = load().msda_temporal_forward(
-            dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(ftab), _p(loc_c), _p(aw_c),
+            type_code(value.dtype, loc_c.dtype), _p(value), _p(shapes), _p(lsi), _p(ftab), _p(loc_c), _p(aw_c),
             _p(loc_t), _p(aw_t), clips, frames, window, S, M, D, L, Lq, Pc, Pt, _p(out),
             value_strides(value, frames), shapes_hint(shapes), _stream(value))
     _check(rc, "msda_temporal_forward")
@@ -243,7 +257,7 @@ def temporal_backward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, grad_o
     with _on(value.device):
         ws = workspace if workspace is not None else bwd_workspace(value.device, G, Lq, M, L * (1 + window))
         rc = load().msda_temporal_backward(
-            dtype_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(ftab), _p(loc_c), _p(aw_c),
+            type_code(value.dtype, loc_c.dtype), _p(value), _p(shapes), _p(lsi), _p(ftab), _p(loc_c), _p(aw_c),
             _p(loc_t), _p(aw_t), _p(grad_out), clips, frames, window, S, M, D, L, Lq, Pc, Pt,
             _p(grad_value), dtype_code(grad_value.dtype), _p(gloc_c), _p(gaw_c), _p(gloc_t), _p(gaw_t), _p(ws), ws.numel() * 4,
             value_strides(value, frames), shapes_hint(shapes), _stream(value))
@@ -253,7 +267,7 @@ def temporal_backward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, grad_o
 def prep_forward(off_c, off_t, logit_c, logit_t, ref_c, ref_t, shapes, rows, M, L, W, Pc, Pt, loc_c, loc_t, aw_c, aw_t, ld=0):
     """msda_prep_forward (include/msda.h): joint softmax + sampling locations in one pass."""
     with _on(off_c.device):
-        rc = load().msda_prep_forward(dtype_code(off_c.dtype), _p(off_c), _p(off_t), _p(logit_c), _p(logit_t), _p(ref_c),
+        rc = load().msda_prep_forward(type_code(off_c.dtype, loc_c.dtype), _p(off_c), _p(off_t), _p(logit_c), _p(logit_t), _p(ref_c),
                                       _p(ref_t), _p(shapes), rows, M, L, W, Pc, Pt, ref_c.shape[-1], ld,
                                       _p(loc_c), _p(loc_t), _p(aw_c), _p(aw_t), _stream(off_c))
     _check(rc, "msda_prep_forward")
@@ -262,7 +276,7 @@ def prep_forward(off_c, off_t, logit_c, logit_t, ref_c, ref_t, shapes, rows, M, 
 def prep_backward(gloc_c, gloc_t, gaw_c, gaw_t, aw_c, aw_t, ref_c, ref_t, shapes, rows, M, L, W, Pc, Pt,
                   goff_c, goff_t, glogit_c, glogit_t, ld=0):
     with _on(gloc_c.device):
-        rc = load().msda_prep_backward(dtype_code(gloc_c.dtype), _p(gloc_c), _p(gloc_t), _p(gaw_c), _p(gaw_t), _p(aw_c),
+        rc = load().msda_prep_backward(type_code(goff_c.dtype, gloc_c.dtype), _p(gloc_c), _p(gloc_t), _p(gaw_c), _p(gaw_t), _p(aw_c),
                                        _p(aw_t), _p(ref_c), _p(ref_t), _p(shapes), rows, M, L, W, Pc, Pt, ref_c.shape[-1], ld,
                                        _p(goff_c), _p(goff_t), _p(glogit_c), _p(glogit_t), _stream(gloc_c))
     _check(rc, "msda_prep_backward")

@@ -126,7 +126,9 @@ int grant_lds(const void *kernel, size_t bytes, LdsGrant &granted, const char *w
 
 namespace {
 
-int elem_bytes(int dtype) { return dtype == MSDA_F32 ? 4 : dtype == MSDA_F64 ? 8 : 2; }
+int elem_bytes(int dtype) { return dtype == MSDA_F32 ? 4 : dtype == MSDA_F64 ? 8 : 2; }        // of value / out / grad_out
+// the storage type of value / out / grad_out behind a dtype code (MSDA_*_LOC32: the 16-bit type)
+int storage_dtype(int dtype) { return dtype == MSDA_BF16_LOC32 ? MSDA_BF16 : dtype == MSDA_F16_LOC32 ? MSDA_F16 : dtype; }
 
 // How many of the LAST pyramid levels fit `cap_pixels` pixels of LDS slab (the device-side rule of first_slab_level,
 // evaluated on the host copy of spatial_shapes when the caller passed one; otherwise guessed from the pixel count:
@@ -227,7 +229,7 @@ bool rs_fits(const Params &p, int esz)
 // band take that kernel's float-atomic branch, so the host copy of the shapes must be there and say they do not occur.
 bool storage_typed_grad_value_ok(int dtype, const Params &p)
 {
-    if (dtype != MSDA_BF16 && dtype != MSDA_F16) return false;
+    if (storage_dtype(dtype) != MSDA_BF16 && storage_dtype(dtype) != MSDA_F16) return false;
     if (knobs().force_generic || knobs().bwd_cull == 2 || !knobs().gv_storage) return false;
     if (!owner_scatter_applicable(p, 2) || !p.shapes_host) return false;
     for (int l = 0; l < p.L; ++l)
@@ -346,7 +348,7 @@ bool fast_path_takes(int dtype, const Params &p, bool bwd)
 
 int run(int dtype, const Params &p_in, bool bwd, hipStream_t stream)
 {
-    if (dtype < MSDA_F32 || dtype > MSDA_F16) return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
+    if (dtype < MSDA_F32 || dtype > MSDA_F16_LOC32) return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
     Params p = p_in;
     p.dbg = knobs().dbg;
     // culling records per point (4 x int16) when the owner-computes scatter will read them; (min, max) intervals for the
@@ -369,7 +371,7 @@ int set_grad_value_dtype(int dtype, int grad_value_dtype, Params &p)
     const int arith = dtype == MSDA_F64 ? MSDA_F64 : MSDA_F32;
     p.gv_storage = 0;
     if (grad_value_dtype == arith) return MSDA_OK;
-    if (grad_value_dtype != dtype || !storage_typed_grad_value_ok(dtype, p))
+    if (grad_value_dtype != storage_dtype(dtype) || !storage_typed_grad_value_ok(dtype, p))
         return fail(MSDA_ERR_ARG, "msda backward: grad_value_dtype must be what msda_grad_value_dtype returns for this call%s");
     p.gv_storage = 1;
     return MSDA_OK;
@@ -475,7 +477,7 @@ int msda_grad_value_dtype(int dtype, int clips, int frames, int window, int spat
     p.S = spatial_size; p.M = num_heads; p.D = channels; p.L = num_levels; p.Lq = num_query;
     p.LA = num_levels; p.PA = num_curr_point; p.LB = window * num_levels; p.PB = window > 0 ? num_temp_point : 1;
     p.shapes_host = spatial_shapes_host;
-    return storage_typed_grad_value_ok(dtype, p) ? dtype : arith;
+    return storage_typed_grad_value_ok(dtype, p) ? storage_dtype(dtype) : arith;
 }
 
 int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes,

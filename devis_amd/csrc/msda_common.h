@@ -415,6 +415,22 @@ constexpr int kMaxDevices = 64;
 struct LdsGrant { size_t bytes[kMaxDevices]; };
 int grant_lds(const void *kernel, size_t bytes, LdsGrant &granted, const char *what);
 
+// Storage-type combinations of a call (include/msda.h msda_dtype): T = value / out / grad_out, TL = sampling_loc /
+// attn_weight and their gradients (TL = float with a 16-bit T for MSDA_BF16_LOC32 / MSDA_F16_LOC32).  f(type_tag<T>, type_tag<TL>).
+template <typename X> struct type_tag { using type = X; };
+template <class F>
+int dispatch_types(int dtype, F &&f)
+{
+    switch (dtype) {
+        case MSDA_F32: return f(type_tag<float>{}, type_tag<float>{});
+        case MSDA_BF16: return f(type_tag<bf16_t>{}, type_tag<bf16_t>{});
+        case MSDA_F16: return f(type_tag<f16_t>{}, type_tag<f16_t>{});
+        case MSDA_BF16_LOC32: return f(type_tag<bf16_t>{}, type_tag<float>{});
+        case MSDA_F16_LOC32: return f(type_tag<f16_t>{}, type_tag<float>{});
+        default: return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
+    }
+}
+
 // ---- per-family launchers (each translation unit owns its kernels; MSDA_OK or a negative msda_status) ----
 // msda_tile.hip: G = D / (16 / sizeof(T)) lanes per row, one wave per workgroup
 int launch_fwd_tile(int dtype, int G, const Params &p, unsigned blocks, size_t lds, hipStream_t stream);

@@ -33,7 +33,7 @@ __device__ __forceinline__ GTaps<A> make_gtaps(A x, A y, const Level lv, int MD)
     return t;
 }
 
-template <typename T, typename A>
+template <typename T, typename TL, typename A>        // T: value / out, TL: sampling_loc / attn_weight, A: arithmetic type
 __global__ void __launch_bounds__(256)
 msda_fwd_generic_kernel(const Params p, int64_t total)
 {
@@ -48,19 +48,19 @@ msda_fwd_generic_kernel(const Params p, int64_t total)
         const T *value = static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head + c;
         A acc = 0;
         for (int arr = 0; arr < 2; ++arr) {
-            const T *loc = static_cast<const T *>(arr ? p.locB : p.locA);
-            const T *aw = static_cast<const T *>(arr ? p.awB : p.awA);
+            const TL *loc = static_cast<const TL *>(arr ? p.locB : p.locA);
+            const TL *aw = static_cast<const TL *>(arr ? p.awB : p.awA);
             const int P = arr ? p.PB : p.PA, nl = arr ? p.LB : p.LA, LP = nl * P;
             for (int pt = 0; pt < LP; ++pt) {
                 const Level lv = make_level(p, t, (arr ? p.LA : 0) + pt / P);
                 const int64_t idx = row * LP + pt;
-                const GTaps<A> tp = make_gtaps<A>((A)Store<T>::get(loc + 2 * idx),
-                                                  (A)Store<T>::get(loc + 2 * idx + 1), lv, p.v_pix);
+                const GTaps<A> tp = make_gtaps<A>((A)Store<TL>::get(loc + 2 * idx),
+                                                  (A)Store<TL>::get(loc + 2 * idx + 1), lv, p.v_pix);
                 if (!tp.valid) continue;
                 A val = 0;
                 for (int k = 0; k < 4; ++k)
                     if (tp.valid & (1 << k)) val += tp.w[k] * (A)Store<T>::get(value + tp.off[k]);
-                acc += val * (A)Store<T>::get(aw + idx);
+                acc += val * (A)Store<TL>::get(aw + idx);
             }
         }
         Store<T>::put(static_cast<T *>(p.out) + i, acc);
@@ -76,7 +76,7 @@ __device__ __forceinline__ A wave_sum(A v)
 }
 
 // one wave per (group, q, m) row; lanes stride over the D channels
-template <typename T, typename A>
+template <typename T, typename TL, typename A>
 __global__ void __launch_bounds__(kWave)
 msda_bwd_generic_kernel(const Params p, int64_t rows)
 {
@@ -90,18 +90,18 @@ msda_bwd_generic_kernel(const Params p, int64_t rows)
         A *gvalue = static_cast<A *>(p.grad_value) + (int64_t)clip * p.frames * p.S * MD + m * p.D;
         const T *go = static_cast<const T *>(p.grad_out) + row * p.D;
         for (int arr = 0; arr < 2; ++arr) {
-            const T *loc = static_cast<const T *>(arr ? p.locB : p.locA);
-            const T *aw = static_cast<const T *>(arr ? p.awB : p.awA);
-            T *gloc = static_cast<T *>(arr ? p.glocB : p.glocA);
-            T *gaw = static_cast<T *>(arr ? p.gawB : p.gawA);
+            const TL *loc = static_cast<const TL *>(arr ? p.locB : p.locA);
+            const TL *aw = static_cast<const TL *>(arr ? p.awB : p.awA);
+            TL *gloc = static_cast<TL *>(arr ? p.glocB : p.glocA);
+            TL *gaw = static_cast<TL *>(arr ? p.gawB : p.gawA);
             const int P = arr ? p.PB : p.PA, nl = arr ? p.LB : p.LA, LP = nl * P;
             for (int pt = 0; pt < LP; ++pt) {
                 const Level lv = make_level(p, t, (arr ? p.LA : 0) + pt / P);
                 const int64_t idx = row * LP + pt;
-                const A a = (A)Store<T>::get(aw + idx);
+                const A a = (A)Store<TL>::get(aw + idx);
                 // offsets in PIXELS: value and grad_value (always the standard layout) have different strides
-                const GTaps<A> tp = make_gtaps<A>((A)Store<T>::get(loc + 2 * idx),
-                                                  (A)Store<T>::get(loc + 2 * idx + 1), lv, 1);
+                const GTaps<A> tp = make_gtaps<A>((A)Store<TL>::get(loc + 2 * idx),
+                                                  (A)Store<TL>::get(loc + 2 * idx + 1), lv, 1);
                 A d[4] = {0, 0, 0, 0};
                 if (tp.valid) {
                     for (int c = lane; c < p.D; c += kWave) {
@@ -120,9 +120,9 @@ msda_bwd_generic_kernel(const Params p, int64_t rows)
                     const A g_aw = tp.w[0] * d[0] + tp.w[1] * d[1] + tp.w[2] * d[2] + tp.w[3] * d[3];
                     const A g_w = hh * (d[1] - d[0]) + tp.lh * (d[3] - d[2]);
                     const A g_h = hw * (d[2] - d[0]) + tp.lw * (d[3] - d[1]);
-                    Store<T>::put(gaw + idx, g_aw);
-                    Store<T>::put(gloc + 2 * idx, (A)lv.W * g_w * a);
-                    Store<T>::put(gloc + 2 * idx + 1, (A)lv.H * g_h * a);
+                    Store<TL>::put(gaw + idx, g_aw);
+                    Store<TL>::put(gloc + 2 * idx, (A)lv.W * g_w * a);
+                    Store<TL>::put(gloc + 2 * idx + 1, (A)lv.H * g_h * a);
                 }
             }
         }
@@ -156,10 +156,14 @@ template <typename A> __device__ __forceinline__ A half_wave_sum(A v)
 __device__ __forceinline__ float prep_exp(float x) { return expf(x); }
 __device__ __forceinline__ double prep_exp(double x) { return exp(x); }
 
-template <typename T, typename A, bool BWD>
+// T: type of the Linear-side tensors (raw offsets / logits, their gradients); TL: type of the operator-side tensors
+// (sampling_loc, attn_weight, their gradients) AND of the reference points -- T, or float with a 16-bit T (MSDA_*_LOC32)
+template <typename T, typename TL, typename A, bool BWD>
 __global__ void __launch_bounds__(256)
 msda_prep_kernel(const PrepParams p)
 {
+    typedef typename std::conditional<BWD, TL, T>::type TI;      // what the pass reads per point: weights / grad_loc, or logits / offsets
+    typedef typename std::conditional<BWD, T, TL>::type TO;      // ... and writes: grad of logits / offsets, or weights / locations
     const int lane = threadIdx.x % 32;
     const int nc = p.L * p.Pc, nt = p.W * p.L * p.Pt, n = nc + nt;
     const int64_t pairs = p.rows * p.M;
@@ -168,19 +172,19 @@ msda_prep_kernel(const PrepParams p)
         const int m = (int)(pair - row * p.M);
         // first element of this (row, head) in a Linear-side tensor with n_ (x2 for offsets) elements per head
         auto raw = [&](int n_) { return p.ld ? row * p.ld + (int64_t)m * n_ : pair * n_; };
-        const T *lc = static_cast<const T *>(BWD ? p.aw_c : p.logit_c) + (BWD ? pair * nc : raw(nc));
-        const T *lt = static_cast<const T *>(BWD ? p.aw_t : p.logit_t) + (BWD ? pair * nt : raw(nt));
+        const TI *lc = static_cast<const TI *>(BWD ? p.aw_c : p.logit_c) + (BWD ? pair * nc : raw(nc));
+        const TI *lt = static_cast<const TI *>(BWD ? p.aw_t : p.logit_t) + (BWD ? pair * nt : raw(nt));
         constexpr int NE = 8;                 // register-resident fast path: n <= 32 * NE logits per (row, head)
         if (!BWD) {
             // ---- joint softmax over the n logits of this (row, head)   (ref :252-258 / F.softmax)
-            T *ac = static_cast<T *>(p.aw_c) + pair * nc, *at = static_cast<T *>(p.aw_t) + pair * nt;
+            TL *ac = static_cast<TL *>(p.aw_c) + pair * nc, *at = static_cast<TL *>(p.aw_t) + pair * nt;
             if (n <= 32 * NE) {               // each logit is read once and exponentiated once
                 A v[NE];
                 A mx = -INFINITY;
 #pragma unroll
                 for (int i = 0; i < NE; ++i) {
                     const int e = lane + 32 * i;
-                    v[i] = e < n ? (A)Store<T>::get(e < nc ? lc + e : lt + (e - nc)) : (A)-INFINITY;
+                    v[i] = e < n ? (A)Store<TI>::get(e < nc ? lc + e : lt + (e - nc)) : (A)-INFINITY;
                     mx = v[i] > mx ? v[i] : mx;
                 }
                 mx = half_wave_max<A>(mx);
@@ -191,26 +195,26 @@ msda_prep_kernel(const PrepParams p)
 #pragma unroll
                 for (int i = 0; i < NE; ++i) {
                     const int e = lane + 32 * i;
-                    if (e < n) Store<T>::put(e < nc ? ac + e : at + (e - nc), v[i] / sum);
+                    if (e < n) Store<TL>::put(e < nc ? ac + e : at + (e - nc), v[i] / sum);
                 }
             } else {
                 A mx = -INFINITY;
                 for (int e = lane; e < n; e += 32) {
-                    const A v = (A)Store<T>::get(e < nc ? lc + e : lt + (e - nc));
+                    const A v = (A)Store<TI>::get(e < nc ? lc + e : lt + (e - nc));
                     mx = v > mx ? v : mx;
                 }
                 mx = half_wave_max<A>(mx);
                 A sum = 0;
-                for (int e = lane; e < n; e += 32) sum += prep_exp((A)Store<T>::get(e < nc ? lc + e : lt + (e - nc)) - mx);
+                for (int e = lane; e < n; e += 32) sum += prep_exp((A)Store<TI>::get(e < nc ? lc + e : lt + (e - nc)) - mx);
                 sum = half_wave_sum<A>(sum);
                 for (int e = lane; e < n; e += 32) {
-                    const A v = prep_exp((A)Store<T>::get(e < nc ? lc + e : lt + (e - nc)) - mx) / sum;
-                    Store<T>::put(e < nc ? ac + e : at + (e - nc), v);
+                    const A v = prep_exp((A)Store<TI>::get(e < nc ? lc + e : lt + (e - nc)) - mx) / sum;
+                    Store<TL>::put(e < nc ? ac + e : at + (e - nc), v);
                 }
             }
         } else {
             // ---- softmax backward: g_logit = p * (g - sum_j p_j g_j)
-            const T *gc = static_cast<const T *>(p.gaw_c) + pair * nc, *gt = static_cast<const T *>(p.gaw_t) + pair * nt;
+            const TL *gc = static_cast<const TL *>(p.gaw_c) + pair * nc, *gt = static_cast<const TL *>(p.gaw_t) + pair * nt;
             T *oc = static_cast<T *>(p.glogit_c) + raw(nc), *ot = static_cast<T *>(p.glogit_t) + raw(nt);
             if (n <= 32 * NE) {
                 A pe[NE], ge[NE];
@@ -218,8 +222,8 @@ msda_prep_kernel(const PrepParams p)
 #pragma unroll
                 for (int i = 0; i < NE; ++i) {
                     const int e = lane + 32 * i;
-                    pe[i] = e < n ? (A)Store<T>::get(e < nc ? lc + e : lt + (e - nc)) : (A)0;
-                    ge[i] = e < n ? (A)Store<T>::get(e < nc ? gc + e : gt + (e - nc)) : (A)0;
+                    pe[i] = e < n ? (A)Store<TI>::get(e < nc ? lc + e : lt + (e - nc)) : (A)0;
+                    ge[i] = e < n ? (A)Store<TL>::get(e < nc ? gc + e : gt + (e - nc)) : (A)0;
                     dot += pe[i] * ge[i];
                 }
                 dot = half_wave_sum<A>(dot);
@@ -231,11 +235,11 @@ msda_prep_kernel(const PrepParams p)
             } else {
                 A dot = 0;
                 for (int e = lane; e < n; e += 32)
-                    dot += (A)Store<T>::get(e < nc ? lc + e : lt + (e - nc)) * (A)Store<T>::get(e < nc ? gc + e : gt + (e - nc));
+                    dot += (A)Store<TI>::get(e < nc ? lc + e : lt + (e - nc)) * (A)Store<TL>::get(e < nc ? gc + e : gt + (e - nc));
                 dot = half_wave_sum<A>(dot);
                 for (int e = lane; e < n; e += 32) {
-                    const A pe = (A)Store<T>::get(e < nc ? lc + e : lt + (e - nc));
-                    const A ge = (A)Store<T>::get(e < nc ? gc + e : gt + (e - nc));
+                    const A pe = (A)Store<TI>::get(e < nc ? lc + e : lt + (e - nc));
+                    const A ge = (A)Store<TL>::get(e < nc ? gc + e : gt + (e - nc));
                     Store<T>::put(e < nc ? oc + e : ot + (e - nc), pe * (ge - dot));
                 }
             }
@@ -249,27 +253,27 @@ msda_prep_kernel(const PrepParams p)
             const int l = cur ? vl : vl % p.L;
             const int64_t idx = (pair * (cur ? nc : nt) + ee) * 2;                 // dense tensors (loc, grad_loc)
             const int64_t ridx = raw(2 * (cur ? nc : nt)) + 2 * ee;                // Linear-side tensors
-            const T *ref = static_cast<const T *>(cur ? p.ref_c : p.ref_t) + (row * (cur ? p.L : p.W * p.L) + vl) * p.d;
-            const T *in = static_cast<const T *>(BWD ? (cur ? p.gloc_c : p.gloc_t) : (cur ? p.off_c : p.off_t)) + (BWD ? idx : ridx);
-            T *out = static_cast<T *>(BWD ? (cur ? p.goff_c : p.goff_t) : (cur ? p.loc_c : p.loc_t)) + (BWD ? ridx : idx);
-            const A x = (A)Store<T>::get(in), y = (A)Store<T>::get(in + 1);
+            const TL *ref = static_cast<const TL *>(cur ? p.ref_c : p.ref_t) + (row * (cur ? p.L : p.W * p.L) + vl) * p.d;
+            const TI *in = static_cast<const TI *>(BWD ? (cur ? p.gloc_c : p.gloc_t) : (cur ? p.off_c : p.off_t)) + (BWD ? idx : ridx);
+            TO *out = static_cast<TO *>(BWD ? (cur ? p.goff_c : p.goff_t) : (cur ? p.loc_c : p.loc_t)) + (BWD ? ridx : idx);
+            const A x = (A)Store<TI>::get(in), y = (A)Store<TI>::get(in + 1);
             if (p.d == 2) {
                 const A nx = (A)p.shapes[2 * l + 1], ny = (A)p.shapes[2 * l];      // (W_l, H_l)
                 if (!BWD) {
-                    Store<T>::put(out, (A)Store<T>::get(ref) + x / nx);
-                    Store<T>::put(out + 1, (A)Store<T>::get(ref + 1) + y / ny);
+                    Store<TO>::put(out, (A)Store<TL>::get(ref) + x / nx);
+                    Store<TO>::put(out + 1, (A)Store<TL>::get(ref + 1) + y / ny);
                 } else {
-                    Store<T>::put(out, x / nx);
-                    Store<T>::put(out + 1, y / ny);
+                    Store<TO>::put(out, x / nx);
+                    Store<TO>::put(out + 1, y / ny);
                 }
             } else {
-                const A bw = (A)Store<T>::get(ref + 2), bh = (A)Store<T>::get(ref + 3);
+                const A bw = (A)Store<TL>::get(ref + 2), bh = (A)Store<TL>::get(ref + 3);
                 if (!BWD) {
-                    Store<T>::put(out, (A)Store<T>::get(ref) + x / (A)P * bw * (A)0.5);
-                    Store<T>::put(out + 1, (A)Store<T>::get(ref + 1) + y / (A)P * bh * (A)0.5);
+                    Store<TO>::put(out, (A)Store<TL>::get(ref) + x / (A)P * bw * (A)0.5);
+                    Store<TO>::put(out + 1, (A)Store<TL>::get(ref + 1) + y / (A)P * bh * (A)0.5);
                 } else {
-                    Store<T>::put(out, x * (A)0.5 * bw / (A)P);
-                    Store<T>::put(out + 1, y * (A)0.5 * bh / (A)P);
+                    Store<TO>::put(out, x * (A)0.5 * bw / (A)P);
+                    Store<TO>::put(out + 1, y * (A)0.5 * bh / (A)P);
                 }
             }
         }
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256) void msda_mask_rows_kernel(char *__restrict__ 
     else *reinterpret_cast<uint16_t *>(dst) = 0;
 }
 
-template <typename T, typename A>
+template <typename T, typename TL, typename A>
 int generic(const Params &p, bool bwd, hipStream_t stream)
 {
     const int64_t rows = (int64_t)p.groups * p.Lq * p.M;
@@ -302,24 +306,24 @@ int generic(const Params &p, bool bwd, hipStream_t stream)
         if (hipMemsetAsync(p.grad_value, 0, (size_t)p.groups * p.S * p.M * p.D * sizeof(A), stream) != hipSuccess)
             return fail(MSDA_ERR_HIP, "msda backward: hipMemsetAsync(grad_value) failed%s");
         const unsigned blocks = (unsigned)(rows < 65536 * 16 ? rows : 65536 * 16);
-        hipLaunchKernelGGL((msda_bwd_generic_kernel<T, A>), dim3(blocks), dim3(kWave), 0, stream, p, rows);
+        hipLaunchKernelGGL((msda_bwd_generic_kernel<T, TL, A>), dim3(blocks), dim3(kWave), 0, stream, p, rows);
         return check_launch("msda backward (generic kernel)");
     }
     const int64_t total = rows * p.D;
     const int64_t want = (total + 255) / 256;
     const unsigned blocks = (unsigned)(want < 65536 * 8 ? want : 65536 * 8);
-    hipLaunchKernelGGL((msda_fwd_generic_kernel<T, A>), dim3(blocks), dim3(256), 0, stream, p, total);
+    hipLaunchKernelGGL((msda_fwd_generic_kernel<T, TL, A>), dim3(blocks), dim3(256), 0, stream, p, total);
     return check_launch("msda forward (generic kernel)");
 }
 
-template <typename T, typename A>
+template <typename T, typename TL, typename A>
 int prep(const PrepParams &p, bool bwd, hipStream_t stream)
 {
     const int64_t pairs = p.rows * p.M;
     const int64_t want = (pairs + 7) / 8;
     const unsigned blocks = (unsigned)(want < 65536 * 4 ? want : 65536 * 4);
-    if (bwd) hipLaunchKernelGGL((msda_prep_kernel<T, A, true>), dim3(blocks), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((msda_prep_kernel<T, A, false>), dim3(blocks), dim3(256), 0, stream, p);
+    if (bwd) hipLaunchKernelGGL((msda_prep_kernel<T, TL, A, true>), dim3(blocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((msda_prep_kernel<T, TL, A, false>), dim3(blocks), dim3(256), 0, stream, p);
     return check_launch(bwd ? "msda prep backward" : "msda prep forward");
 }
 
@@ -327,24 +331,18 @@ int prep(const PrepParams &p, bool bwd, hipStream_t stream)
 
 int launch_generic(int dtype, const Params &p, bool bwd, hipStream_t stream)
 {
-    switch (dtype) {
-        case MSDA_F32: return generic<float, float>(p, bwd, stream);
-        case MSDA_BF16: return generic<bf16_t, float>(p, bwd, stream);
-        case MSDA_F16: return generic<f16_t, float>(p, bwd, stream);
-        case MSDA_F64: return generic<double, double>(p, bwd, stream);
-        default: return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
-    }
+    if (dtype == MSDA_F64) return generic<double, double, double>(p, bwd, stream);
+    return dispatch_types(dtype, [&](auto t, auto tl) {
+        return generic<typename decltype(t)::type, typename decltype(tl)::type, float>(p, bwd, stream);
+    });
 }
 
 int launch_prep(int dtype, const PrepParams &p, bool bwd, hipStream_t stream)
 {
-    switch (dtype) {
-        case MSDA_F32: return prep<float, float>(p, bwd, stream);
-        case MSDA_F64: return prep<double, double>(p, bwd, stream);
-        case MSDA_BF16: return prep<bf16_t, float>(p, bwd, stream);
-        case MSDA_F16: return prep<f16_t, float>(p, bwd, stream);
-        default: return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
-    }
+    if (dtype == MSDA_F64) return prep<double, double, double>(p, bwd, stream);
+    return dispatch_types(dtype, [&](auto t, auto tl) {
+        return prep<typename decltype(t)::type, typename decltype(tl)::type, float>(p, bwd, stream);
+    });
 }
 
 int launch_mask_rows(int bytes_per_thread, char *rows, const uint8_t *mask, long long pixels, int chunks,

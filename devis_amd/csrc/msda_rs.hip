@@ -278,7 +278,8 @@ template <int R> __device__ __forceinline__ float quad_bcast(float v)
     return __int_as_float(quad_bcast<R>(__float_as_int(v)));
 }
 
-template <typename T, int NT, int PL0>       // PL0: the first slab level the software-pipelined slot body is compiled for (1 or 2)
+// T = storage type of value / out, TL = of sampling_loc / attn_weight (T, or float with a 16-bit T)
+template <typename T, typename TL, int NT, int PL0>       // PL0: the first slab level the software-pipelined slot body is compiled for (1 or 2)
 __global__ void __launch_bounds__(kRsThreads)
 msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
 {
@@ -387,8 +388,8 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
             while (todo) {                                     // sl = -1: the tile's current-frame points
                 const int sl = (int)__builtin_ctz(todo) - 1;
                 todo &= todo - 1;
-                const T *loc = static_cast<const T *>(sl < 0 ? p.locA : p.locB);
-                const T *aw = static_cast<const T *>(sl < 0 ? p.awA : p.awB);
+                const TL *loc = static_cast<const TL *>(sl < 0 ? p.locA : p.locB);
+                const TL *aw = static_cast<const TL *>(sl < 0 ? p.awA : p.awB);
                 const int P = sl < 0 ? p.PA : p.PB;
                 const int LP = (sl < 0 ? p.LA : p.LB) * P;
                 const int npts = (sl < 0 ? p.LA : L) * P;
@@ -397,7 +398,7 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                 const int first_slab_pt = l0 * P;              // points of levels >= l0 read the slab
                 const bool wide = p.wide_loads && P == 4 && npts == 16;           // (uniform) see load_slot_points
                 float xs[4], ys[4], as[4];
-                if (wide) load_slot_points<T>(loc, aw, idx0, cor, live, xs, ys, as);
+                if (wide) load_slot_points<TL>(loc, aw, idx0, cor, live, xs, ys, as);
 #if MSDA_RS_PIPE
                 if (wide && l0 == PL0) {
                     // 4 levels x 4 points, levels < l0 outside the slab.  Work units are corner PAIRS: 8 * l0 memory pairs (4
@@ -459,7 +460,7 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                             x = get4(xs, g0 >> 2); y = get4(ys, g0 >> 2); a = get4(as, g0 >> 2);
                         } else if (live && kk < npts) {
                             load_xy(loc + 2 * (idx0 + kk), x, y);
-                            a = Store<T>::get(aw + idx0 + kk);
+                            a = Store<TL>::get(aw + idx0 + kk);
                         }
                         const int lvl = min((int)(((unsigned)kk * invP) >> 16), L - 1);
                         const RsRec rec = rs_records<ROWSH>(x, y, a, lvl, l0, fS, sh, pixB);
@@ -528,7 +529,7 @@ __device__ __forceinline__ void quad_sum4(float (&d)[4])
                  : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
 }
 
-template <typename T, int PL0>
+template <typename T, typename TL, int PL0>      // T: value / grad_out, TL: sampling_loc / attn_weight and their gradients
 __global__ void __launch_bounds__(kRsThreads)
 msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
 {
@@ -594,10 +595,10 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
             while (todo) {                                     // sl = -1: the tile's current-frame points
                 const int sl = (int)__builtin_ctz(todo) - 1;
                 todo &= todo - 1;
-                const T *loc = static_cast<const T *>(sl < 0 ? p.locA : p.locB);
-                const T *aw = static_cast<const T *>(sl < 0 ? p.awA : p.awB);
-                T *gloc = static_cast<T *>(sl < 0 ? p.glocA : p.glocB);
-                T *gaw = static_cast<T *>(sl < 0 ? p.gawA : p.gawB);
+                const TL *loc = static_cast<const TL *>(sl < 0 ? p.locA : p.locB);
+                const TL *aw = static_cast<const TL *>(sl < 0 ? p.awA : p.awB);
+                TL *gloc = static_cast<TL *>(sl < 0 ? p.glocA : p.glocB);
+                TL *gaw = static_cast<TL *>(sl < 0 ? p.gawA : p.gawB);
                 const int P = sl < 0 ? p.PA : p.PB;
                 const int LP = (sl < 0 ? p.LA : p.LB) * P;
                 const int npts = (sl < 0 ? p.LA : L) * P;
@@ -615,7 +616,7 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                 int wr[4] = {0, 0, 0, 0};
                 const bool wide_ld = p.wide_loads && P == 4 && npts == 16;
                 float xs[4], ys[4], as[4];
-                if (wide_ld) load_slot_points<T>(loc, aw, idx0, cor, live, xs, ys, as);
+                if (wide_ld) load_slot_points<TL>(loc, aw, idx0, cor, live, xs, ys, as);
                 // every lane finishes its own point (cuh:123-158 on the reduced dots k[]; dots of corners outside the map are 0:
                 // their loads returned zeros)
                 auto finish = [&](const RsGeom &pt, const float (&k)[4], float &gx, float &gy, float &g_aw) {
@@ -712,7 +713,7 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                         x = get4(xs, g0 >> 2); y = get4(ys, g0 >> 2); a = get4(as, g0 >> 2);
                     } else if (mine) {
                         load_xy(loc + 2 * (idx0 + kk), x, y);
-                        a = Store<T>::get(aw + idx0 + kk);
+                        a = Store<TL>::get(aw + idx0 + kk);
                     }
                     const int lvl = min((int)(((unsigned)kk * invP) >> 16), L - 1);
                     // own point: corner addresses, fractions, validity (rs_geometry) -- the quad reads lane R's addresses in step R
@@ -762,9 +763,9 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                         if (wide) {
                             set4(wx, g0 >> 2, gx); set4(wy, g0 >> 2, gy); set4(wa, g0 >> 2, g_aw);
                         } else if (mine) {
-                            Store<T>::put(gloc + 2 * (idx0 + kk), gx);
-                            Store<T>::put(gloc + 2 * (idx0 + kk) + 1, gy);
-                            Store<T>::put(gaw + idx0 + kk, g_aw);
+                            Store<TL>::put(gloc + 2 * (idx0 + kk), gx);
+                            Store<TL>::put(gloc + 2 * (idx0 + kk) + 1, gy);
+                            Store<TL>::put(gaw + idx0 + kk, g_aw);
                         }
                     }
                 }
@@ -773,17 +774,17 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
                     quad_transpose4(wx, cor); quad_transpose4(wy, cor); quad_transpose4(wa, cor); quad_transpose4(wr, cor);
                     if (live) {
                         const float xy[8] = {wx[0], wy[0], wx[1], wy[1], wx[2], wy[2], wx[3], wy[3]};
-                        T *gl = gloc + 2 * (idx0 + 4 * cor);
-                        if constexpr (kHalf) {
-                            Store<T>::store(gl, xy);
+                        TL *gl = gloc + 2 * (idx0 + 4 * cor);
+                        if constexpr (sizeof(TL) == 2) {
+                            Store<TL>::store(gl, xy);
                         } else {
                             // (non-temporal: the 309 MB of results must not evict the level-0 lines the gathers live on)
                             typedef float f32x4 __attribute__((ext_vector_type(4)));
                             __builtin_nontemporal_store((f32x4){xy[0], xy[1], xy[2], xy[3]}, reinterpret_cast<f32x4 *>(gl));
                             __builtin_nontemporal_store((f32x4){xy[4], xy[5], xy[6], xy[7]}, reinterpret_cast<f32x4 *>(gl + 4));
                         }
-                        if constexpr (kHalf) {
-                            SlabStore<T>::store(gaw + idx0 + 4 * cor, wa);
+                        if constexpr (sizeof(TL) == 2) {
+                            SlabStore<TL>::store(gaw + idx0 + 4 * cor, wa);
                         } else {
                             typedef float f32x4 __attribute__((ext_vector_type(4)));
                             __builtin_nontemporal_store((f32x4){wa[0], wa[1], wa[2], wa[3]}, reinterpret_cast<f32x4 *>(gaw + idx0 + 4 * cor));
@@ -798,70 +799,64 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
     }
 }
 
-template <typename T, int NT, int PL0>
+template <typename T, typename TL, int NT, int PL0>
 int fwd_rs(const Params &p, int parts, unsigned grid, hipStream_t stream, const char *what)
 {
     static LdsGrant granted;
     const size_t total = (size_t)kRsSlabBytes + kRsTailBytes;
-    const auto kern = &msda_fwd_rs_kernel<T, NT, PL0>;
+    const auto kern = &msda_fwd_rs_kernel<T, TL, NT, PL0>;
     if (const int rc = grant_lds(reinterpret_cast<const void *>(kern), total, granted, "the resident-slab forward kernel")) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kRsThreads), total, stream, p, kRsSlabBytes, parts);
     return check_launch(what);
 }
 
-template <typename T, int PL0>
+template <typename T, typename TL, int PL0>
 int fwd_rs_nt(int nt, const Params &p, int parts, unsigned grid, hipStream_t stream)
 {
     switch (nt) {
-        case 4: return fwd_rs<T, 4, PL0>(p, parts, grid, stream, "msda forward (resident-slab kernel, 4 tiles per wave)");
-        case 2: return fwd_rs<T, 2, PL0>(p, parts, grid, stream, "msda forward (resident-slab kernel, 2 tiles per wave)");
-        default: return fwd_rs<T, 1, PL0>(p, parts, grid, stream, "msda forward (resident-slab kernel, 1 tiles per wave)");
+        case 4: return fwd_rs<T, TL, 4, PL0>(p, parts, grid, stream, "msda forward (resident-slab kernel, 4 tiles per wave)");
+        case 2: return fwd_rs<T, TL, 2, PL0>(p, parts, grid, stream, "msda forward (resident-slab kernel, 2 tiles per wave)");
+        default: return fwd_rs<T, TL, 1, PL0>(p, parts, grid, stream, "msda forward (resident-slab kernel, 1 tiles per wave)");
     }
 }
 
-template <typename T>
+template <typename T, typename TL>
 int fwd_rs_l0(int nt, int pl0, const Params &p, int parts, unsigned grid, hipStream_t stream)
 {
-    return pl0 == 2 ? fwd_rs_nt<T, 2>(nt, p, parts, grid, stream) : fwd_rs_nt<T, 1>(nt, p, parts, grid, stream);
+    return pl0 == 2 ? fwd_rs_nt<T, TL, 2>(nt, p, parts, grid, stream) : fwd_rs_nt<T, TL, 1>(nt, p, parts, grid, stream);
 }
 
-template <typename T, int PL0>
+template <typename T, typename TL, int PL0>
 int bwd_rs(const Params &p, int parts, unsigned grid, hipStream_t stream)
 {
     static LdsGrant granted;
     const size_t total = (size_t)kRsSlabBytes + kRsTailBytes;
-    const auto kern = &msda_bwd_rs_kernel<T, PL0>;
+    const auto kern = &msda_bwd_rs_kernel<T, TL, PL0>;
     if (const int rc = grant_lds(reinterpret_cast<const void *>(kern), total, granted, "the resident-slab gather-pass kernel")) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kRsThreads), total, stream, p, kRsSlabBytes, parts);
     return check_launch("msda backward (resident-slab kernel, grad_loc/grad_attn)");
 }
 
-template <typename T>
+template <typename T, typename TL>
 int bwd_rs_l0(int pl0, const Params &p, int parts, unsigned grid, hipStream_t stream)
 {
-    return pl0 == 2 ? bwd_rs<T, 2>(p, parts, grid, stream) : bwd_rs<T, 1>(p, parts, grid, stream);
+    return pl0 == 2 ? bwd_rs<T, TL, 2>(p, parts, grid, stream) : bwd_rs<T, TL, 1>(p, parts, grid, stream);
 }
 
 }  // namespace
 
 int launch_fwd_rs(int dtype, int nt, int first_slab_level, const Params &p, int parts, unsigned grid, hipStream_t stream)
 {
-    switch (dtype) {
-        case MSDA_F32: return fwd_rs_l0<float>(nt, first_slab_level, p, parts, grid, stream);
-        case MSDA_BF16: return fwd_rs_l0<bf16_t>(nt, first_slab_level, p, parts, grid, stream);
-        case MSDA_F16: return fwd_rs_l0<f16_t>(nt, first_slab_level, p, parts, grid, stream);
-        default: return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
-    }
+    return dispatch_types(dtype, [&](auto t, auto tl) {
+        return fwd_rs_l0<typename decltype(t)::type, typename decltype(tl)::type>(nt, first_slab_level, p, parts, grid, stream);
+    });
 }
 
 int launch_bwd_rs(int dtype, int first_slab_level, const Params &p, int parts, unsigned grid, hipStream_t stream)
 {
-    switch (dtype) {
-        case MSDA_F32: return bwd_rs_l0<float>(first_slab_level, p, parts, grid, stream);
-        case MSDA_BF16: return bwd_rs_l0<bf16_t>(first_slab_level, p, parts, grid, stream);
-        case MSDA_F16: return bwd_rs_l0<f16_t>(first_slab_level, p, parts, grid, stream);
-        default: return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
-    }
+    return dispatch_types(dtype, [&](auto t, auto tl) {
+        return bwd_rs_l0<typename decltype(t)::type, typename decltype(tl)::type>(first_slab_level, p, parts, grid, stream);
+    });
 }
 
 }  // namespace msda

@@ -49,7 +49,7 @@ namespace {
 constexpr int kScatterThreads = 1024;
 constexpr int kScatterList = 3072;         // capacity of the survivor list (12 KiB of the 16 KiB LDS left by the band)
 
-template <typename T, int G>
+template <typename T, typename TL, int G>        // T: grad_out, TL: sampling_loc / attn_weight
 __global__ void __launch_bounds__(kScatterThreads)
 msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
 {
@@ -168,14 +168,14 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
         const int VL = p.LA + p.LB;
         int n_cand = 0;
         const int pshift = (Pmax & (Pmax - 1)) == 0 ? __builtin_ctz(Pmax) : -1;     // i / Pmax as a shift
-        auto source_of = [&](int k, int &t, int &vl, int &vlg, int &P, int &LP, const T *&loc, const T *&aw) {
+        auto source_of = [&](int k, int &t, int &vl, int &vlg, int &P, int &LP, const TL *&loc, const TL *&aw) {
             t = s_src_t[k]; vl = s_src_vl[k];
             const bool cur = (k == 0);
             vlg = cur ? vl : p.LA + vl;
             P = cur ? p.PA : p.PB;
             LP = cur ? p.LA * p.PA : p.LB * p.PB;
-            loc = static_cast<const T *>(cur ? p.locA : p.locB);
-            aw = static_cast<const T *>(cur ? p.awA : p.awB);
+            loc = static_cast<const TL *>(cur ? p.locA : p.locB);
+            aw = static_cast<const TL *>(cur ? p.awA : p.awB);
         };
         // one candidate per lane per pass; the NEXT pass's (x, y, attn) are loaded before this pass's
         // hits are processed, so the scan's memory latency hides behind stage 2
@@ -185,14 +185,14 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
                 const int ei = pshift >= 0 ? (i >> pshift) : i / Pmax, pt = i - ei * Pmax;
                 const int e = s_list[ei];
                 int t, vl, vlg, P, LP;
-                const T *loc, *aw;
+                const TL *loc, *aw;
                 source_of(e >> 24, t, vl, vlg, P, LP, loc, aw);
                 if (pt < P) {
                     const int64_t gq = ((int64_t)clip * p.frames + t) * p.Lq + (e & 0xffffff);
                     const int64_t idx = (gq * p.M + m) * LP + vl * P + pt;
-                    x = Store<T>::get(loc + 2 * idx);
-                    y = Store<T>::get(loc + 2 * idx + 1);
-                    a = Store<T>::get(aw + idx);
+                    x = Store<TL>::get(loc + 2 * idx);
+                    y = Store<TL>::get(loc + 2 * idx + 1);
+                    a = Store<TL>::get(aw + idx);
                     qrow = (int)gq;
                 }
             }
@@ -295,7 +295,7 @@ msda_bwd_value_lds_kernel(const Params p, int cap_slots, int dbg)
                 k = gi / p.Lq; q = gi - k * p.Lq;
                 if (p.bbox) {
                     int t, vl, vlg, P, LP;
-                    const T *loc, *aw;
+                    const TL *loc, *aw;
                     source_of(k, t, vl, vlg, P, LP, loc, aw);
                     const int64_t gm = (((int64_t)clip * p.frames + t) * p.M + m) * VL + vlg;
                     const int2 iv = *reinterpret_cast<const int2 *>(p.bbox + (gm * p.Lq + q) * 2);
@@ -460,7 +460,7 @@ template <typename T> constexpr int grp_lds_bytes()
 // The grad_out rows are staged in LDS as FP32 whatever T is: a 16-bit row would have to be unpacked once per list entry in
 // the walk (16 entries read each row: measured 0.29 ms of walk for bf16 against 0.185 for fp32 on the bench workload),
 // now it is converted once, on its way in (4-byte types keep the LDS-DMA; 2-byte types go through registers).
-template <typename T, typename GV>
+template <typename T, typename TL, typename GV>        // TL: storage type of sampling_loc / attn_weight (T, or float with a 16-bit T)
 __global__ void __launch_bounds__(kOwnThreads)
 msda_bwd_value_grp_kernel(const Params p, int dbg)
 {
@@ -607,10 +607,10 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                 if ((e >> (22 + pt)) & 1u) {
                     const bool curf = (k == 0);
                     const int64_t idx = s_src_loc[k] + (int64_t)q * (curf ? strideA : strideB) + pt;
-                    const T *loc = static_cast<const T *>(curf ? p.locA : p.locB);
-                    const T *aw = static_cast<const T *>(curf ? p.awA : p.awB);
+                    const TL *loc = static_cast<const TL *>(curf ? p.locA : p.locB);
+                    const TL *aw = static_cast<const TL *>(curf ? p.awA : p.awB);
                     load_xy(loc + 2 * idx, x, y);
-                    a = Store<T>::get(aw + idx);
+                    a = Store<TL>::get(aw + idx);
                     qrow = s_src_q0[k] + q;
                     act = true;
                 }
@@ -939,37 +939,36 @@ msda_zero_unowned_kernel(const Params p, int cap_slots, int gv_bytes)
     }
 }
 
-template <typename T, int G>
+template <typename T, typename TL, int G>
 int scatter_lds(const Params &p, unsigned grid, int cap_bytes, int dbg, hipStream_t stream)
 {
     static LdsGrant granted;       // per instantiation and device
-    if (const int rc = grant_lds(reinterpret_cast<const void *>(&msda_bwd_value_lds_kernel<T, G>), (size_t)cap_bytes, granted,
-                                 "the LDS scatter kernel")) return rc;
-    hipLaunchKernelGGL((msda_bwd_value_lds_kernel<T, G>), dim3(grid), dim3(kScatterThreads), (size_t)cap_bytes, stream, p,
-                       cap_bytes / 8, dbg);
+    const auto kern = &msda_bwd_value_lds_kernel<T, TL, G>;
+    if (const int rc = grant_lds(reinterpret_cast<const void *>(kern), (size_t)cap_bytes, granted, "the LDS scatter kernel")) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kScatterThreads), (size_t)cap_bytes, stream, p, cap_bytes / 8, dbg);
     return check_launch("msda backward (LDS scatter kernel)");
 }
 
-template <typename T>
+template <typename T, typename TL>
 int scatter_lds_g(int G, const Params &p, unsigned grid, int cap_bytes, int dbg, hipStream_t stream)
 {
     switch (G) {
-        case 1: return scatter_lds<T, 1>(p, grid, cap_bytes, dbg, stream);
-        case 2: return scatter_lds<T, 2>(p, grid, cap_bytes, dbg, stream);
-        case 4: return scatter_lds<T, 4>(p, grid, cap_bytes, dbg, stream);
-        case 8: return scatter_lds<T, 8>(p, grid, cap_bytes, dbg, stream);
-        case 16: return scatter_lds<T, 16>(p, grid, cap_bytes, dbg, stream);
-        case 32: return scatter_lds<T, 32>(p, grid, cap_bytes, dbg, stream);
-        case 64: return scatter_lds<T, 64>(p, grid, cap_bytes, dbg, stream);
+        case 1: return scatter_lds<T, TL, 1>(p, grid, cap_bytes, dbg, stream);
+        case 2: return scatter_lds<T, TL, 2>(p, grid, cap_bytes, dbg, stream);
+        case 4: return scatter_lds<T, TL, 4>(p, grid, cap_bytes, dbg, stream);
+        case 8: return scatter_lds<T, TL, 8>(p, grid, cap_bytes, dbg, stream);
+        case 16: return scatter_lds<T, TL, 16>(p, grid, cap_bytes, dbg, stream);
+        case 32: return scatter_lds<T, TL, 32>(p, grid, cap_bytes, dbg, stream);
+        case 64: return scatter_lds<T, TL, 64>(p, grid, cap_bytes, dbg, stream);
         default: return fail(MSDA_ERR_ARG, "msda: unsupported lanes per row%s");
     }
 }
 
-template <typename T, typename GV>
+template <typename T, typename TL, typename GV>
 int scatter_grp(const Params &p, unsigned grid, int dbg, hipStream_t stream)
 {
     static LdsGrant granted;
-    const auto kern = &msda_bwd_value_grp_kernel<T, GV>;
+    const auto kern = &msda_bwd_value_grp_kernel<T, TL, GV>;
     if (const int rc = grant_lds(reinterpret_cast<const void *>(kern), (size_t)grp_lds_bytes<T>(), granted,
                                  "the group-granular owner-computes scatter kernel")) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kOwnThreads), (size_t)grp_lds_bytes<T>(), stream, p, dbg);
@@ -997,22 +996,21 @@ int launch_cull_summary(const Params &p, hipStream_t stream)
 
 int launch_scatter_lds(int dtype, int G, const Params &p, unsigned grid, int cap_bytes, int dbg, hipStream_t stream)
 {
-    switch (dtype) {
-        case MSDA_F32: return scatter_lds_g<float>(G, p, grid, cap_bytes, dbg, stream);
-        case MSDA_BF16: return scatter_lds_g<bf16_t>(G, p, grid, cap_bytes, dbg, stream);
-        case MSDA_F16: return scatter_lds_g<f16_t>(G, p, grid, cap_bytes, dbg, stream);
-        default: return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
-    }
+    return dispatch_types(dtype, [&](auto t, auto tl) {
+        return scatter_lds_g<typename decltype(t)::type, typename decltype(tl)::type>(G, p, grid, cap_bytes, dbg, stream);
+    });
 }
 
 int launch_scatter_grp(int dtype, bool storage_typed, const Params &p, unsigned grid, int dbg, hipStream_t stream)
 {
-    switch (dtype) {
-        case MSDA_F32: return scatter_grp<float, float>(p, grid, dbg, stream);
-        case MSDA_BF16: return storage_typed ? scatter_grp<bf16_t, bf16_t>(p, grid, dbg, stream) : scatter_grp<bf16_t, float>(p, grid, dbg, stream);
-        case MSDA_F16: return storage_typed ? scatter_grp<f16_t, f16_t>(p, grid, dbg, stream) : scatter_grp<f16_t, float>(p, grid, dbg, stream);
-        default: return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
-    }
+    return dispatch_types(dtype, [&](auto t, auto tl) {
+        using T = typename decltype(t)::type;
+        using TL = typename decltype(tl)::type;
+        if constexpr (sizeof(T) == 2) {
+            if (storage_typed) return scatter_grp<T, TL, T>(p, grid, dbg, stream);
+        }
+        return scatter_grp<T, TL, float>(p, grid, dbg, stream);
+    });
 }
 
 }  // namespace msda

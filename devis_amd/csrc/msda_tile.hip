@@ -104,8 +104,8 @@ __device__ __forceinline__ void init_tap_rows(int *entry, bool points)
 }
 
 // Builds the tap records of one chunk (<= kPch points of every row of the wave) in LDS.
-template <typename T, int RPW, bool BWD>
-__device__ __forceinline__ void build_chunk(const Params &p, const ChunkRef<T> &c,
+template <typename T, int RPW, bool BWD, typename TL>      // T: value type (out-of-map offset), TL: type of the chunk's loc / attn
+__device__ __forceinline__ void build_chunk(const Params &p, const ChunkRef<TL> &c,
                                             const Staged<staged_per_lane<RPW>()> &st, const Level *s_lvl,
                                             int4 *s_off, float4 *s_w, float4 *s_e, int lane,
                                             int *s_bb = nullptr, int nvl = 0)
@@ -137,7 +137,7 @@ __device__ __forceinline__ void build_chunk(const Params &p, const ChunkRef<T> &
 
 // NB = sampling points whose 4*NB corner loads are issued back to back before any FMA consumes them
 // (memory-level parallelism per wave); more points in flight cost VGPRs, i.e. waves per SIMD.
-template <typename T, int G, int NB>
+template <typename T, typename TL, int G, int NB>       // T: value / out, TL: sampling_loc / attn_weight
 __global__ void __launch_bounds__(kWave, 4)
 msda_fwd_tile_kernel(const Params p)
 {
@@ -175,8 +175,8 @@ msda_fwd_tile_kernel(const Params p)
     Staged<staged_per_lane<RPW>()> st;
 #pragma unroll 1
     for (int ci = 0; ci < n_all; ++ci) {
-        const ChunkRef<T> c = get_chunk<T>(p, ci, nA);
-        load_chunk<T, RPW>(p, c, row0, rows_valid, lane, st);
+        const ChunkRef<TL> c = get_chunk<TL>(p, ci, nA);
+        load_chunk<TL, RPW>(p, c, row0, rows_valid, lane, st);
         build_chunk<T, RPW, false>(p, c, st, s_lvl, s_off, s_w, nullptr, lane);
         __syncthreads();
         const int np = min(kPch, c.LP - c.p0);
@@ -291,7 +291,7 @@ __device__ __forceinline__ void row_sum4(float &d0, float &d1, float &d2, float 
 //                  the LDS scatter kernel below cannot take the shape).
 // ATOMICS = false: computes grad_sampling_loc / grad_attn_weight only; grad_value comes from
 //                  msda_bwd_value_lds_kernel.
-template <typename T, int G, bool ATOMICS>
+template <typename T, typename TL, int G, bool ATOMICS>      // T: value / grad_out, TL: sampling_loc / attn_weight + gradients
 __global__ void __launch_bounds__(kWave)
 msda_bwd_tile_kernel(const Params p)
 {
@@ -335,10 +335,10 @@ msda_bwd_tile_kernel(const Params p)
 #pragma unroll 1
     for (int ci = 0; ci < n_all; ++ci) {
         {
-            const ChunkRef<T> c = get_chunk<T>(p, ci, nA);
-            load_chunk<T, RPW>(p, c, row0, rows_valid, lane, st);
-            T *gloc = static_cast<T *>(c.arr ? p.glocB : p.glocA);
-            T *gaw = static_cast<T *>(c.arr ? p.gawB : p.gawA);
+            const ChunkRef<TL> c = get_chunk<TL>(p, ci, nA);
+            load_chunk<TL, RPW>(p, c, row0, rows_valid, lane, st);
+            TL *gloc = static_cast<TL *>(c.arr ? p.glocB : p.glocA);
+            TL *gaw = static_cast<TL *>(c.arr ? p.gawB : p.gawA);
             const int LP = c.LP, p0 = c.p0;
             build_chunk<T, RPW, true>(p, c, st, s_lvl, s_off, s_w, s_e, lane, s_bb, nvl);
             __syncthreads();
@@ -416,9 +416,9 @@ msda_bwd_tile_kernel(const Params p)
                 const int64_t idx0 = row * LP + p0;
                 const float *res = reinterpret_cast<const float *>(s_e + r * kRowSlots);
                 for (int el = sub; el < 2 * np; el += G)
-                    Store<T>::put(gloc + 2 * idx0 + el, res[(el >> 1) * 4 + (el & 1)]);
+                    Store<TL>::put(gloc + 2 * idx0 + el, res[(el >> 1) * 4 + (el & 1)]);
                 for (int el = sub; el < np; el += G)
-                    Store<T>::put(gaw + idx0 + el, res[el * 4 + 2]);
+                    Store<TL>::put(gaw + idx0 + el, res[el * 4 + 2]);
             }
             __syncthreads();
         }
@@ -435,29 +435,29 @@ msda_bwd_tile_kernel(const Params p)
 }
 
 
-template <typename T, int G>
+template <typename T, typename TL, int G>
 int fwd_tile(const Params &p, unsigned blocks, size_t lds, hipStream_t stream)
 {
     // points whose 4 * NB corner loads are in flight: 4 for 4-byte types; 2 for 2-byte types, whose lanes hold 8 channels
     // (4 points x 4 corners x 8 fp32 channels would be the whole register budget)
     constexpr int NB = sizeof(T) == 4 ? 4 : 2;
-    hipLaunchKernelGGL((msda_fwd_tile_kernel<T, G, NB>), dim3(blocks), dim3(kWave), lds, stream, p);
+    hipLaunchKernelGGL((msda_fwd_tile_kernel<T, TL, G, NB>), dim3(blocks), dim3(kWave), lds, stream, p);
     return check_launch("msda forward (tile kernel)");
 }
 
-template <typename T, int G>
+template <typename T, typename TL, int G>
 int bwd_tile(bool atomics, const Params &p, unsigned blocks, size_t lds, hipStream_t stream)
 {
     if (atomics) {
-        hipLaunchKernelGGL((msda_bwd_tile_kernel<T, G, true>), dim3(blocks), dim3(kWave), lds, stream, p);
+        hipLaunchKernelGGL((msda_bwd_tile_kernel<T, TL, G, true>), dim3(blocks), dim3(kWave), lds, stream, p);
         return check_launch("msda backward (tile kernel, global atomics)");
     }
-    hipLaunchKernelGGL((msda_bwd_tile_kernel<T, G, false>), dim3(blocks), dim3(kWave), lds, stream, p);
+    hipLaunchKernelGGL((msda_bwd_tile_kernel<T, TL, G, false>), dim3(blocks), dim3(kWave), lds, stream, p);
     return check_launch("msda backward (tile kernel, grad_loc/grad_attn)");
 }
 
 // G (lanes per row) -> instantiation
-template <typename T, class F>
+template <class F>
 int by_lanes(int G, F &&f)
 {
     switch (G) {
@@ -476,22 +476,20 @@ int by_lanes(int G, F &&f)
 
 int launch_fwd_tile(int dtype, int G, const Params &p, unsigned blocks, size_t lds, hipStream_t stream)
 {
-    switch (dtype) {
-        case MSDA_F32: return by_lanes<float>(G, [&](auto g) { return fwd_tile<float, decltype(g)::value>(p, blocks, lds, stream); });
-        case MSDA_BF16: return by_lanes<bf16_t>(G, [&](auto g) { return fwd_tile<bf16_t, decltype(g)::value>(p, blocks, lds, stream); });
-        case MSDA_F16: return by_lanes<f16_t>(G, [&](auto g) { return fwd_tile<f16_t, decltype(g)::value>(p, blocks, lds, stream); });
-        default: return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
-    }
+    return dispatch_types(dtype, [&](auto t, auto tl) {
+        return by_lanes(G, [&](auto g) {
+            return fwd_tile<typename decltype(t)::type, typename decltype(tl)::type, decltype(g)::value>(p, blocks, lds, stream);
+        });
+    });
 }
 
 int launch_bwd_tile(int dtype, int G, bool atomics, const Params &p, unsigned blocks, size_t lds, hipStream_t stream)
 {
-    switch (dtype) {
-        case MSDA_F32: return by_lanes<float>(G, [&](auto g) { return bwd_tile<float, decltype(g)::value>(atomics, p, blocks, lds, stream); });
-        case MSDA_BF16: return by_lanes<bf16_t>(G, [&](auto g) { return bwd_tile<bf16_t, decltype(g)::value>(atomics, p, blocks, lds, stream); });
-        case MSDA_F16: return by_lanes<f16_t>(G, [&](auto g) { return bwd_tile<f16_t, decltype(g)::value>(atomics, p, blocks, lds, stream); });
-        default: return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
-    }
+    return dispatch_types(dtype, [&](auto t, auto tl) {
+        return by_lanes(G, [&](auto g) {
+            return bwd_tile<typename decltype(t)::type, typename decltype(tl)::type, decltype(g)::value>(atomics, p, blocks, lds, stream);
+        });
+    });
 }
 
 }  // namespace msda

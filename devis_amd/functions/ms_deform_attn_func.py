@@ -43,8 +43,8 @@ def _check_op_shapes(value, shapes, lsi, loc, aw):
     _require(shapes.dtype == torch.int64 and lsi.dtype == torch.int64,
              "spatial_shapes / level_start_index must be int64")
     _require(tuple(shapes.shape) == (L, 2) and tuple(lsi.shape) == (L,), "bad spatial_shapes/level_start_index")
-    _require(loc.dtype == value.dtype and aw.dtype == value.dtype, "value/loc/attn must share one dtype")
-    _native.dtype_code(value.dtype)
+    _require(aw.dtype == loc.dtype, "sampling_locations / attention_weights must share one dtype")
+    _native.type_code(value.dtype, loc.dtype)       # value's dtype, or float32 beside a 16-bit value (raises otherwise)
 
 
 def _im2col_step(batch, im2col_step):
@@ -153,8 +153,8 @@ class MSDeformAttnTemporalFunction(Function):
         _require(loc_temp.dim() == 6 and tuple(loc_temp.shape[:4]) == (G, Lq, M, W * L) and
                  loc_temp.shape[5] == 2, "loc_temp must be [G, Lq, M, window*L, Pt, 2]")
         _require(tuple(aw_temp.shape) == tuple(loc_temp.shape[:5]), "aw_temp does not match loc_temp")
-        _require(loc_temp.dtype == value.dtype and aw_temp.dtype == value.dtype,
-                 "value/loc/attn must share one dtype")
+        _require(loc_temp.dtype == loc_curr.dtype and aw_temp.dtype == loc_curr.dtype,
+                 "current-frame and temporal sampling tensors must share one dtype")
         out = torch.empty((G, Lq, M * D), dtype=value.dtype, device=value.device)
         _native.temporal_forward(value, spatial_shapes, level_start_index, frame_table, loc_curr,
                                  aw_curr, loc_temp, aw_temp, clips, out)
@@ -276,11 +276,12 @@ def project_value(x, linear, n_heads, padding_mask=None, pad_heads=1, consumer_m
                                   bool(consumer_masks_grad) and padding_mask is not None)
 
 
-def _check_prep_inputs(y, named_refs, shapes):
-    """Preconditions of the fused pre-op pass.  msda_prep_* reads the reference points AS THE DTYPE OF ``y`` and
-    ``spatial_shapes`` as int64 device memory through raw pointers, so a mismatch would not fail, it would
-    reinterpret memory: reference points follow ``y`` (cast here when they differ -- DeVIS's
-    ``get_reference_points`` builds them in fp32 whatever the model's dtype), everything must sit on ``y``'s GPU."""
+def _check_prep_inputs(y, named_refs, shapes, sampling_dtype=None):
+    """Preconditions of the fused pre-op pass.  msda_prep_* reads the reference points AS THE SAMPLING DTYPE (``y``'s, or
+    float32 with MSDA_*_LOC32) and ``spatial_shapes`` as int64 device memory through raw pointers, so a mismatch would
+    not fail, it would reinterpret memory: reference points are cast here when they differ (DeVIS's
+    ``get_reference_points`` builds them in fp32 whatever the model's dtype: with float32 sampling they are used
+    unrounded), everything must sit on ``y``'s GPU."""
     if not y.is_cuda:
         raise RuntimeError("Not implemented on the CPU (the fused pre-op pass needs GPU tensors)")
     _native.dtype_code(y.dtype)
@@ -295,8 +296,15 @@ def _check_prep_inputs(y, named_refs, shapes):
         _require(isinstance(ref, torch.Tensor) and ref.is_floating_point(), "%s must be a floating-point tensor" % name)
         _require(ref.device == y.device, "%s must be on the same device as the query" % name)
         _require(ref.shape[-1] in (2, 4), "Last dim of reference_points must be 2 or 4, but get %d instead." % ref.shape[-1])
-        out.append(ref.to(y.dtype).contiguous())
+        out.append(ref.to(sampling_dtype or y.dtype).contiguous())
     return out
+
+
+def _sampling_dtype(raw_dtype, loc32):
+    """dtype of the sampling locations / attention weights the fused pre-op pass writes: the Linear outputs' dtype, or
+    float32 beside 16-bit Linears when `loc32` (include/msda.h MSDA_*_LOC32: a bf16 coordinate resolves only 0.16 px on an
+    80-pixel-wide level; the pass computes in fp32 anyway and hands the locations over unrounded)."""
+    return torch.float32 if (loc32 and raw_dtype in (torch.bfloat16, torch.float16)) else raw_dtype
 
 
 class MSDeformPrepFunction(Function):
@@ -309,13 +317,14 @@ class MSDeformPrepFunction(Function):
     temporal part).  Same arithmetic as ref ms_deform_attn.py:112-121 (locations) and :252-258 (softmax)."""
 
     @staticmethod
-    def forward(ctx, off_c, off_t, logit_c, logit_t, ref_c, ref_t, shapes):
+    def forward(ctx, off_c, off_t, logit_c, logit_t, ref_c, ref_t, shapes, loc32=False):
         R, M, L, Pc, _ = off_c.shape
         W = 0 if off_t is None else off_t.shape[2] // L
         Pt = 1 if off_t is None else off_t.shape[3]
         ctx.ref_dtypes = (ref_c.dtype if isinstance(ref_c, torch.Tensor) else None,
                           ref_t.dtype if isinstance(ref_t, torch.Tensor) else None)
-        ref_c, ref_t = _check_prep_inputs(off_c, (("reference_points", ref_c), ("temporal reference_points", ref_t if W else None)), shapes)
+        sdt = _sampling_dtype(off_c.dtype, loc32)
+        ref_c, ref_t = _check_prep_inputs(off_c, (("reference_points", ref_c), ("temporal reference_points", ref_t if W else None)), shapes, sdt)
         _require(logit_c.dtype == off_c.dtype and logit_c.device == off_c.device, "offsets / logits must share dtype and device")
         off_c, logit_c = off_c.contiguous(), logit_c.contiguous()
         _require(tuple(ref_c.shape) == (R, L, ref_c.shape[-1]), "reference_points must be [rows, L, 2|4]")
@@ -324,9 +333,9 @@ class MSDeformPrepFunction(Function):
             _require(tuple(ref_t.shape) == (R, W * L, ref_t.shape[-1]) and ref_t.shape[-1] == ref_c.shape[-1],
                      "temporal reference_points must be [rows, window*L, 2|4]")
             off_t, logit_t = off_t.contiguous(), logit_t.contiguous()
-        loc_c, aw_c = torch.empty_like(off_c), torch.empty((R, M, L, Pc), dtype=off_c.dtype, device=off_c.device)
-        loc_t = torch.empty_like(off_t) if W else None
-        aw_t = torch.empty((R, M, W * L, Pt), dtype=off_c.dtype, device=off_c.device) if W else None
+        loc_c, aw_c = torch.empty_like(off_c, dtype=sdt), torch.empty((R, M, L, Pc), dtype=sdt, device=off_c.device)
+        loc_t = torch.empty_like(off_t, dtype=sdt) if W else None
+        aw_t = torch.empty((R, M, W * L, Pt), dtype=sdt, device=off_c.device) if W else None
         _native.prep_forward(off_c, off_t, logit_c, logit_t, ref_c, ref_t, shapes, R, M, L, W, Pc, Pt,
                              loc_c, loc_t, aw_c, aw_t)
         ctx.save_for_backward(aw_c, aw_t, ref_c, ref_t, shapes, off_c, off_t)
@@ -338,7 +347,7 @@ class MSDeformPrepFunction(Function):
     def backward(ctx, gloc_c, gloc_t, gaw_c, gaw_t):
         aw_c, aw_t, ref_c, ref_t, shapes, off_c, off_t = ctx.saved_tensors
         R, M, L, W, Pc, Pt = ctx.dims
-        zeros = lambda like: torch.zeros_like(like)
+        zeros = lambda like: torch.zeros_like(like, dtype=aw_c.dtype)        # (the sampling-side dtype: see _sampling_dtype)
         gloc_c = zeros(off_c) if gloc_c is None else gloc_c.contiguous()
         gaw_c = zeros(aw_c) if gaw_c is None else gaw_c.contiguous()
         if W:
@@ -359,7 +368,7 @@ class MSDeformPrepFunction(Function):
 
         gref_c = ref_grad(gloc_c, off_c, ref_c, Pc).to(ctx.ref_dtypes[0]) if ctx.needs_input_grad[4] else None
         gref_t = ref_grad(gloc_t, off_t, ref_t, Pt).to(ctx.ref_dtypes[1]) if (W and ctx.needs_input_grad[5]) else None
-        return goff_c, goff_t, glogit_c, glogit_t, gref_c, gref_t, None
+        return goff_c, goff_t, glogit_c, glogit_t, gref_c, gref_t, None, None
 
 
 class MSDeformPrepFusedFunction(Function):
@@ -376,7 +385,7 @@ class MSDeformPrepFusedFunction(Function):
         return [(a, a + b) for a, b in zip(o, n)]
 
     @staticmethod
-    def forward(ctx, y, ref_c, ref_t, shapes, M, L, W, Pc, Pt):
+    def forward(ctx, y, ref_c, ref_t, shapes, M, L, W, Pc, Pt, loc32=False):
         R = y.shape[0]
         if y.stride(1) != 1:
             y = y.contiguous()
@@ -385,15 +394,16 @@ class MSDeformPrepFusedFunction(Function):
         v = [y[:, a:b] for a, b in cols]
         ctx.ref_dtypes = (ref_c.dtype if isinstance(ref_c, torch.Tensor) else None,
                           ref_t.dtype if isinstance(ref_t, torch.Tensor) else None)
-        ref_c, ref_t = _check_prep_inputs(y, (("reference_points", ref_c), ("temporal reference_points", ref_t if W else None)), shapes)
+        sdt = _sampling_dtype(y.dtype, loc32)
+        ref_c, ref_t = _check_prep_inputs(y, (("reference_points", ref_c), ("temporal reference_points", ref_t if W else None)), shapes, sdt)
         _require(tuple(ref_c.shape) == (R, L, ref_c.shape[-1]), "reference_points must be [rows, L, 2|4]")
         if W:
             _require(tuple(ref_t.shape) == (R, W * L, ref_t.shape[-1]) and ref_t.shape[-1] == ref_c.shape[-1],
                      "temporal reference_points must be [rows, window*L, 2|4]")
-        loc_c = torch.empty((R, M, L, Pc, 2), dtype=y.dtype, device=y.device)
-        aw_c = torch.empty((R, M, L, Pc), dtype=y.dtype, device=y.device)
-        loc_t = torch.empty((R, M, W * L, Pt, 2), dtype=y.dtype, device=y.device) if W else None
-        aw_t = torch.empty((R, M, W * L, Pt), dtype=y.dtype, device=y.device) if W else None
+        loc_c = torch.empty((R, M, L, Pc, 2), dtype=sdt, device=y.device)
+        aw_c = torch.empty((R, M, L, Pc), dtype=sdt, device=y.device)
+        loc_t = torch.empty((R, M, W * L, Pt, 2), dtype=sdt, device=y.device) if W else None
+        aw_t = torch.empty((R, M, W * L, Pt), dtype=sdt, device=y.device) if W else None
         _native.prep_forward(v[0], v[1] if W else None, v[2], v[3] if W else None, ref_c, ref_t, shapes, R, M, L, W,
                              Pc, Pt if W else 1, loc_c, loc_t, aw_c, aw_t, ld=y.stride(0))
         ctx.save_for_backward(aw_c, aw_t, ref_c, ref_t, shapes, y)
@@ -425,4 +435,4 @@ class MSDeformPrepFusedFunction(Function):
 
         gref_c = ref_grad(gloc_c, y[:, cols[0][0]:cols[0][1]], ref_c, Pc).to(ctx.ref_dtypes[0]) if ctx.needs_input_grad[1] else None
         gref_t = ref_grad(gloc_t, y[:, cols[1][0]:cols[1][1]], ref_t, Pt).to(ctx.ref_dtypes[1]) if (W and ctx.needs_input_grad[2]) else None
-        return gy, gref_c, gref_t, None, None, None, None, None, None
+        return gy, gref_c, gref_t, None, None, None, None, None, None, None

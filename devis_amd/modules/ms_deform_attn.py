@@ -91,6 +91,8 @@ def _locations(reference, offsets, normalizer, n_points):
 class MSDeformAttn(nn.Module):
     value_pad_heads = 1     # spare head slots per pixel row of `value` (0 = the reference's dense layout)
     fused_prep = True       # softmax + sampling-location arithmetic in one fused pass (False: torch ops)
+    sampling_fp32 = True    # 16-bit modules: the fused pass hands sampling locations / weights to the operator in float32
+                            # (a bf16 coordinate resolves 0.16 px on an 80-pixel level; False: the module's own dtype)
 
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
         """Multi-Scale Deformable Attention Module (ref ``ms_deform_attn.py:30-132``).
@@ -153,7 +155,7 @@ class MSDeformAttn(nn.Module):
             y = F.linear(query.reshape(R, -1), *_fused_linear_params(self, (self.sampling_offsets, self.attention_weights)))
             locations, _, weights, _ = MSDeformPrepFusedFunction.apply(
                 y, reference_points.reshape(R, L, reference_points.shape[-1]), None, input_spatial_shapes,
-                M, L, 0, P, 1)
+                M, L, 0, P, 1, self.sampling_fp32)
             locations, weights = locations.view(N, Len_q, M, L, P, 2), weights.view(N, Len_q, M, L, P)
         else:
             offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
@@ -171,6 +173,7 @@ class TemporalMSDeformAttnBase(nn.Module):
 
     fused = True   # False: replay the reference's 2*T-call pattern (same results)
     fused_prep = True       # joint softmax + sampling-location arithmetic in one fused pass (False: torch ops)
+    sampling_fp32 = True    # 16-bit modules: float32 sampling locations / weights out of the fused pass (see MSDeformAttn)
     value_pad_heads = 1     # spare head slots per pixel row of `value` (0 = the reference's dense layout)
 
     def __init__(self, n_frames=36, d_model=256, n_levels=4, t_window=2, n_heads=8, n_curr_points=4,
@@ -258,7 +261,7 @@ class TemporalMSDeformAttnBase(nn.Module):
         y = F.linear(query.reshape(R, -1), *_fused_linear_params(self, lins))
         loc_c, loc_t, w_c, w_t = MSDeformPrepFusedFunction.apply(
             y, ref_curr.reshape(R, L, d), ref_temp.expand(T, Len_q, W * L, d).reshape(R, W * L, d), shapes,
-            M, L, W, Pc, Pt)
+            M, L, W, Pc, Pt, self.sampling_fp32)
         return (value, loc_c.view(T, Len_q, M, L, Pc, 2), loc_t.view(T, Len_q, M, W * L, Pt, 2),
                 w_c.view(T, Len_q, M, L, Pc), w_t.view(T, Len_q, M, W * L, Pt))
 

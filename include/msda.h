@@ -57,10 +57,17 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 10
+#define MSDA_ABI_VERSION 11
 #define MSDA_BWD_WORKSPACE_BYTES 64   /* minimum device scratch of the backward entry points (ticket counters) */
 
-enum msda_dtype { MSDA_F32 = 0, MSDA_F64 = 1, MSDA_BF16 = 2, MSDA_F16 = 3 };
+enum msda_dtype {
+    MSDA_F32 = 0, MSDA_F64 = 1, MSDA_BF16 = 2, MSDA_F16 = 3,
+    /* ABI v11, operator entry points and msda_prep_*: value / out / grad_out in bf16 / f16, but sampling_loc, attn_weight and
+     * their gradients in FLOAT.  A normalised coordinate stored in bf16 resolves 2^-9 = 0.16 px on an 80-pixel-wide level
+     * (f16: 0.02 px), which caps the accuracy of 16-bit modules; the fused pre-op pass computes locations in fp32 anyway and
+     * hands them over unrounded with these codes.  msda_prep_*: offsets / logits in the 16-bit type, reference points in float. */
+    MSDA_BF16_LOC32 = 4, MSDA_F16_LOC32 = 5
+};
 
 enum msda_status {
     MSDA_OK = 0,

@@ -99,7 +99,7 @@ def cfg_sample(a):
                                                                       flat.min(), flat.max()])}
 
 
-def cfg_build(kind, module_cls, dtype=torch.float64):
+def cfg_build(kind, module_cls, dtype=torch.float64, ref_dtype=None):
     """(module, args, names of the args that get gradients) for kind in {'dec', 'enc'}; `module_cls` is the reference's
     or our TemporalMSDeformAttn{Decoder,Encoder}.  Everything is drawn on the CPU in float64 from fixed seeds."""
     c = CFG
@@ -130,12 +130,15 @@ def cfg_build(kind, module_cls, dtype=torch.float64):
                              .reshape(-1, 2).flip(-1) for h, w in c["pyramid"]], 0)
         ref = centres[None, :, None, :].expand(T, S, L, 2).contiguous()
     loss_w = torch.randn(query.shape[0] if kind == "enc" else 1, query.shape[1], C, generator=g, dtype=torch.float64)
-    args = [query.to(dtype), ref.to(dtype), src.to(dtype), (shapes, t_shapes), (lsi, t_lsi), offsets]
+    # (ref_dtype: DeVIS's encoder builds its reference points in fp32 whatever the model's dtype, deformable_transformer.py:185-198)
+    args = [query.to(dtype), ref.to(ref_dtype or dtype), src.to(dtype), (shapes, t_shapes), (lsi, t_lsi), offsets]
     return mod.to(dtype), args, loss_w.to(dtype)
 
 
-def cfg_run(kind, module_cls, device="cpu", dtype=torch.float64):
-    mod, args, loss_w = cfg_build(kind, module_cls, dtype)
+def cfg_run(kind, module_cls, device="cpu", dtype=torch.float64, ref_dtype=None, sampling_fp32=None):
+    mod, args, loss_w = cfg_build(kind, module_cls, dtype, ref_dtype)
+    if sampling_fp32 is not None:
+        mod.sampling_fp32 = sampling_fp32
     mod = mod.to(device)
     mv = lambda x: x.to(device) if isinstance(x, torch.Tensor) else type(x)(y.to(device) for y in x)
     args = [mv(a) for a in args]

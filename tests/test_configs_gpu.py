@@ -70,11 +70,12 @@ BENCH_SCALE = [
     (torch.float32, 32, "dense", 4, 1e-5, 1e-4),           # 4 tiles per wave forced (fp32 picks 1): accumulator sets 2 and 3 in use
     (torch.bfloat16, 16, "dense", 4, 1e-2, 2e-2),          # 16-bit storage: 4 tiles per wave at the bench's 16 clips
     (torch.float16, 16, "dense", 4, 1e-3, 4e-3),
+    (torch.bfloat16, 16, "loc32", 4, 1e-2, 2e-2),          # bf16 value, float32 sampling locations / weights (MSDA_BF16_LOC32)
 ]
 
 
 @pytest.mark.parametrize("dtype,clips,layout,want_nt,tol_out,tol_grad", BENCH_SCALE,
-                         ids=["f32-16", "f32-16-padded", "f32-32-nt4", "bf16-16-nt4", "f16-16-nt4"])
+                         ids=["f32-16", "f32-16-padded", "f32-32-nt4", "bf16-16-nt4", "f16-16-nt4", "bf16-16-fp32-sampling"])
 def test_bench_scale_batch_against_the_oracle(dtype, clips, layout, want_nt, tol_out, tol_grad, monkeypatch):
     """The regimes bench.py times -- 16 / 32 cfg3 clips in ONE fused call (resident-slab forward and gather pass with
     2 or 4 tiles per wave, owner-computes scatter), fp32 and 16-bit storage, dense and padded `value` -- compared clip
@@ -92,7 +93,14 @@ def test_bench_scale_batch_against_the_oracle(dtype, clips, layout, want_nt, tol
           for c in range(clips)]
     shapes, lsi, ftab = (torch.from_numpy(ds[0][k]).to(DEV) for k in ("shapes", "lsi", "ftab"))
     keys = ("value", "loc_c", "aw_c", "loc_t", "aw_t")
-    cat = lambda k: torch.from_numpy(np.concatenate([d[k] for d in ds], 0)).to(DEV, dtype)
+    loc32 = layout == "loc32"
+    if loc32:           # only value / grad_out are rounded to the storage type; locations and weights stay fp32
+        ds = [dict(make_temporal_inputs(900 + c, T=T, W=5, M=M, D=D, Lq=Lq, shapes=PYR_A, Pc=4, Pt=4),
+                   **{k: round_to({k: np.asarray(v, dtype=np.float64)}, dtype)[k] for k, v in
+                      make_temporal_inputs(900 + c, T=T, W=5, M=M, D=D, Lq=Lq, shapes=PYR_A, Pc=4, Pt=4).items() if k in ("value", "grad_out")})
+              for c in range(clips)]
+    cat = lambda k: torch.from_numpy(np.concatenate([d[k] for d in ds], 0)).to(
+        DEV, torch.float32 if (loc32 and k in ("loc_c", "aw_c", "loc_t", "aw_t")) else dtype)
     leaves = [cat(k).requires_grad_(True) for k in keys]
     if layout == "padded":
         buf = torch.zeros((clips * T, leaves[0].shape[1], M + 1, D), dtype=dtype, device=DEV)
@@ -122,7 +130,7 @@ def test_bench_scale_batch_against_the_oracle(dtype, clips, layout, want_nt, tol
             want = ref32[i] if name.startswith("grad_loc") else ref[i]
             tol = tol_grad if i else tol_out
             scale = max(1.0, np.abs(want).max())
-            if name.startswith("grad_loc") and dtype != torch.float32:
+            if name.startswith("grad_loc") and dtype != torch.float32 and not loc32:
                 # 16-bit results: rounding on top of the border effect -- all but a few per mille within tolerance
                 assert (np.abs(mine - want) > tol * scale).mean() <= 2e-3, (c, name)
             else:
@@ -132,27 +140,35 @@ def test_bench_scale_batch_against_the_oracle(dtype, clips, layout, want_nt, tol
 MODULE_FIXTURES = [n for n in golden_names("mod_") if n != "mod_fresh_init"]
 
 
-@pytest.mark.parametrize("dtype,tol_out,tol_grad", [(torch.bfloat16, 1e-1, 5e-1), (torch.float16, 1.5e-2, 1.5e-1)], ids=["bf16", "f16"])
+@pytest.mark.parametrize("dtype,sampling,tol_out,tol_grad", [
+    (torch.bfloat16, "fp32", 1e-2, 1e-1), (torch.float16, "fp32", 2e-3, 3e-2),
+    (torch.bfloat16, "storage", 1e-1, 5e-1), (torch.float16, "storage", 1.5e-2, 1.5e-1)],
+    ids=["bf16-fp32-sampling", "f16-fp32-sampling", "bf16", "f16"])
 @pytest.mark.parametrize("kind", ["dec", "enc"])
-def test_config_sized_modules_reduced_precision_vs_reference_fixture(kind, dtype, tol_out, tol_grad):
-    """The temporal decoder / encoder at DeVIS's real size in bf16 / f16 (parameters, activations, `value` AND the
-    sampling locations stored in 16 bits, arithmetic fp32) against the fp64 fixture captured from the REFERENCE modules
-    (tests/golden/cfg_*.npz), norm-wise over the sampled elements.  The bounds are what 16-bit SAMPLING LOCATIONS allow,
-    not what the operator does to given inputs (that is 1e-2 / 1e-3, tests/test_op_gpu.py): a normalised coordinate in
-    [0.5, 1) resolves 2^-9 in bf16 = 0.16 px on the 80-pixel-wide level 0 (f16: 2^-12 = 0.02 px), and the maps here are
-    white noise.  Measured: outputs 6e-2 (bf16) / 9e-3 (f16); gradients are piecewise-constant bilinear derivatives -- a
-    location rounded across a cell border flips single terms -- hence the looser norm-wise bound on them."""
+def test_config_sized_modules_reduced_precision_vs_reference_fixture(kind, dtype, sampling, tol_out, tol_grad):
+    """The temporal decoder / encoder at DeVIS's real size in bf16 / f16 (parameters, activations and `value` stored in
+    16 bits, arithmetic fp32) against the fp64 fixture captured from the REFERENCE modules (tests/golden/cfg_*.npz),
+    norm-wise over the sampled elements.
+    * `fp32` sampling (the modules' default, ABI v11 MSDA_*_LOC32): the fused pre-op pass hands sampling locations and
+      attention weights to the operator in float32 and uses the (fp32) reference points unrounded -- outputs within the
+      north_star's 1e-2 for bf16.
+    * `storage` sampling (`sampling_fp32 = False`, reference points in the module's dtype): everything in 16 bits; a
+      normalised coordinate in [0.5, 1) then resolves 2^-9 in bf16 = 0.16 px on the 80-pixel-wide level 0 (f16: 0.02 px) on
+      white-noise maps: measured 6e-2 (bf16) / 9e-3 (f16) on outputs.
+    Gradients are piecewise-constant bilinear derivatives -- a location rounded across a cell border flips single
+    terms -- hence the looser norm-wise bound on them."""
     from conftest import golden
     from devis_amd.modules import TemporalMSDeformAttnDecoder, TemporalMSDeformAttnEncoder
     g = golden("cfg_" + kind)
     cls = TemporalMSDeformAttnDecoder if kind == "dec" else TemporalMSDeformAttnEncoder
-    got = module_cases.cfg_run(kind, cls, device=DEV, dtype=dtype)
+    got = module_cases.cfg_run(kind, cls, device=DEV, dtype=dtype, ref_dtype=torch.float32 if sampling == "fp32" else None,
+                               sampling_fp32=sampling == "fp32")
     report = {}
     for k, v in got.items():
         assert np.isfinite(v).all(), k
         mine, want = module_cases.cfg_sample(v)["sample"], g[k + "/sample"]
         report[k] = float(np.linalg.norm(mine - want) / max(1e-12, np.linalg.norm(want)))
-    print("cfg_%s %s relative errors:" % (kind, dtype), {k: "%.2e" % e for k, e in report.items()})
+    print("cfg_%s %s %s-sampling relative errors:" % (kind, dtype, sampling), {k: "%.2e" % e for k, e in report.items()})
     for k, rel in report.items():
         assert rel <= (tol_out if (k == "out" or k.startswith("aux/")) else tol_grad), (k, rel)
 
@@ -177,7 +193,8 @@ def test_gradcheck_reference_large_head_dims():
 def test_fused_prep_takes_reference_points_of_another_dtype():
     """DeVIS builds reference points in fp32 (get_reference_points) whatever the model's dtype; the fused pre-op pass
     reads raw pointers, so it must cast rather than reinterpret: a bf16 module fed fp32 reference points
-    equals the same module fed bf16 reference points, and agrees with the torch-op path."""
+    with 16-bit sampling (`sampling_fp32 = False`) equals the same module fed bf16 reference points, and agrees with the
+    torch-op path; with fp32 sampling (the default) the fp32 reference points are used unrounded."""
     from devis_amd.modules import MSDeformAttn
     torch.manual_seed(1)
     C, M, L, P, N, Lq = 64, 8, 2, 4, 2, 50
@@ -193,9 +210,13 @@ def test_fused_prep_takes_reference_points_of_another_dtype():
     src = torch.randn(N, S, C, device=DEV, dtype=torch.bfloat16)
     ref32 = torch.rand(N, Lq, L, 2, device=DEV, dtype=torch.float32)
     ref16 = ref32.to(torch.bfloat16)
+    out_f = mod(query, ref32, src, shapes, lsi, None)[0]            # fp32 sampling: unrounded reference points
+    mod.sampling_fp32 = False
     out_a = mod(query, ref32, src, shapes, lsi, None)[0]
     out_b = mod(query, ref16, src, shapes, lsi, None)[0]
     assert torch.isfinite(out_a).all() and torch.equal(out_a, out_b)
+    assert torch.isfinite(out_f).all() and not torch.equal(out_f, out_a)
+    assert (out_f.float() - out_a.float()).abs().max().item() <= 5e-2 * max(1.0, out_a.float().abs().max().item())
     mod.fused_prep = False
     out_c = mod(query, ref16, src, shapes, lsi, None)[0]
     assert (out_a.float() - out_c.float()).abs().max().item() <= 5e-2 * max(1.0, out_c.float().abs().max().item())

@@ -657,3 +657,51 @@ def test_graph_replay_equals_eager():
                 assert _maxabs(a.double().cpu().numpy(), b.double().cpu().numpy()) <= 1e-5 * max(1.0, float(b.abs().max()))
             else:
                 assert torch.equal(a, b), i
+
+
+@pytest.mark.parametrize("env", [{}, {"MSDA_FWD_RS": "1", "MSDA_BWD_RS": "1"}, {"MSDA_FORCE_GENERIC": "1"}, {"MSDA_SCATTER_OWN": "0"},
+                                 {"MSDA_BWD_MODE": "atomic"}],
+                         ids=["auto", "resident-slab", "generic", "lds-scatter", "atomic"])
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3)], ids=["bf16", "f16"])
+def test_fp32_sampling_beside_a_16_bit_value(dtype, tol, env, monkeypatch):
+    """ABI v11 (MSDA_BF16_LOC32 / MSDA_F16_LOC32): value / out / grad_out in 16 bits, sampling locations and attention
+    weights -- and their gradients -- in float32, on every route, plain and fused temporal op, against the fp64 oracle on
+    the same inputs (only value and grad_out rounded).  grad_loc / grad_attn come back in float32."""
+    from devis_amd.functions import MSDeformAttnFunction, MSDeformAttnTemporalFunction
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    shapes = [(12, 20), (6, 10), (3, 5), (2, 3)]
+    d = make_inputs(61, 2, 8, 32, 45, shapes, 4, "wide", np.float32, value_scale=1.0)
+    d.update(round_to({k: np.asarray(d[k], dtype=np.float64) for k in ("value", "grad_out")}, dtype))
+    ref = oracle_fwd_bwd(d, np.float64)
+    ref32 = oracle_fwd_bwd({k: (np.asarray(v, dtype=np.float32) if v.dtype.kind == "f" else v) for k, v in d.items()}, np.float32)
+    v = torch.from_numpy(np.asarray(d["value"], dtype=np.float64)).to(DEV, dtype).requires_grad_(True)
+    loc = torch.from_numpy(d["loc"]).to(DEV).requires_grad_(True)
+    aw = torch.from_numpy(d["aw"]).to(DEV).requires_grad_(True)
+    assert loc.dtype == torch.float32
+    out = MSDeformAttnFunction.apply(v, torch.from_numpy(d["shapes"]).to(DEV), torch.from_numpy(d["lsi"]).to(DEV), loc, aw, 64)
+    go = torch.from_numpy(np.asarray(d["grad_out"], dtype=np.float64)).to(DEV, dtype)
+    gv, gl, ga = torch.autograd.grad(out, (v, loc, aw), go)
+    assert out.dtype == dtype and gv.dtype == dtype and gl.dtype == torch.float32 and ga.dtype == torch.float32
+    scale = lambda x: max(1.0, float(np.abs(x).max()))
+    npy = lambda t: t.detach().double().cpu().numpy()
+    assert _maxabs(npy(out), ref[0]) <= tol * scale(ref[0])
+    assert _maxabs(npy(gv), ref[1]) <= 2 * tol * scale(ref[1])
+    assert _maxabs(npy(gl), ref32[2]) <= 1e-4 * scale(ref32[2])       # fp32 arithmetic on the same rounded value
+    assert _maxabs(npy(ga), ref[3]) <= 1e-4 * scale(ref[3])
+    # fused temporal op
+    dt = make_temporal_inputs(62, T=3, W=2, M=8, D=32, Lq=40, shapes=shapes[:3], Pc=4, Pt=3)
+    dt.update(round_to({k: np.asarray(dt[k], dtype=np.float64) for k in ("value", "grad_out")}, dtype))
+    keys = ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")
+    tref = temporal_reference(*(np.asarray(dt[k], dtype=np.float64) if dt[k].dtype.kind == "f" else dt[k] for k in keys))
+    f = lambda k, t: torch.from_numpy(np.asarray(dt[k], dtype=np.float64)).to(DEV, t).requires_grad_(True)
+    tv = f("value", dtype)
+    tl = [f(k, torch.float32) for k in ("loc_c", "aw_c", "loc_t", "aw_t")]
+    tout = MSDeformAttnTemporalFunction.apply(tv, torch.from_numpy(dt["shapes"]).to(DEV), torch.from_numpy(dt["lsi"]).to(DEV),
+                                              torch.from_numpy(dt["ftab"]).to(DEV), *tl, 1)
+    tg = torch.autograd.grad(tout, [tv] + tl, torch.from_numpy(np.asarray(dt["grad_out"], dtype=np.float64)).to(DEV, dtype))
+    got = [tout] + list(tg)
+    for i, (a, b) in enumerate(zip(got, tref)):
+        if i in (2, 4):
+            continue        # grad_loc against an fp64 reference flips cells at pixel borders (checked above against fp32)
+        assert _maxabs(npy(a), b) <= (2 * tol if i < 2 else 1e-4) * scale(b), i
