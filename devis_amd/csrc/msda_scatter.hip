@@ -460,6 +460,13 @@ template <typename T> constexpr int grp_lds_bytes()
 // The grad_out rows are staged in LDS as FP32 whatever T is: a 16-bit row would have to be unpacked once per list entry in
 // the walk (16 entries read each row: measured 0.29 ms of walk for bf16 against 0.185 for fp32 on the bench workload),
 // now it is converted once, on its way in (4-byte types keep the LDS-DMA; 2-byte types go through registers).
+// A value the compiler must recompute where it is used (keeps loop-invariant per-thread addresses out of long-lived registers).
+__device__ __forceinline__ int per_item(int x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 template <typename T, typename TL, typename GV>        // TL: storage type of sampling_loc / attn_weight (T, or float with a 16-bit T)
 __global__ void __launch_bounds__(kOwnThreads)
 msda_bwd_value_grp_kernel(const Params p, int dbg)
@@ -567,7 +574,9 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         // frame_table[t, w] == f; per source the first culling-table entry, first loc/attn element, first query row
         if (wave == 0) {
             const int n_tw = p.frames * p.window;
-            const bool hit = lane < n_tw && p.ftab[lane] == f;
+            // (per_item(): the address is formed here, once per item, instead of living in registers across the item loop --
+            // loop-invariant 64-bit addresses hoisted out of it were this kernel's only VGPR spills)
+            const bool hit = lane < n_tw && p.ftab[per_item(lane)] == f;
             const u64 bal = __ballot(hit);
             if (lane == 0) {
                 const int64_t g = (int64_t)clip * p.frames + f;
@@ -578,7 +587,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                 s_nsrc = 1 + (int)__popcll(bal);
             }
             if (hit) {
-                const int n = 1 + (int)__popcll(bal & ((1ull << lane) - 1ull)), t = lane / p.window;
+                const int n = 1 + (int)__popcll(bal & ((1ull << per_item(lane)) - 1ull)), t = lane / p.window;
                 const int vl = (lane - t * p.window) * L + l;
                 const int64_t g = (int64_t)clip * p.frames + t;
                 s_src_tab[n] = ((g * p.M + m) * VL + p.LA + vl) * p.Lq;
@@ -625,7 +634,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         u32x4 raw_rows[kHalf ? RPWV / HPI : 1];
         auto stage_rows = [&](int base, int n) {
             if (direct || (dbg & 4)) return;
-            const T *go = static_cast<const T *>(p.grad_out) + m * D + (lane % LPR) * (16 / (int)sizeof(T));
+            const T *go = static_cast<const T *>(p.grad_out) + m * D + per_item(lane % LPR) * (16 / (int)sizeof(T));
 #pragma unroll
             for (int i = 0; i < RPWV / HPI; ++i) {
                 const int r0w = wave * RPWV + HPI * i;
@@ -854,12 +863,13 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         };
         if (!direct && SF == 1) {
             GV *gband = gmap + (int64_t)r0 * W * MD;
+            GV *gquad = gband + (int64_t)per_item(Q) * MD;          // pixel Q of the band; slot s is kOwnQuads pixels further
 #pragma unroll
             for (int s = 0; s < kOwnSlots; ++s) {
                 const int pix = s * kOwnQuads + Q;
                 if constexpr (std::is_same<GV, float>::value) {
                     if (pix < npix) {
-                        GV *o = gband + (int64_t)pix * MD;
+                        GV *o = gquad + (int64_t)s * kOwnQuads * MD;
                         put4(o + ch1, acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
                         put4(o + ch2, acc[s][4], acc[s][5], acc[s][6], acc[s][7]);
                     }
@@ -889,7 +899,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
 #pragma unroll
                         for (int c = 0; c < 8; ++c) tmp[c] = SlabStore<GV>::cvt(o8[c]);
                         __builtin_memcpy(&w, tmp, 16);
-                        __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t *>(gband + (int64_t)pix * MD + cq * 8));
+                        __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t *>(gquad + (int64_t)s * kOwnQuads * MD + cq * 8));
                     }
                 }
             }
@@ -898,8 +908,9 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             // free) row area as [v][32 channels] floats; one thread per (pixel, 4 channels) adds the SF partials
             float *part = reinterpret_cast<float *>(rows);
             if (Q < nvpix) {
-                *reinterpret_cast<float4 *>(part + Q * D + ch1) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
-                *reinterpret_cast<float4 *>(part + Q * D + ch2) = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
+                float *mine = part + per_item(Q) * D;
+                *reinterpret_cast<float4 *>(mine + ch1) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+                *reinterpret_cast<float4 *>(mine + ch2) = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
             }
             __syncthreads();
             GV *gband = gmap + (int64_t)r0 * W * MD;
