@@ -381,7 +381,10 @@ constexpr int kOwnQuads = kOwnThreads / 4;
 constexpr int kOwnSlots = 4;                        // pixels per owner quad
 constexpr int kOwnPix = kOwnQuads * kOwnSlots;      // pixels per band
 // resident-slab kernels
-constexpr int kRsThreads = 1024, kRsWaves = kRsThreads / kWave;
+#ifndef MSDA_RS_THREADS
+#define MSDA_RS_THREADS 1024        // (512: 8 waves with a 256-VGPR budget each -- measured slower)
+#endif
+constexpr int kRsThreads = MSDA_RS_THREADS, kRsWaves = kRsThreads / kWave;
 constexpr int kRsRows = kWave / 4;       // rows per wave tile: one quad per row
 constexpr int kRsSlack = 1024;          // bytes: the last LDS-DMA piece may overrun the slab's pixels
 constexpr int kRsMaxFrames = 32;        // frames x frames slot masks live in LDS

@@ -210,13 +210,16 @@ __device__ __forceinline__ void load_slot_points(const T *loc, const T *aw, int6
 //     lane R's eight values to the quad (v_add_u32_dpp with the lane's slice offset, v_mov_b32_dpp).  Round 2 derived
 //     each corner in the lane of the same number with six DPP-operand instructions per step and then broadcast all four:
 //     16.5 VALU instructions per corner, now 7 (forward 0.430 -> 0.369 ms on the bench workload, same box).
-//   * ABLATIONS (timing-only builds, profiles/r03_*): without the level-0 (memory) corners the kernel takes 0.154 ms,
-//     without the slab (LDS) corners 0.377 ms = the time of the full kernel (0.374): the LDS / VALU side is completely
-//     hidden behind the level-0 gathers, i.e. behind the rate at which a CU's vector-memory path returns scattered 128-byte
-//     lines that miss the L1 (86 k lines per CU and launch at ~420 clk average L2 round trip).  A software-pipelined
-//     variant that kept 4-8 level-0 loads in flight per lane across the LDS steps was therefore no faster (0.380 ms)
-//     and is not kept; what helps is a smaller L2 working set (fewer (clip, head) pairs in flight per XCD: 1 tile per
-//     wave 0.345 ms against 0.374 with 2), which is what the host's choice of `parts` now optimises.
+//   * ABLATIONS (timing-only builds, MSDA_RS_EXP, profiles/r03_logs): without the level-0 (memory) corners the kernel takes
+//     0.154 ms, without the slab (LDS) corners 0.377 ms = the time of the full kernel then (0.374): the LDS / VALU side is
+//     completely hidden behind the level-0 gathers, i.e. behind the rate at which a CU's vector-memory path returns
+//     scattered 128-byte lines that miss the L1 (86 k lines per CU and launch; 31 M L2 read requests per launch, 34 % of
+//     the L2's peak request rate).  What helps: (a) a smaller L2 working set -- fewer (clip, head) pairs in flight per XCD
+//     (1 tile per wave 0.345 ms against 0.374 with 2), which the host's choice of `parts` optimises; (b) PAIRS of memory
+//     corners software-pipelined under the LDS pairs of the same slot (0.374 -> 0.337 ms; PL0 below).  What does not:
+//     4-8 level-0 loads in flight per lane across whole LDS steps (0.380), non-temporal point loads, 512-thread
+//     workgroups with a 256-VGPR budget (-DMSDA_RS_THREADS=512: 0.342 at 4 tiles per wave = the 1024-thread kernel;
+//     gather pass 0.46 against 0.435).
 struct RsRec { int a[4]; float w[4]; };      // this lane's point: byte address (without the lane's slice offset) and weight of corners 0..3
 
 // The lane's own point at level `lvl` of source frame f: cuh:285-288 (pixel coords, range test), cuh:38-53 (floor,

@@ -489,6 +489,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
     __shared__ int s_src_q0[kScatterMaxSources], s_src_gmv[kScatterMaxSources];
     __shared__ unsigned s_live[kLiveWords];            // bitmap of the cull batches that hold a live 64-query block
     __shared__ long long s_item;
+    __shared__ int s_ftab[kWave];                      // the frame table (<= 64 slots: scatter_applicable), read once
 
     const int tid = threadIdx.x, lane = tid % kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -505,6 +506,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         s_first[L] = first;
         s_cnt[0] = s_cnt[1] = s_cnt[2] = 0;
     }
+    if (tid < kWave) s_ftab[tid] = tid < p.frames * p.window ? p.ftab[tid] : -1;
     int ci = 0;                             // counter of the current cull batch
     for (int i = tid; i < kOwnPix; i += kOwnThreads) head[i] = kOwnNil;
     __syncthreads();
@@ -574,9 +576,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         // frame_table[t, w] == f; per source the first culling-table entry, first loc/attn element, first query row
         if (wave == 0) {
             const int n_tw = p.frames * p.window;
-            // (per_item(): the address is formed here, once per item, instead of living in registers across the item loop --
-            // loop-invariant 64-bit addresses hoisted out of it were this kernel's only VGPR spills)
-            const bool hit = lane < n_tw && p.ftab[per_item(lane)] == f;
+            const bool hit = lane < n_tw && s_ftab[lane] == f;
             const u64 bal = __ballot(hit);
             if (lane == 0) {
                 const int64_t g = (int64_t)clip * p.frames + f;

@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
-bash scripts/ab_bench.sh devis_amd/libmsda_exp_prev.so devis_amd/libmsda_hip.so
-bash scripts/ab_bench.sh devis_amd/libmsda_exp_prev.so devis_amd/libmsda_hip.so -- --dtype bf16
-python -m pytest tests/test_op_gpu.py tests/test_configs_gpu.py -m gpu -q 2>&1 | tail -3
+export MSDA_ENABLE_HOOKS=1
+bash scripts/ab_bench.sh devis_amd/libmsda_hip.so | head -1
+for nt in 1 2 4; do
+MSDA_FWD_RS_NT=$nt MSDA_BWD_RS_TPW=$nt bash scripts/ab_bench.sh devis_amd/libmsda_exp_t512.so | head -1
+done
