@@ -453,7 +453,7 @@ template <typename T> constexpr int grp_chunk() { return sizeof(T) == 4 ? MSDA_G
 // (rows are staged as fp32 for every storage type: 128 bytes per group)
 template <typename T> constexpr int grp_lds_bytes()
 {
-    return grp_chunk<T>() * 128 + 32 + 16 * grp_chunk<T>() * 8 + kOwnPix * 4 + kGrpList * 4;
+    return grp_chunk<T>() * 128 + 128 + 16 * grp_chunk<T>() * 8 + kOwnPix * 4 + kGrpList * 4;
 }
 
 // T = storage type of loc / attn / grad_out; GV = type of grad_value as written (float, or T: include/msda.h grad_value_dtype).
@@ -477,9 +477,10 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
     constexpr bool kHalf = sizeof(T) == 2;
     extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];
     unsigned char *rows = lds_raw;                                              // [kOwnChunk][kRowB]  one row per group
-    // [16 * kOwnChunk] {weight bits, next reference}, on a 32-byte boundary; a reference = the absolute LDS address of an entry
+    // [16 * kOwnChunk] {weight bits, next reference}, on a 128-byte boundary of the LDS address space (the walk derives an
+    // entry's row from its address); a reference = the absolute LDS address of an entry
     uint2 *ents = reinterpret_cast<uint2 *>(lds_raw + kOwnChunk * kRowB +
-                                            ((32u - (lds_addr(lds_raw) & 31u)) & 31u));
+                                            ((128u - (lds_addr(lds_raw) & 127u)) & 127u));
     unsigned *head = reinterpret_cast<unsigned *>(ents + 16 * kOwnChunk);       // [kOwnPix]
     unsigned *list = head + kOwnPix;                                            // [kGrpList] (k:6 | points:4 | q:22)
     __shared__ int s_H[kScatterMaxLevels], s_W[kScatterMaxLevels], s_R[kScatterMaxLevels],
@@ -710,6 +711,8 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         // ---- owners walk their pixels' lists (references are absolute LDS addresses; the row is (A - entries) >> 7)
         auto walk = [&]() {
             if (direct || (dbg & 1)) return;
+            // this lane's two 16-byte pieces of a row, relative to the 128-byte group of the entry's own address
+            const unsigned row_k1 = lds_addr(rows) - ents_lds + (unsigned)off1, row_k2 = lds_addr(rows) - ents_lds + (unsigned)(off1 ^ 64);
 #pragma unroll
             for (int s = 0; s < kOwnSlots; ++s) {
                 const int pix = s * kOwnQuads + Q;
@@ -718,9 +721,13 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                 while (e != kOwnNil) {
                     const uint2 en = *reinterpret_cast<const uint2 *>(lds_raw + (e - lds_addr(lds_raw)));
                     const float w = __uint_as_float(en.x);
-                    const unsigned char *r = rows + ((e - ents_lds) >> 7) * kRowB;
-                    const float4 v1 = *reinterpret_cast<const float4 *>(r + off1);
-                    const float4 v2 = *reinterpret_cast<const float4 *>(r + (off1 ^ 64));
+                    // the row of entry e: a group has 16 x 8 = 128 = kRowB bytes of entries and the entries start on a
+                    // 128-byte boundary, so (e & ~127) + (rows - ents) is the row's address
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    typedef const __attribute__((address_space(3))) f32x4 *lds_f32x4;
+                    const unsigned rg = e & ~127u;
+                    const f32x4 v1 = *(lds_f32x4)(size_t)(rg + row_k1);
+                    const f32x4 v2 = *(lds_f32x4)(size_t)(rg + row_k2);
                     const float v[8] = {v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
 #pragma unroll
                     for (int c = 0; c < 8; ++c) acc[s][c] = fmaf(w, v[c], acc[s][c]);
