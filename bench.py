@@ -119,6 +119,7 @@ def make_clip_batch(args, device, dtype, seed):
 
 
 ROUTE_KERNELS = [   # msda_last_route() phrase -> kernel symbol
+    ("resident-window kernel, grad_loc/grad_attn", "msda_bwd_win_kernel"), ("forward (resident-window kernel", "msda_fwd_win_kernel"),
     ("resident-slab kernel, grad_loc/grad_attn", "msda_bwd_rs_kernel"), ("forward (resident-slab kernel", "msda_fwd_rs_kernel"),
     ("forward (slab kernel)", "msda_fwd_slab_kernel"),
     ("forward (tile kernel)", "msda_fwd_tile_kernel"), ("forward (generic kernel)", "msda_fwd_generic_kernel"),

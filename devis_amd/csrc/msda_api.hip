@@ -2,6 +2,7 @@
 // (which family takes a shape: resident-slab / tile / generic kernels; owner-computes / LDS / atomic scatter), the test
 // knobs and the per-device caches.  The kernels live in the other translation units of this directory.
 #include "msda_common.h"
+#include <algorithm>
 
 namespace msda {
 
@@ -45,6 +46,7 @@ size_t tile_lds_bytes(int rpw, int nvl, bool bwd, bool intervals = false)
 struct Knobs {
     int fwd_rs = -1, fwd_rs_nt = 0;     // resident-slab forward: -1 auto, 0 off, 1 force; tiles per wave (0 = auto)
     int bwd_rs = -1, bwd_rs_tpw = 0;    // resident-slab gather pass: -1 auto, 0 off, 1 force; tiles per wave (0 = auto)
+    int fwd_win = -1, bwd_win = -1;     // resident-window kernels (encoder-shaped calls): -1 auto, 0 off, 1 force
     int bwd_atomic = 0;                 // MSDA_BWD_MODE=atomic: one-kernel backward with global atomics
     int bwd_phases = 3;                 // 1 = gather pass only, 2 = scatter pass only, 3 = both
     int bwd_cull = 1;                   // 0: no culling structure, 2: (min, max) intervals instead of per-point records
@@ -70,6 +72,7 @@ void load_knobs()
     if (env_int("MSDA_ENABLE_HOOKS", 0) == 1) {
         k.fwd_rs = env_int("MSDA_FWD_RS", k.fwd_rs); k.fwd_rs_nt = env_int("MSDA_FWD_RS_NT", k.fwd_rs_nt);
         k.bwd_rs = env_int("MSDA_BWD_RS", k.bwd_rs); k.bwd_rs_tpw = env_int("MSDA_BWD_RS_TPW", k.bwd_rs_tpw);
+        k.fwd_win = env_int("MSDA_FWD_WIN", k.fwd_win); k.bwd_win = env_int("MSDA_BWD_WIN", k.bwd_win);
         const char *mode = getenv("MSDA_BWD_MODE");
         k.bwd_atomic = (mode && !strcmp(mode, "atomic")) ? 1 : 0;
         k.bwd_phases = env_int("MSDA_BWD_PHASES", k.bwd_phases);
@@ -223,6 +226,88 @@ bool rs_fits(const Params &p, int esz)
            pmax * pmax * p.L < 65536;         // the kernels take a point's level as (k * ceil(2^16 / P)) >> 16
 }
 
+// Plan of the resident-window kernels (msda_win.hip; WinPlan in msda_common.h) for an encoder-shaped call: the largest tile
+// whose rows fit a workgroup (frames * ceil(queries / 16) wave tiles <= 4 per wave), then the widest halo whose windows fit
+// the LDS -- all levels at once when that halo reaches 6 pixels, else level 0 and the other levels in two staging phases.
+// `force`: the test knob; without it the call must LOOK like an encoder (one query per pixel).
+bool win_plan(const Params &p, int esz, bool force, WinPlan &w)
+{
+    if (!rs_fits(p, esz) || !p.shapes_host || p.L > kWinMaxLevels || p.L < 1) return false;
+    long long pixels = 0;
+    for (int l = 0; l < p.L; ++l) {
+        if (p.shapes_host[2 * l] <= 0 || p.shapes_host[2 * l + 1] <= 0 || p.shapes_host[2 * l] > 32767 || p.shapes_host[2 * l + 1] > 32767) return false;
+        pixels += p.shapes_host[2 * l] * p.shapes_host[2 * l + 1];
+    }
+    if (pixels != p.Lq) return false;                 // the tiles enumerate the queries as the pixels of the pyramid
+    (void)force;
+    const int cap_px = kWinSlabBytes / (32 * esz), H0 = (int)p.shapes_host[0], W0 = (int)p.shapes_host[1];
+    auto H = [&](int l) { return (int)p.shapes_host[2 * l]; };
+    auto W = [&](int l) { return (int)p.shapes_host[2 * l + 1]; };
+    // most pixels of level l a tile owns / needs in its window, per axis (maxima over the tiles)
+    auto extent = [&](int n_l, int n_0, int B, int halo, bool window) {
+        int best = 0;
+        for (int t = 0; t < (n_0 + B - 1) / B; ++t) {
+            int q0, q1, w0, w1;
+            win_axis(n_l, n_0, t, B, halo, q0, q1, w0, w1);
+            best = std::max(best, window ? w1 - w0 : q1 - q0);
+        }
+        return best;
+    };
+    // Tile sizes are tried from large to small; a size is taken when its rows fill the workgroup's wave tiles (16 waves x nt x
+    // 16 rows) best -- rows of tiles at the map's edge and the idle tail of the last wave tiles cost as much as full ones.
+    double best_score = 0.0;
+    bool found = false;
+    static const int kEdges[] = {24, 20, 16, 12, 10, 8, 6, 4};
+    for (int By : kEdges) for (int Bx : kEdges) {
+        if (By > 2 * Bx || Bx > 2 * By) continue;
+        const int tiles_y = (H0 + By - 1) / By, tiles_x = (W0 + Bx - 1) / Bx;
+        int nq = 0;
+        for (int l = 0; l < p.L; ++l) nq += extent(H(l), H0, By, 0, false) * extent(W(l), W0, Bx, 0, false);
+        const int tpg = (nq + kRsRows - 1) / kRsRows, nt = (p.frames * tpg + kRsWaves - 1) / kRsWaves;
+        if (nq <= 0 || nt > 4) continue;
+        auto need = [&](int la, int lb, int halo) {       // LDS pixels of the windows of levels [la, lb) (each rounded to a DMA piece)
+            int acc = 0;
+            for (int l = la; l < lb; ++l)
+                acc += (extent(H(l), H0, By, halo, true) * extent(W(l), W0, Bx, halo, true) + 15) / 16 * 16;
+            return acc;
+        };
+        auto widest = [&](int la, int lb) {
+            int h = -1;
+            while (h < 16 && need(la, lb, h + 1) <= cap_px) ++h;
+            return h;
+        };
+        int split = 0, h0 = widest(0, p.L), h1 = h0;
+        if (h0 < 6 && p.L > 1) {
+            int best = h0;
+            for (int sp = 1; sp < p.L; ++sp) {
+                const int a = widest(0, sp), b = widest(sp, p.L);
+                if (std::min(a, b) > best) { best = std::min(a, b); split = sp; h0 = a; h1 = b; }
+            }
+        }
+        if (std::min(h0, h1) < 6) continue;             // (a corner outside its window costs a memory round trip of the whole wave)
+        // useful rows per row slot of a workgroup, less the share of a source frame's time spent staging (estimated as the
+        // window pixels per row served, one pixel ~ the LDS time of a sixth of a row's slot)
+        const double rows = (double)p.Lq / ((double)tiles_y * tiles_x) * p.frames;
+        const double staged = (split ? need(0, split, h0) + need(split, p.L, h1) : need(0, p.L, h0));
+        const double score = rows / (nt * kRsWaves * kRsRows) / (1.0 + staged / (6.0 * rows)) / (split ? 1.08 : 1.0);
+        if (score <= best_score) continue;
+        best_score = score; found = true;
+        w.By = By; w.Bx = Bx; w.tiles_y = tiles_y; w.tiles_x = tiles_x; w.split = split; w.halo[0] = h0; w.halo[1] = h1;
+        w.tpg = tpg; w.nt = nt;
+        int acc = 0;
+        for (int l = 0; l < kWinMaxLevels; ++l) {
+            if (l == split && split > 0) acc = 0;
+            w.wbase[l] = acc;
+            if (l < p.L) {
+                const int halo = (split > 0 && l >= split) ? h1 : h0;
+                acc += (extent(H(l), H0, By, halo, true) * extent(W(l), W0, Bx, halo, true) + 15) / 16 * 16;
+            }
+        }
+    }
+    if (!found) return false;
+    return (long long)(p.groups / p.frames) * p.M * w.tiles_y * w.tiles_x <= 0x7fffffffLL;
+}
+
 // grad_value may be written in the 16-bit STORAGE type (include/msda.h, msda_grad_value_dtype) when the owner-computes
 // scatter will produce it: that kernel overwrites every pixel exactly once from fp32 registers.  Every other route
 // accumulates into grad_value (LDS-atomic flush aside, float atomics) and needs the arithmetic type.  Levels wider than a
@@ -255,7 +340,16 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
     const int l0_host = rs_ok ? host_first_slab_level(p, (kRsSlabBytes - kRsSlack) / rs_row) : p.L;
     const long long l2_budget = esz == 4 ? (2ll << 20) : (4ll << 20);        // see rs_tiles_per_wave
 
+    // Encoder-shaped calls (one query per pixel) take the resident-window kernels when the slab of the resident-slab kernels
+    // would hold the last level at most (fp32 at 800x1333: 273 of 22223 pixels) -- measured forward 2.36 -> 1.47 ms there; where
+    // more levels fit the slab (16-bit types, the 360x640 pyramid) the two families are on a par and the slab kernels stay.
+    auto window_route = [&](int mode, WinPlan &w) {
+        if (mode == 0 || !win_plan(p, esz, mode == 1, w)) return false;
+        return mode == 1 || (p.Lq == p.S && p.L > 1 && l0_host >= p.L - 1);
+    };
     if (!bwd) {
+        WinPlan w;
+        if (window_route(knobs().fwd_win, w)) return launch_fwd_win(dtype, p, w, stream);
         if (rs_ok) {
             // resident-slab forward: up to NT * 16 tiles of 16 rows per workgroup, so that the per-frame slab staging is
             // amortised; tiles per wave (NT) and workgroups per (clip, head) (parts): see rs_tiles_per_wave
@@ -284,7 +378,13 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
     int rc = MSDA_OK;
     if (phases & 1) {
         bool done = false;
-        if (rs_ok && (p.cull_points || !p.bbox)) {
+        WinPlan w;
+        if ((p.cull_points || !p.bbox) && window_route(knobs().bwd_win, w)) {
+            rc = launch_bwd_win(dtype, p, w, stream);
+            if (rc) return rc;
+            done = true;
+        }
+        if (!done && rs_ok && (p.cull_points || !p.bbox)) {
             // resident-slab gather pass: same applicability rule as the forward
             const int mode = knobs().bwd_rs;
             int tpw = rs_tiles_per_wave(p, rs_tiles_per_clip, host_pixels_below(p, l0_host) * rs_row, mode == 1, l2_budget);

@@ -392,6 +392,40 @@ constexpr int kRsRowB = 128;            // bytes of one pixel of one head in a 4
 constexpr int kRsTailBytes = kRsRowB + kRsMaxFrames * kRsMaxFrames * 4 + 4 * kSlabMaxLevels * 4 + 16;   // after the slab
 constexpr int kRsSlabBytes = ((160 * 1024 - 256 - kRsTailBytes) / 128) * 128;
 
+// ---- resident-window kernels (msda_win.hip): encoder-shaped calls, where query i IS pixel i of the pyramid and samples round
+// its own position.  A workgroup owns the queries of one spatial TILE (By x Bx level-0 pixels and the pixels of the other
+// levels whose centres fall into it) and stages, per source frame, a WINDOW of every level -- the tile's footprint on that
+// level plus `halo` pixels on every side -- in LDS; taps outside the window are read from memory (any input is computed
+// exactly; only speed depends on locality).  When all windows do not fit at a useful halo the levels are staged in two
+// phases per source frame: levels < split, then levels >= split (split = 0: one phase).
+constexpr int kWinMaxLevels = 8;
+struct WinPlan {
+    int By, Bx, tiles_y, tiles_x;       // tile size in level-0 pixels; tiles of one map
+    int split;                          // first level of the second staging phase (0 = one phase)
+    int halo[2];                        // pixels round the footprint, per phase
+    int wbase[kWinMaxLevels];           // first LDS pixel of level l's window (inside its phase's layout)
+    int tpg;                            // wave tiles (16 rows) per query frame: ceil(most queries of a tile / 16)
+    int nt;                             // wave tiles per wave: ceil(frames * tpg / 16 waves) <= 4
+};
+
+// One axis of a tile's geometry on a level with n_l pixels (n_0 on level 0): the level's own pixels the tile OWNS
+// [q0, q1) -- pixel y belongs to the tile its centre falls into, i.e. floor((2y + 1) n_0 / (2 n_l) / B) -- and the window
+// [w0, w1) that holds every tap of a point within `halo` pixels of the tile's extent (floor(y n_l - 0.5) and the row below).
+// Host (planning: maxima over the tiles) and device (the tile's own tables) evaluate the same integers.
+__host__ __device__ inline int win_fdiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+__host__ __device__ inline void win_axis(int n_l, int n_0, int t, int B, int halo, int &q0, int &q1, int &w0, int &w1)
+{
+    const int a = 2 * n_l * t * B - n_0, b = 2 * n_l * (t + 1) * B - n_0, d = 2 * n_0;
+    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    q0 = clampi(-win_fdiv(-a, d), 0, n_l);          // ceil
+    q1 = clampi(-win_fdiv(-b, d), 0, n_l);
+    w0 = clampi(win_fdiv(a, d) - halo, 0, n_l);
+    w1 = clampi(win_fdiv(b, d) + 2 + halo, 0, n_l);
+}
+
+constexpr int kWinTailBytes = 128 + kRsMaxFrames * kRsMaxFrames * 4 + 14 * kWinMaxLevels * 4 + 64;    // zero row, slot masks, level tables
+constexpr int kWinSlabBytes = ((160 * 1024 - 256 - kWinTailBytes) / 128) * 128;
+
 struct PrepParams {
     const void *off_c, *off_t;        // [rows, M, L, Pc, 2], [rows, M, W*L, Pt, 2]   raw sampling offsets
     const void *logit_c, *logit_t;    // [rows, M, L*Pc], [rows, M, W*L*Pt]           raw attention logits
@@ -443,6 +477,8 @@ int launch_bwd_tile(int dtype, int G, bool atomics, const Params &p, unsigned bl
 // for it -- speed only: a kernel whose device-side level differs falls back to its plain loop)
 int launch_fwd_rs(int dtype, int nt, int first_slab_level, const Params &p, int parts, unsigned grid, hipStream_t stream);
 int launch_bwd_rs(int dtype, int first_slab_level, const Params &p, int parts, unsigned grid, hipStream_t stream);
+int launch_fwd_win(int dtype, const Params &p, const WinPlan &w, hipStream_t stream);
+int launch_bwd_win(int dtype, const Params &p, const WinPlan &w, hipStream_t stream);
 // msda_scatter.hip: grad_value
 int launch_zero_unowned(const Params &p, int cap_slots, int grad_value_elem_bytes, hipStream_t stream);
 int launch_cull_summary(const Params &p, hipStream_t stream);

@@ -28,60 +28,7 @@ namespace {
 #ifndef MSDA_RS_PIPE
 #define MSDA_RS_PIPE 1       // software-pipelined level-0 corners (0: the plain group loop only; A/B builds)
 #endif
-template <typename T> constexpr int rs_row_bytes() { return 32 * (int)sizeof(T); }
-
-// A pixel row slice as it comes out of the load -- 2 x 16 bytes (4-byte types: channels [4c, 4c+4) of both
-// 64-byte halves) or 16 bytes (2-byte types: channels [8c, 8c+8)) -- and its conversion to the lane's 8 fp32 channels,
-// as two steps, so that a row in flight costs its raw registers only.  The LDS byte address is used AS the address (the
-// slab starts at LDS address 0: no base to add); the second half of a 4-byte-type row is at a + delta2 (= a ^ 64 for
-// the lane's own first-half choice).
-template <typename T> struct RsRaw { u32x4 q[sizeof(T) == 4 ? 2 : 1]; };
-
-template <typename T, bool SLAB>
-__device__ __forceinline__ RsRaw<T> rs_issue_row(__amdgpu_buffer_rsrc_t rsrc, int a, int delta2)
-{
-    typedef __attribute__((address_space(3))) const u32x4 *lds_u4;
-    RsRaw<T> r;
-    if constexpr (SLAB) {
-        r.q[0] = *(lds_u4)(uintptr_t)(unsigned)a;
-        if constexpr (sizeof(T) == 4) r.q[1] = *(lds_u4)(uintptr_t)(unsigned)(a + delta2);
-    } else {
-        r.q[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, a, 0, 0);
-        if constexpr (sizeof(T) == 4) r.q[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, a + delta2, 0, 0);
-    }
-    return r;
-}
-
-template <typename T>
-__device__ __forceinline__ void rs_fma_row(const RsRaw<T> &r, float w, float (&acc)[8])
-{
-    float v[8];
-    if constexpr (sizeof(T) == 4) {
-        v[0] = __uint_as_float(r.q[0].x); v[1] = __uint_as_float(r.q[0].y); v[2] = __uint_as_float(r.q[0].z); v[3] = __uint_as_float(r.q[0].w);
-        v[4] = __uint_as_float(r.q[1].x); v[5] = __uint_as_float(r.q[1].y); v[6] = __uint_as_float(r.q[1].z); v[7] = __uint_as_float(r.q[1].w);
-    } else {
-        unpack_raw(static_cast<const T *>(nullptr), r.q[0], v);
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] = fmaf(w, v[c], acc[c]);
-}
-
-// <g, row> over the lane's 8 channels
-template <typename T>
-__device__ __forceinline__ float rs_dot_row(const RsRaw<T> &r, const float (&g)[8])
-{
-    float v[8];
-    if constexpr (sizeof(T) == 4) {
-        v[0] = __uint_as_float(r.q[0].x); v[1] = __uint_as_float(r.q[0].y); v[2] = __uint_as_float(r.q[0].z); v[3] = __uint_as_float(r.q[0].w);
-        v[4] = __uint_as_float(r.q[1].x); v[5] = __uint_as_float(r.q[1].y); v[6] = __uint_as_float(r.q[1].z); v[7] = __uint_as_float(r.q[1].w);
-    } else {
-        unpack_raw(static_cast<const T *>(nullptr), r.q[0], v);
-    }
-    float acc = g[0] * v[0];
-#pragma unroll
-    for (int c = 1; c < 8; ++c) acc = fmaf(g[c], v[c], acc);
-    return acc;
-}
+#include "msda_rs_common.inc"
 
 // levels >= l0 of source frame f (head m) -> LDS slab, 16 bytes per lane by LDS-DMA (8 lanes per pixel)
 template <typename T>
@@ -143,63 +90,6 @@ __device__ __forceinline__ RsShared rs_setup(const Params &p, unsigned char *lds
     __syncthreads();
     sh.l0 = geo[0]; sh.px0 = geo[1]; sh.npx = geo[2];
     return sh;
-}
-
-// 4 x 4 transpose inside a quad: lane c, element e  <-  lane e, element c  (two butterfly stages of one DPP move and
-// three selects per pair of elements)
-template <typename V>
-__device__ __forceinline__ void quad_transpose4(V (&a)[4], int c)
-{
-    static_assert(sizeof(V) == 4, "32-bit elements");
-    auto xchg = [&](int lo, int hi, bool up, int ctrl) {
-        const V send = up ? a[lo] : a[hi];
-        int bits;
-        __builtin_memcpy(&bits, &send, 4);
-        const int got = ctrl == 1 ? __builtin_amdgcn_mov_dpp(bits, 0xB1, 0xf, 0xf, true)      // quad_perm [1,0,3,2]
-                                  : __builtin_amdgcn_mov_dpp(bits, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
-        V r;
-        __builtin_memcpy(&r, &got, 4);
-        a[lo] = up ? r : a[lo];
-        a[hi] = up ? a[hi] : r;
-    };
-    xchg(0, 1, (c & 1) != 0, 1); xchg(2, 3, (c & 1) != 0, 1);
-    xchg(0, 2, (c & 2) != 0, 2); xchg(1, 3, (c & 2) != 0, 2);
-}
-// a[i] = v for the (wave-uniform) index i: four selects instead of a dynamically indexed register array
-template <typename V> __device__ __forceinline__ void set4(V (&a)[4], int i, V v)
-{
-    a[0] = i == 0 ? v : a[0]; a[1] = i == 1 ? v : a[1]; a[2] = i == 2 ? v : a[2]; a[3] = i == 3 ? v : a[3];
-}
-
-// a[i] for the (wave-uniform) index i
-template <typename V> __device__ __forceinline__ V get4(const V (&a)[4], int i)
-{
-    return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : a[3];
-}
-// The 16 sampling points (4 levels x 4 points) of one (row, slot), loaded as whole rows: lane c of the row's quad reads
-// points 4c..4c+3 (32 + 16 contiguous bytes for 4-byte types) and the quad transposes, so that element g of lane c is
-// point c of level g -- three 16-byte loads per slot instead of eight 8- / 4-byte loads, one memory latency instead of four.
-template <typename T>
-__device__ __forceinline__ void load_slot_points(const T *loc, const T *aw, int64_t idx0, int cor, bool live,
-                                                 float (&xs)[4], float (&ys)[4], float (&as)[4])
-{
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { xs[i] = ys[i] = -10.f; as[i] = 0.f; }       // far outside every map
-    if (live) {
-        float xy[8];
-        if constexpr (sizeof(T) == 2) {
-            Store<T>::load(loc + 2 * (idx0 + 4 * cor), xy);
-        } else {
-            float lo[4], hi[4];
-            Store<T>::load(loc + 2 * (idx0 + 4 * cor), lo); Store<T>::load(loc + 2 * (idx0 + 4 * cor) + 4, hi);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { xy[i] = lo[i]; xy[4 + i] = hi[i]; }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { xs[i] = xy[2 * i]; ys[i] = xy[2 * i + 1]; }
-        SlabStore<T>::load(aw + idx0 + 4 * cor, as);
-    }
-    quad_transpose4(xs, cor); quad_transpose4(ys, cor); quad_transpose4(as, cor);
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------------
@@ -269,16 +159,6 @@ __device__ __forceinline__ RsRec rs_records(float x, float y, float a, int lvl, 
     for (int s = 0; s < 4; ++s) r.a[s] = g.adr[s];
     r.w[0] = g.a * (hh * hw); r.w[1] = g.a * (hh * g.lw); r.w[2] = g.a * (g.lh * hw); r.w[3] = g.a * (g.lh * g.lw);
     return r;
-}
-
-// lane R's value of `v`, for every lane of the quad (R a compile-time constant)
-template <int R> __device__ __forceinline__ int quad_bcast(int v)
-{
-    return __builtin_amdgcn_mov_dpp(v, R | (R << 2) | (R << 4) | (R << 6), 0xf, 0xf, true);
-}
-template <int R> __device__ __forceinline__ float quad_bcast(float v)
-{
-    return __int_as_float(quad_bcast<R>(__float_as_int(v)));
 }
 
 // T = storage type of value / out, TL = of sampling_loc / attn_weight (T, or float with a 16-bit T)
@@ -516,22 +396,6 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
 // lane R of the quad keeps the dots of point R, and after the group's four points every lane finishes ITS point and
 // stores its (grad_x, grad_y, grad_attn) directly: the 4 points of a group are 32 + 16 contiguous bytes per row.
 // Also leaves the per-point culling records (top tap row as int16) the scatter pass reads.
-// d[k] <- sum of d[k] over the four lanes of the quad (all lanes get the total)
-__device__ __forceinline__ void quad_sum4(float (&d)[4])
-{
-    asm volatile("s_nop 1\n"
-                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-                 "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-                 "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-                 "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-                 "s_nop 0\n"
-                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-                 "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-                 "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-                 "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
-}
-
 template <typename T, typename TL, int PL0>      // T: value / grad_out, TL: sampling_loc / attn_weight and their gradients
 __global__ void __launch_bounds__(kRsThreads)
 msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)

@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q 2>&1 | tail -3
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_window_gpu.py -m gpu -q 2>&1 | grep -E "^FAILED|^E   +Assert|passed|failed" | cut -c 1-300 | tail -30

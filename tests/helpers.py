@@ -93,3 +93,27 @@ def make_temporal_inputs(seed, T, W, M, D, Lq, shapes, Pc, Pt, ftab=None, dtype=
     f = lambda x: np.ascontiguousarray(x.astype(dtype))
     return dict(value=f(value), shapes=shapes, lsi=O.level_start_index(shapes), ftab=np.ascontiguousarray(ftab),
                 loc_c=f(loc_c), aw_c=f(aw_c), loc_t=f(loc_t), aw_t=f(aw_t), grad_out=f(grad_out))
+
+
+def pixel_centres(shapes):
+    """[S, 2] normalised (x, y) centres of the pixels of a pyramid, in query order (= the encoder's reference points,
+    deformable_transformer.py:185-198 with valid_ratios = 1)."""
+    out = []
+    for h, w in np.asarray(shapes, dtype=np.int64).tolist():
+        ys, xs = np.meshgrid((np.arange(h) + 0.5) / h, (np.arange(w) + 0.5) / w, indexing="ij")
+        out.append(np.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    return np.concatenate(out, 0)
+
+
+def localise(loc, shapes, sigma_px, seed, levels_per_slot=None):
+    """Replace sampling locations [..., Lq = S, M, LL, P, 2] by encoder-like ones: the query's own pixel centre plus
+    N(0, sigma_px^2) pixels of the sampled level (LL = a multiple of the number of levels: slot-major, level-minor)."""
+    rng = np.random.default_rng(seed)
+    shapes = np.asarray(shapes, dtype=np.int64)
+    L = shapes.shape[0]
+    c = pixel_centres(shapes)                                           # [S, 2]
+    LL = loc.shape[-3]
+    wh = np.stack([shapes[:, 1], shapes[:, 0]], -1).astype(np.float64)  # (W, H) per level
+    wh = np.tile(wh, (LL // L, 1))                                      # [LL, 2]
+    noise = rng.standard_normal(loc.shape) * sigma_px / wh[:, None, :]
+    return (c[:, None, None, None, :] + noise).astype(loc.dtype)
