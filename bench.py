@@ -383,6 +383,48 @@ def other_configs(args, device):
         del c, leaves
         torch.cuda.empty_cache()
 
+    # (v) the fused temporal ENCODER call at 800x1333 (what dominates a DeVIS step: Lq = S = 22223 per frame, T = 6, 102 M
+    # sampling points per layer), fp32, per kernel
+    def temporal_encoder_b():
+        class A:
+            pass
+        a = A()
+        a.clips, a.frames, a.queries, a.pyramid, a.locs, a.sampling = 1, args.frames, 22223, "B", "local", "storage"
+        b = make_clip_batch(a, device, torch.float32, seed=777)
+        T, q, M, D, L, P, W, S = b["dims"]
+        dv = [b[k] for k in ("value", "loc_c", "aw_c", "loc_t", "aw_t")]
+        out = torch.empty((T, q, M * D), dtype=torch.float32, device=device)
+        gv = torch.zeros(b["value"].shape, dtype=torch.float32, device=device)
+        grads = [torch.empty_like(x) for x in dv[1:]]
+        ws = _native.bwd_workspace(device, T, q, M, L * (1 + W))
+        t, names = {}, {}
+        t["fwd"] = _event_ms(lambda: _native.temporal_forward(dv[0], b["shapes"], b["lsi"], b["ftab"], dv[1], dv[2], dv[3], dv[4], 1, out), 5, 2)
+        names["fwd"] = kernel_name(_native.last_route(), "forward")
+        def bwd():
+            ws[:16].zero_()
+            _native.temporal_backward(dv[0], b["shapes"], b["lsi"], b["ftab"], dv[1], dv[2], dv[3], dv[4], b["grad_out"], 1, gv, *grads, workspace=ws)
+        os.environ["MSDA_ENABLE_HOOKS"] = "1"
+        for ph, key in (("1", "gather"), ("2", "scatter")):
+            os.environ["MSDA_BWD_PHASES"] = ph
+            _native.reload_knobs()
+            t[key] = _event_ms(bwd, 5, 2)
+            names[key] = kernel_name(_native.last_route(), key)
+        os.environ.pop("MSDA_BWD_PHASES"); os.environ.pop("MSDA_ENABLE_HOOKS")
+        _native.reload_knobs()
+        class B:
+            pass
+        ab_args = B(); ab_args.frames, ab_args.queries, ab_args.pyramid = T, q, "B"
+        ab = algorithmic_bytes(ab_args, 4, 4)
+        alg = {"fwd": ab["fwd"], "gather": ab["bwd_gather"], "scatter": ab["bwd_scatter"]}
+        total = sum(t.values())
+        return {"workload": "fused temporal encoder call at 800x1333: ONE clip, T=%d, Lq = S = %d per frame, L=4, K=4, M=8xD=32, fp32, local "
+                            "sampling (N(0, (2 px)^2) round the query's own pixel)" % (T, q),
+                "fwd_bwd_ms": round(total, 4), "M_queries_per_s": round(T * q / total / 1e3, 3),
+                "kernels": {names[k]: {"avg_ms": round(t[k], 4), "algorithmic_GBps": round(alg[k] / t[k] / 1e6, 1),
+                                       "frac_of_hbm_peak": round(alg[k] / t[k] / 1e6 / HBM_PEAK_GBS, 4)} for k in t}}
+    res["temporal_encoder_800x1333_f32"] = temporal_encoder_b()
+    torch.cuda.empty_cache()
+
     plain("cfg1_encoder_800x1333_bf16: single-frame encoder attention, N=8 images, Lq = S = 22223, L=4, K=4, M=8xD=32, bf16, "
           "encoder-like local sampling", torch.bfloat16, PYRAMIDS["B"], 8, 22223, "local", (64,), per_kernel=True)
     swin = [(60, 96), (30, 48), (15, 24), (8, 12)]            # SwinL training size 480x768 (src/datasets/vis.py:228-231)
