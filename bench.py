@@ -63,6 +63,7 @@ def parse_args():
                          "N(0, (3 px)^2) offsets per level, as a trained decoder produces; local: query i sits on "
                          "pixel i of the pyramid (needs --queries S) and samples N(0, (2 px)^2) around it in every "
                          "frame, as the temporal ENCODER does")
+    ap.add_argument("--sigma", type=float, default=0.0, help="spread in pixels of the clustered / local sampling (0: 3 px clustered, 2 px local)")
     ap.add_argument("--mode", choices=["clip-parallel", "sharded"], default="clip-parallel",
                     help="clip-parallel: independent clips per GPU, no collective (default, weak scaling); "
                          "sharded: every clip is split over ALL ranks (devis_amd/clip_parallel.py: RCCL all-gather "
@@ -97,6 +98,8 @@ def make_clip_batch(args, device, dtype, seed):
             if q != S:
                 sys.exit("--locs local needs --queries %d (= S of pyramid %s)" % (S, args.pyramid))
             sigma = 2.0
+            if getattr(args, "sigma", 0.0) > 0:
+                sigma = args.sigma
             centres = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w,
                                                              indexing="ij"), -1).reshape(-1, 2).flip(-1)
                                  for h, w in shapes.tolist()], 0)                       # [S, 2] as (x, y)

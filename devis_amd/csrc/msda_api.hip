@@ -47,6 +47,8 @@ struct Knobs {
     int fwd_rs = -1, fwd_rs_nt = 0;     // resident-slab forward: -1 auto, 0 off, 1 force; tiles per wave (0 = auto)
     int bwd_rs = -1, bwd_rs_tpw = 0;    // resident-slab gather pass: -1 auto, 0 off, 1 force; tiles per wave (0 = auto)
     int fwd_win = -1, bwd_win = -1;     // resident-window kernels (encoder-shaped calls): -1 auto, 0 off, 1 force
+    int win_min_halo = 5;               // narrowest halo a window plan may have; one staging phase is preferred from here on (5 holds
+                                        // the reference's initial offsets, <= 4 pixels of every level: ms_deform_attn.py:64-76)
     int bwd_atomic = 0;                 // MSDA_BWD_MODE=atomic: one-kernel backward with global atomics
     int bwd_phases = 3;                 // 1 = gather pass only, 2 = scatter pass only, 3 = both
     int bwd_cull = 1;                   // 0: no culling structure, 2: (min, max) intervals instead of per-point records
@@ -73,6 +75,7 @@ void load_knobs()
         k.fwd_rs = env_int("MSDA_FWD_RS", k.fwd_rs); k.fwd_rs_nt = env_int("MSDA_FWD_RS_NT", k.fwd_rs_nt);
         k.bwd_rs = env_int("MSDA_BWD_RS", k.bwd_rs); k.bwd_rs_tpw = env_int("MSDA_BWD_RS_TPW", k.bwd_rs_tpw);
         k.fwd_win = env_int("MSDA_FWD_WIN", k.fwd_win); k.bwd_win = env_int("MSDA_BWD_WIN", k.bwd_win);
+        k.win_min_halo = env_int("MSDA_WIN_MIN_HALO", k.win_min_halo);
         const char *mode = getenv("MSDA_BWD_MODE");
         k.bwd_atomic = (mode && !strcmp(mode, "atomic")) ? 1 : 0;
         k.bwd_phases = env_int("MSDA_BWD_PHASES", k.bwd_phases);
@@ -277,14 +280,15 @@ bool win_plan(const Params &p, int esz, bool force, WinPlan &w)
             return h;
         };
         int split = 0, h0 = widest(0, p.L), h1 = h0;
-        if (h0 < 6 && p.L > 1) {
+        const int min_halo = knobs().win_min_halo;
+        if (h0 < min_halo && p.L > 1) {
             int best = h0;
             for (int sp = 1; sp < p.L; ++sp) {
                 const int a = widest(0, sp), b = widest(sp, p.L);
                 if (std::min(a, b) > best) { best = std::min(a, b); split = sp; h0 = a; h1 = b; }
             }
         }
-        if (std::min(h0, h1) < 6) continue;             // (a corner outside its window costs a memory round trip of the whole wave)
+        if (std::min(h0, h1) < min_halo) continue;      // (a corner outside its window costs a memory round trip of the whole wave)
         // useful rows per row slot of a workgroup, less the share of a source frame's time spent staging (estimated as the
         // window pixels per row served, one pixel ~ the LDS time of a sixth of a row's slot)
         const double rows = (double)p.Lq / ((double)tiles_y * tiles_x) * p.frames;
@@ -341,7 +345,7 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
     const long long l2_budget = esz == 4 ? (2ll << 20) : (4ll << 20);        // see rs_tiles_per_wave
 
     // Encoder-shaped calls (one query per pixel) take the resident-window kernels when the slab of the resident-slab kernels
-    // would hold the last level at most (fp32 at 800x1333: 273 of 22223 pixels) -- measured forward 2.36 -> 1.47 ms there; where
+    // would hold the last level at most (fp32 at 800x1333: 273 of 22223 pixels) -- measured forward 2.38 -> 1.22 ms, gather pass 2.85 -> 1.79 ms there; where
     // more levels fit the slab (16-bit types, the 360x640 pyramid) the two families are on a par and the slab kernels stay.
     auto window_route = [&](int mode, WinPlan &w) {
         if (mode == 0 || !win_plan(p, esz, mode == 1, w)) return false;
