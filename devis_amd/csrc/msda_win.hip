@@ -76,28 +76,32 @@ __device__ __forceinline__ WinShared win_setup(const Params &p, const WinPlan &w
     return sh;
 }
 
-// windows of levels [la, lb) of source frame f (head m) -> LDS, 16 bytes per lane by LDS-DMA
+// windows of levels [la, lb) of source frame f (head m) -> LDS, 16 bytes per lane by LDS-DMA.  A wave takes whole window rows
+// (no per-lane division); an instruction moves up to PXW pixels of one row, the lanes past the row's end are switched off.
 template <typename T>
 __device__ __forceinline__ void win_stage(const Params &p, const WinShared &sh, T *slab, int clip, int m, int f, int la, int lb,
                                           int wave, int lane)
 {
     constexpr int GL = rs_row_bytes<T>() / 16, D = 32;
     constexpr int PXW = kWave / GL;                 // pixels per LDS-DMA wave instruction
+    const int lpx = lane / GL;
     const T *src = static_cast<const T *>(p.value) + clip * p.v_clip + m * p.v_head + ((int64_t)f * p.S) * p.v_pix +
                    (lane % GL) * (16 / (int)sizeof(T));
     for (int l = la; l < lb; ++l) {
-        const int ww = sh.ww[l], npx = sh.wh[l] * ww, W = sh.W[l];
-        const int first = sh.lsi[l] + sh.wy0[l] * W + sh.wx0[l];
-        T *dst = slab + (size_t)sh.wb[l] * D;
-        for (int pb = wave * PXW; pb < npx; pb += kRsWaves * PXW) {
-            const int px = min(pb + lane / GL, npx - 1);
-            const int wy = px / ww, wx = px - wy * ww;
-            const T *gp = src + (int64_t)(first + wy * W + wx) * p.v_pix;
+        const int ww = __builtin_amdgcn_readfirstlane(sh.ww[l]), wh = __builtin_amdgcn_readfirstlane(sh.wh[l]);
+        const int W = __builtin_amdgcn_readfirstlane(sh.W[l]);
+        const int first = __builtin_amdgcn_readfirstlane(sh.lsi[l] + sh.wy0[l] * W + sh.wx0[l]);
+        T *dst = slab + (size_t)__builtin_amdgcn_readfirstlane(sh.wb[l]) * D;
+        for (int wy = wave; wy < wh; wy += kRsWaves) {
+            const T *rowp = src + (int64_t)(first + wy * W + lpx) * p.v_pix;
+            for (int c = 0; c < ww; c += PXW) {
+                if (c + lpx < ww) {
 #if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_global_load_lds(gp, (__attribute__((address_space(3))) void *)(dst + (size_t)pb * D), 16, 0, 0);
-#else
-            (void)gp; (void)dst;
+                    __builtin_amdgcn_global_load_lds(rowp + (int64_t)c * p.v_pix,
+                                                     (__attribute__((address_space(3))) void *)(dst + (size_t)(wy * ww + c) * D), 16, 0, 0);
 #endif
+                }
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
