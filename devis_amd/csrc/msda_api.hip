@@ -312,6 +312,28 @@ bool win_plan(const Params &p, int esz, bool force, WinPlan &w)
     return (long long)(p.groups / p.frames) * p.M * w.tiles_y * w.tiles_x <= 0x7fffffffLL;
 }
 
+// win_plan searches tile sizes and halos (~10^5 integer operations): the last plan is kept, keyed by everything it depends on.
+bool win_plan_cached(const Params &p, int esz, bool force, WinPlan &w)
+{
+    struct Key { int L, frames, esz, Lq, min_halo; int64_t shapes[2 * kWinMaxLevels]; };
+    static thread_local Key last_key;
+    static thread_local WinPlan last_plan;
+    static thread_local int last_state = -1;           // -1 nothing cached, 0 no plan, 1 plan
+    if (!p.shapes_host || p.L < 1 || p.L > kWinMaxLevels || !rs_fits(p, esz)) return false;
+    Key k;
+    memset(&k, 0, sizeof k);
+    k.L = p.L; k.frames = p.frames; k.esz = esz; k.Lq = p.Lq; k.min_halo = knobs().win_min_halo;
+    for (int i = 0; i < 2 * p.L; ++i) k.shapes[i] = p.shapes_host[i];
+    if (last_state < 0 || memcmp(&k, &last_key, sizeof k) != 0) {
+        // (the remaining inputs of win_plan -- D, M, strides, window -- only gate it through rs_fits, checked above)
+        last_state = win_plan(p, esz, force, last_plan) ? 1 : 0;
+        last_key = k;
+    }
+    if (last_state != 1) return false;
+    w = last_plan;
+    return (long long)(p.groups / p.frames) * p.M * w.tiles_y * w.tiles_x <= 0x7fffffffLL;
+}
+
 // grad_value may be written in the 16-bit STORAGE type (include/msda.h, msda_grad_value_dtype) when the owner-computes
 // scatter will produce it: that kernel overwrites every pixel exactly once from fp32 registers.  Every other route
 // accumulates into grad_value (LDS-atomic flush aside, float atomics) and needs the arithmetic type.  Levels wider than a
@@ -348,8 +370,8 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
     // would hold the last level at most (fp32 at 800x1333: 273 of 22223 pixels) -- measured forward 2.38 -> 1.22 ms, gather pass 2.85 -> 1.79 ms there; where
     // more levels fit the slab (16-bit types, the 360x640 pyramid) the two families are on a par and the slab kernels stay.
     auto window_route = [&](int mode, WinPlan &w) {
-        if (mode == 0 || !win_plan(p, esz, mode == 1, w)) return false;
-        return mode == 1 || (p.Lq == p.S && p.L > 1 && l0_host >= p.L - 1);
+        if (mode == 0 || (mode != 1 && !(p.Lq == p.S && p.L > 1 && l0_host >= p.L - 1))) return false;     // (cheap tests first)
+        return win_plan_cached(p, esz, mode == 1, w);
     };
     if (!bwd) {
         WinPlan w;
