@@ -238,7 +238,7 @@ bool win_plan(const Params &p, int esz, bool force, WinPlan &w)
     if (!rs_fits(p, esz) || !p.shapes_host || p.L > kWinMaxLevels || p.L < 1) return false;
     long long pixels = 0;
     for (int l = 0; l < p.L; ++l) {
-        if (p.shapes_host[2 * l] <= 0 || p.shapes_host[2 * l + 1] <= 0 || p.shapes_host[2 * l] > 32767 || p.shapes_host[2 * l + 1] > 32767) return false;
+        if (p.shapes_host[2 * l] <= 0 || p.shapes_host[2 * l + 1] <= 0 || p.shapes_host[2 * l] > 16000 || p.shapes_host[2 * l + 1] > 16000) return false;       // (win_axis: 2 * n_l * n_0 in 32 bits)
         pixels += p.shapes_host[2 * l] * p.shapes_host[2 * l + 1];
     }
     if (pixels != p.Lq) return false;                 // the tiles enumerate the queries as the pixels of the pyramid

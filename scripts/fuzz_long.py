@@ -36,7 +36,38 @@ for seed in range(first, first + count):
     _native_mod.reload_knobs()
     lay = int(rng.integers(0, 3))
     big = rng.random() < 0.25
-    if seed % 2 == 0:
+    if seed % 7 == 3:
+        # encoder-shaped: one query per pixel, forced onto the resident-window kernels
+        from helpers import localise
+        os.environ.update({"MSDA_FWD_WIN": "1", "MSDA_BWD_WIN": "1", "MSDA_WIN_MIN_HALO": str(int(rng.choice([3, 5, 9])))}); _native_mod.reload_knobs()
+        L = int(rng.integers(1, 6)); h0, w0 = int(rng.integers(4, 48)), int(rng.integers(4, 48))
+        shp = []
+        for l in range(L):
+            shp.append((h0, w0)); h0, w0 = max(1, (h0 + int(rng.integers(0, 2))) // 2), max(1, (w0 + int(rng.integers(0, 2))) // 2)
+        S = sum(h * w for h, w in shp)
+        T = int(rng.integers(1, 6)); W = int(rng.integers(1, 4)); Pc, Pt = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        ftab = rng.integers(0, T, size=(T, W)).astype(np.int32)
+        tdt = [torch.float32, torch.float32, torch.bfloat16, torch.float16][int(rng.integers(0, 4))]
+        d = make_temporal_inputs(seed, T, W, 8, 32, S, shp, Pc, Pt, ftab=ftab, dtype=np.float32)
+        sg = [None, 1.0, 2.5, 6.0][int(rng.integers(0, 4))]
+        if sg is not None:
+            d["loc_c"] = localise(d["loc_c"], shp, sg, seed + 1); d["loc_t"] = localise(d["loc_t"], shp, sg, seed + 2)
+        if tdt != torch.float32: d = round_to(d, tdt)
+        keys = ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")
+        ref = temporal_reference(*(np.asarray(d[k], dtype=np.float64) if d[k].dtype.kind == "f" else d[k] for k in keys))
+        f = lambda k: torch.from_numpy(np.asarray(d[k], dtype=np.float64)).to(DEV, tdt)
+        v = layout(f("value"), lay).requires_grad_(True)
+        lc, ac, lt, at = (f(k).requires_grad_(True) for k in ("loc_c", "aw_c", "loc_t", "aw_t"))
+        out = MSDeformAttnTemporalFunction.apply(v, torch.from_numpy(d["shapes"]).to(DEV), torch.from_numpy(d["lsi"]).to(DEV),
+                                                 torch.from_numpy(d["ftab"]).to(DEV), lc, ac, lt, at, 1)
+        used = "resident-window" in _native.last_route()
+        g = torch.autograd.grad(out, (v, lc, ac, lt, at), f("grad_out"))
+        got = [t.detach().double().cpu().numpy() for t in (out,) + tuple(g)]
+        errs = [maxabs(x, y) / max(1.0, np.abs(y).max()) for x, y in zip(got, ref)]
+        cfg = dict(kind="window", shapes=shp, T=T, W=W, Pc=Pc, Pt=Pt, lay=lay, dtype=str(tdt), sigma=sg, used=used)
+        ok = max(errs[0], errs[1], errs[3], errs[5]) <= {torch.float32: 1e-4, torch.bfloat16: 2e-2, torch.float16: 4e-3}[tdt]
+        for k in ("MSDA_FWD_WIN", "MSDA_BWD_WIN", "MSDA_WIN_MIN_HALO"): os.environ.pop(k, None)
+    elif seed % 2 == 0:
         D = int(rng.choice([4, 8, 16, 32, 32, 32, 64, 128, 12])); M = int(rng.choice([1, 2, 4, 8, 8, 16]))
         L, P = int(rng.integers(1, 6)), int(rng.integers(1, 7))
         N, Lq = int(rng.integers(1, 5)), int(rng.integers(1, 3000 if big else 80))
