@@ -230,7 +230,7 @@ bool rs_fits(const Params &p, int esz)
 }
 
 // Plan of the resident-window kernels (msda_win.hip; WinPlan in msda_common.h) for an encoder-shaped call: the largest tile
-// whose rows fit a workgroup (frames * ceil(queries / 16) wave tiles <= 4 per wave), then the widest halo whose windows fit
+// whose rows fit a workgroup (frames * ceil(queries / 16) wave tiles <= 3 per wave), then the widest halo whose windows fit
 // the LDS -- all levels at once when that halo reaches 6 pixels, else level 0 and the other levels in two staging phases.
 // `force`: the test knob; without it the call must LOOK like an encoder (one query per pixel).
 bool win_plan(const Params &p, int esz, bool force, WinPlan &w)
@@ -267,7 +267,7 @@ bool win_plan(const Params &p, int esz, bool force, WinPlan &w)
         int nq = 0;
         for (int l = 0; l < p.L; ++l) nq += extent(H(l), H0, By, 0, false) * extent(W(l), W0, Bx, 0, false);
         const int tpg = (nq + kRsRows - 1) / kRsRows, nt = (p.frames * tpg + kRsWaves - 1) / kRsWaves;
-        if (nq <= 0 || nt > 4) continue;
+        if (nq <= 0 || nt > 3) continue;                // (the forward keeps nt accumulator sets in registers)
         auto need = [&](int la, int lb, int halo) {       // LDS pixels of the windows of levels [la, lb) (each rounded to a DMA piece)
             int acc = 0;
             for (int l = la; l < lb; ++l)
@@ -367,7 +367,7 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
     const long long l2_budget = esz == 4 ? (2ll << 20) : (4ll << 20);        // see rs_tiles_per_wave
 
     // Encoder-shaped calls (one query per pixel) take the resident-window kernels when the slab of the resident-slab kernels
-    // would hold the last level at most (fp32 at 800x1333: 273 of 22223 pixels) -- measured forward 2.38 -> 1.22 ms, gather pass 2.85 -> 1.79 ms there; where
+    // would hold the last level at most (fp32 at 800x1333: 273 of 22223 pixels) -- measured forward 2.38 -> 1.07 ms, gather pass 2.85 -> 1.60 ms there; where
     // more levels fit the slab (16-bit types, the 360x640 pyramid) the two families are on a par and the slab kernels stay.
     auto window_route = [&](int mode, WinPlan &w) {
         if (mode == 0 || (mode != 1 && !(p.Lq == p.S && p.L > 1 && l0_host >= p.L - 1))) return false;     // (cheap tests first)

@@ -405,7 +405,7 @@ struct WinPlan {
     int halo[2];                        // pixels round the footprint, per phase
     int wbase[kWinMaxLevels];           // first LDS pixel of level l's window (inside its phase's layout)
     int tpg;                            // wave tiles (16 rows) per query frame: ceil(most queries of a tile / 16)
-    int nt;                             // wave tiles per wave: ceil(frames * tpg / 16 waves) <= 4
+    int nt;                             // wave tiles per wave: ceil(frames * tpg / 16 waves) <= 3
 };
 
 // One axis of a tile's geometry on a level with n_l pixels (n_0 on level 0): the level's own pixels the tile OWNS

@@ -188,14 +188,6 @@ msda_fwd_win_kernel(const Params p, const WinPlan wp, int slab_bytes)
     const int ty = tile / wp.tiles_x, tx = tile - ty * wp.tiles_x;
     const WinShared sh = win_setup(p, wp, lds_raw, slab_bytes, ty, tx);
     const int nq = sh.nq, tpg = wp.tpg, ntiles = p.frames * tpg;
-    WinLevel lv4[4];                    // levels 0..3 in scalar registers (the 4-level fast path)
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-        const WinLevel t = win_level(sh, min(l, L - 1));
-        lv4[l] = WinLevel{__builtin_amdgcn_readfirstlane(t.H), __builtin_amdgcn_readfirstlane(t.W), __builtin_amdgcn_readfirstlane(t.lsi),
-                          __builtin_amdgcn_readfirstlane(t.wb), __builtin_amdgcn_readfirstlane(t.wy0), __builtin_amdgcn_readfirstlane(t.wx0),
-                          __builtin_amdgcn_readfirstlane(t.wh), __builtin_amdgcn_readfirstlane(t.ww)};
-    }
     const int my_tiles = wave < ntiles ? (ntiles - wave + kRsWaves - 1) / kRsWaves : 0;       // <= NT (host)
 
     const int j = lane / 4, cor = lane & 3, hsw = j & 1;
@@ -281,18 +273,20 @@ msda_fwd_win_kernel(const Params p, const WinPlan wp, int slab_bytes)
                     auto group = [&](int g0, float x, float y, float a, const WinLevel &lv, bool in_phase) __attribute__((always_inline)) {
                         const WinGeom g = win_geometry<ROWSH>(x, y, a, lv, in_phase, fS, sh.zero_off);
                         const float hh = 1.f - g.lh, hw = 1.f - g.lw;
-                        const float w4[4] = {g.a * (hh * hw), g.a * (hh * g.lw), g.a * (g.lh * hw), g.a * (g.lh * g.lw)};
+                        float w4[4] = {g.a * (hh * hw), g.a * (hh * g.lw), g.a * (g.lh * hw), g.a * (g.lh * g.lw)};
+                        int a4[4] = {g.adr[0], g.adr[1], g.adr[2], g.adr[3]};
                         static_for<4>([&](auto Rc) {
                             constexpr int R = decltype(Rc)::value;
-                            if (g0 + R >= npts) return;
+                            // (ties step R's broadcasts to this point of the instruction stream: after the previous step's FMAs --
+                            // otherwise the 32 broadcast values of a group are all formed up front and spill)
+                            asm volatile("" : "+v"(a4[0]), "+v"(a4[1]), "+v"(a4[2]), "+v"(a4[3]), "+v"(w4[0]), "+v"(w4[1]), "+v"(w4[2]), "+v"(w4[3]) : "v"(wacc[0]));
 #pragma unroll
-                            for (int s = 0; s < 4; ++s) corner(std::true_type{}, quad_bcast<R>(g.adr[s]) + off1, quad_bcast<R>(w4[s]));
+                            for (int s = 0; s < 4; ++s) corner(std::true_type{}, quad_bcast<R>(a4[s]) + off1, quad_bcast<R>(w4[s]));
                         });
                         // second pass (normally skipped): corners outside their window, from memory
                         if (__builtin_amdgcn_ballot_w64(g.far != 0)) {
                             static_for<4>([&](auto Rc) {
                                 constexpr int R = decltype(Rc)::value;
-                                if (g0 + R >= npts) return;
                                 const int far = quad_bcast<R>(g.far);
                                 if (!__builtin_amdgcn_ballot_w64(far != 0)) return;
                                 const int p00 = quad_bcast<R>(g.p00), Wm = quad_bcast<R>(g.W);
@@ -304,7 +298,6 @@ msda_fwd_win_kernel(const Params p, const WinPlan wp, int slab_bytes)
                             });
                         }
                     };
-                    const bool level_groups = wide && L == 4;         // (uniform) 4 levels x 4 points: group g = level g
 #pragma unroll 1
                     for (int g0 = 0; g0 < npts; g0 += 4) {
                         // (uniform) the group's levels: skip it unless one of them is staged in this phase
@@ -318,21 +311,11 @@ msda_fwd_win_kernel(const Params p, const WinPlan wp, int slab_bytes)
                             load_xy(loc + 2 * (idx0 + kk), x, y);
                             a = Store<TL>::get(aw + idx0 + kk);
                         }
-                        WinLevel lv;
-                        bool in_phase = true;
-                        if (level_groups) {
-                            // the level's tables from scalar registers (selected with the uniform group index)
-                            const int G = g0 >> 2;
-                            auto pick = [&](int a0, int a1, int a2, int a3) { return G == 0 ? a0 : G == 1 ? a1 : G == 2 ? a2 : a3; };
-                            lv = WinLevel{pick(lv4[0].H, lv4[1].H, lv4[2].H, lv4[3].H), pick(lv4[0].W, lv4[1].W, lv4[2].W, lv4[3].W),
-                                          pick(lv4[0].lsi, lv4[1].lsi, lv4[2].lsi, lv4[3].lsi), pick(lv4[0].wb, lv4[1].wb, lv4[2].wb, lv4[3].wb),
-                                          pick(lv4[0].wy0, lv4[1].wy0, lv4[2].wy0, lv4[3].wy0), pick(lv4[0].wx0, lv4[1].wx0, lv4[2].wx0, lv4[3].wx0),
-                                          pick(lv4[0].wh, lv4[1].wh, lv4[2].wh, lv4[3].wh), pick(lv4[0].ww, lv4[1].ww, lv4[2].ww, lv4[3].ww)};
-                        } else {
-                            const int lvl = min((int)(((unsigned)kk * invP) >> 16), L - 1);
-                            lv = win_level(sh, lvl);
-                            in_phase = lvl >= la && lvl < lb;
-                        }
+                        // (the level's tables come from LDS: keeping them in registers -- scalar selects, or one level per lane read
+                        // with v_readlane -- cost ~24 branches per group or the registers the fourth accumulator set needs)
+                        const int lvl = min((int)(((unsigned)kk * invP) >> 16), L - 1);
+                        const WinLevel lv = win_level(sh, lvl);
+                        const bool in_phase = lvl >= la && lvl < lb;
 #if defined(MSDA_WIN_EXP) && MSDA_WIN_EXP == 4           // (timing: points loaded, nothing done with them)
                         wacc[0] += x + y + a + (float)lv.H;
 #else
@@ -416,14 +399,6 @@ msda_bwd_win_kernel(const Params p, const WinPlan wp, int slab_bytes)
     const int ty = tile / wp.tiles_x, tx = tile - ty * wp.tiles_x;
     const WinShared sh = win_setup(p, wp, lds_raw, slab_bytes, ty, tx);
     const int nq = sh.nq, tpg = wp.tpg, ntiles = p.frames * tpg;
-    WinLevel lv4[4];
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-        const WinLevel t = win_level(sh, min(l, L - 1));
-        lv4[l] = WinLevel{__builtin_amdgcn_readfirstlane(t.H), __builtin_amdgcn_readfirstlane(t.W), __builtin_amdgcn_readfirstlane(t.lsi),
-                          __builtin_amdgcn_readfirstlane(t.wb), __builtin_amdgcn_readfirstlane(t.wy0), __builtin_amdgcn_readfirstlane(t.wx0),
-                          __builtin_amdgcn_readfirstlane(t.wh), __builtin_amdgcn_readfirstlane(t.ww)};
-    }
 
     const int j = lane / 4, cor = lane & 3, hsw = j & 1;
     const int off1 = kHalf ? cor * 16 : cor * 16 + hsw * 64, delta2 = hsw ? -64 : 64;
@@ -482,7 +457,6 @@ msda_bwd_win_kernel(const Params p, const WinPlan wp, int slab_bytes)
                     const unsigned invP = (65536u + (unsigned)P - 1u) / (unsigned)P;      // kk / P for kk * P < 2^16
                     const bool wide_ld = p.wide_loads && P == 4 && npts == 16;
                     const bool wide = p.wide_stores && P == 4 && npts == 16 && nph == 1;      // whole-row stores (one phase only)
-                    const bool level_groups = wide_ld && L == 4;         // (uniform) 4 levels x 4 points: group g = level g
                     float wx[4] = {0.f, 0.f, 0.f, 0.f}, wy[4] = {0.f, 0.f, 0.f, 0.f}, wa[4] = {0.f, 0.f, 0.f, 0.f};
                     int wr[4] = {0, 0, 0, 0};
                     float xs[4], ys[4], as[4];
@@ -502,17 +476,7 @@ msda_bwd_win_kernel(const Params p, const WinPlan wp, int slab_bytes)
                             load_xy(loc + 2 * (idx0 + kk), x, y);
                             a = Store<TL>::get(aw + idx0 + kk);
                         }
-                        WinLevel lv;
-                        if (level_groups) {
-                            const int G = g0 >> 2;
-                            auto pick = [&](int a0, int a1, int a2, int a3) { return G == 0 ? a0 : G == 1 ? a1 : G == 2 ? a2 : a3; };
-                            lv = WinLevel{pick(lv4[0].H, lv4[1].H, lv4[2].H, lv4[3].H), pick(lv4[0].W, lv4[1].W, lv4[2].W, lv4[3].W),
-                                          pick(lv4[0].lsi, lv4[1].lsi, lv4[2].lsi, lv4[3].lsi), pick(lv4[0].wb, lv4[1].wb, lv4[2].wb, lv4[3].wb),
-                                          pick(lv4[0].wy0, lv4[1].wy0, lv4[2].wy0, lv4[3].wy0), pick(lv4[0].wx0, lv4[1].wx0, lv4[2].wx0, lv4[3].wx0),
-                                          pick(lv4[0].wh, lv4[1].wh, lv4[2].wh, lv4[3].wh), pick(lv4[0].ww, lv4[1].ww, lv4[2].ww, lv4[3].ww)};
-                        } else {
-                            lv = win_level(sh, lvl);
-                        }
+                        const WinLevel lv = win_level(sh, lvl);
                         const WinGeom pt = win_geometry<ROWSH>(x, y, a, lv, in_phase, fS, sh.zero_off);
                         const int rowrec = pt.bits ? min(pt.yl, 32767) : kNoRow16;
                         if (wide) set4(wr, g0 >> 2, rowrec);
@@ -526,7 +490,6 @@ msda_bwd_win_kernel(const Params p, const WinPlan wp, int slab_bytes)
                         float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f;      // the dots of THIS lane's point
                         static_for<4>([&](auto Rc) {
                             constexpr int R = decltype(Rc)::value;
-                            if (g0 + R >= npts) return;
                             float d[4];
 #pragma unroll
                             for (int s = 0; s < 4; ++s) {
@@ -544,8 +507,7 @@ msda_bwd_win_kernel(const Params p, const WinPlan wp, int slab_bytes)
                         if (__builtin_amdgcn_ballot_w64(pt.far != 0)) {
                             static_for<4>([&](auto Rc) {
                                 constexpr int R = decltype(Rc)::value;
-                                if (g0 + R >= npts) return;
-                                const int far = quad_bcast<R>(pt.far);
+                                    const int far = quad_bcast<R>(pt.far);
                                 if (!__builtin_amdgcn_ballot_w64(far != 0)) return;
                                 const int p00 = quad_bcast<R>(pt.p00), Wm = quad_bcast<R>(pt.W);
                                 const int mpix[4] = {p00, p00 + 1, p00 + Wm, p00 + Wm + 1};
@@ -624,7 +586,8 @@ int launch_fwd_win(int dtype, const Params &p, const WinPlan &w, hipStream_t str
     return dispatch_types(dtype, [&](auto t, auto tl) {
         typedef typename decltype(t)::type T;
         typedef typename decltype(tl)::type TL;
-        return w.nt <= 2 ? fwd_win<T, TL, 2>(p, w, grid, stream) : fwd_win<T, TL, 4>(p, w, grid, stream);
+        // (plans have at most 3 wave tiles per wave: a fourth accumulator set does not fit the 128 registers without spills)
+        return w.nt <= 2 ? fwd_win<T, TL, 2>(p, w, grid, stream) : fwd_win<T, TL, 3>(p, w, grid, stream);
     });
 }
 

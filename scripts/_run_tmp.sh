@@ -1,5 +1,7 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_window_gpu.py tests/test_op_gpu.py -m gpu -q 2>&1 | tail -2
-python3 bench.py --no-cpu-baseline --steps 20 2>&1 | tail -1 | python3 -c "
+timeout 900 python -m pytest tests/test_window_gpu.py -m gpu -q -x 2>&1 | tail -2
+for lib in libmsda_exp_prev libmsda_hip libmsda_exp_prev libmsda_hip; do
+MSDA_LIB=$PWD/devis_amd/$lib.so python3 bench.py --no-other-configs --no-cpu-baseline --steps 5 --warmup 2 --clips 1 --queries 22223 --pyramid B --locs local --dtype f32 2>&1 | tail -1 | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline']['traffic'], d['other_configs']['single_clip_latency'], d['other_configs']['temporal_encoder_800x1333_f32']['fwd_bwd_ms'])"
+d=json.loads(sys.stdin.readline()); print('$lib', d['ms_per_step'], '  '.join('%s %.4f' % (k[:18], v['avg_ms']) for k,v in d['kernels'].items()))"
+done

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from devis_amd import _native
 class A: pass
-a = A(); a.clips=int(os.environ.get("CLIPS","16")); a.frames=6; a.queries=300; a.pyramid=os.environ.get("PYR","A"); a.locs=os.environ.get("LOCS","uniform")
+a = A(); a.clips=int(os.environ.get("CLIPS","16")); a.frames=6; a.queries=int(os.environ.get("QUERIES","300")); a.sampling="storage"; a.pyramid=os.environ.get("PYR","A"); a.locs=os.environ.get("LOCS","uniform")
 dt = bench.DTYPES[os.environ.get("DT","f32")]
 dev = torch.device("cuda:0")
 b = bench.make_clip_batch(a, dev, dt, 1)
