@@ -131,19 +131,32 @@ def gather_value(value_chunk, n_frames, spatial_size, group=None):
 
 
 def sharded_temporal_attention(value_chunk, n_frames, spatial_size, spatial_shapes, level_start_index,
-                               frame_table, loc_curr, aw_curr, loc_temp, aw_temp, group=None):
+                               frame_table, loc_curr, aw_curr, loc_temp, aw_temp, group=None, transport_dtype=None):
     """Mode 2 for one clip.  value_chunk: this rank's rows of the flattened value (see gather_value);
     loc_*/aw_* hold this rank's query range of every frame ([T, Lq_local, M, ...]) -- tensors, or ONE callable that
     produces the four of them (``loc_curr``; the others None): it is called while the all-gather is in flight, so the
     layer's query-side GEMM and pre-op pass overlap the collective.  Returns this rank's output rows
-    [T, Lq_local, M*D].  One all-gather forward, one reduce-scatter backward."""
+    [T, Lq_local, M*D].  One all-gather forward, one reduce-scatter backward.
+
+    ``transport_dtype`` (torch.bfloat16 / torch.float16, with an fp32 model): ``value`` crosses xGMI -- and is sampled -- in that
+    16-bit type, its gradient comes back through the reduce-scatter in it; sampling locations, attention weights and their
+    gradients stay float32 (ABI v11 ``MSDA_*_LOC32``), the output is returned in float32.  Halves the bytes of both
+    collectives (SURVEY f-3: value in the dtype the transport prefers) at the price of ``value`` rounded once to 16 bits
+    (outputs within 5e-3 of the fp32 ones, tests/dist_worker.py)."""
+    out_dtype = None
+    if transport_dtype is not None and value_chunk.dtype != transport_dtype:
+        if value_chunk.dtype != torch.float32 or transport_dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("transport_dtype: bfloat16 / float16 for a float32 value")
+        out_dtype = value_chunk.dtype
+        value_chunk = value_chunk.to(transport_dtype)
     if callable(loc_curr):
         pending = start_gather_value(value_chunk, n_frames, spatial_size, group)
         loc_curr, aw_curr, loc_temp, aw_temp = loc_curr()
         value = pending.wait()
     else:
         value = gather_value(value_chunk, n_frames, spatial_size, group)
-    return MSDeformAttnTemporalFunction.apply(value.contiguous(), spatial_shapes, level_start_index,
-                                              frame_table, loc_curr.contiguous(), aw_curr.contiguous(),
-                                              loc_temp.contiguous(), aw_temp.contiguous(), 1)
+    out = MSDeformAttnTemporalFunction.apply(value.contiguous(), spatial_shapes, level_start_index,
+                                             frame_table, loc_curr.contiguous(), aw_curr.contiguous(),
+                                             loc_temp.contiguous(), aw_temp.contiguous(), 1)
+    return out if out_dtype is None else out.to(out_dtype)
 

@@ -84,6 +84,23 @@ def main():
     close(gac, ref[3][:, q0:q1], "grad_aw_c")
     close(glt, ref[4][:, q0:q1], "grad_loc_t")
     close(gat, ref[5][:, q0:q1], "grad_aw_t")
+    # 16-bit transport of an fp32 clip: value crosses the collective (and is sampled) in bf16, locations / weights stay fp32
+    f32 = lambda t: t.detach().to(torch.float32).requires_grad_(True)
+    v32, l32 = f32(v_chunk), [f32(t) for t in (lc, ac, lt, at)]
+    out3 = cp.sharded_temporal_attention(v32, T, S, shapes, lsi, ftab, *l32, transport_dtype=torch.bfloat16)
+    assert out3.dtype == torch.float32
+    g3 = torch.autograd.grad(out3, [v32] + l32, go.to(torch.float32))
+    assert g3[0].dtype == torch.float32 and all(g.dtype == torch.float32 for g in g3[1:])
+    v_b = torch.from_numpy(d["value"]).to(torch.bfloat16).double().numpy()
+    ref_b = temporal_reference(v_b, *(d[k] for k in ("shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")))
+    def near(a, b, tol, what):
+        err = float(np.abs(a.detach().double().cpu().numpy() - b).max())
+        assert err <= tol * max(1.0, float(np.abs(b).max())), (what, rank, err)
+    near(out3, ref_b[0][:, q0:q1], 1e-2, "transport out")             # (the output leaves the op in bf16)
+    gvb = np.zeros_like(flat); gvb[:rows] = ref_b[1].reshape(rows, M, D)
+    near(g3[0], gvb[rank * chunk:(rank + 1) * chunk], 3e-2, "transport grad_value chunk")    # bf16 partial sums over the ranks
+    near(g3[2], ref_b[3][:, q0:q1], 1e-2, "transport grad_aw_c")
+    near(g3[4], ref_b[5][:, q0:q1], 1e-2, "transport grad_aw_t")
     # the ranges tile the query axis
     r = [cp.shard_range(Lq, world, k) for k in range(world)]
     assert r[0][0] == 0 and r[-1][1] == Lq and all(r[i][1] == r[i + 1][0] for i in range(world - 1))
