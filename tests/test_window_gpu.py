@@ -86,6 +86,42 @@ def test_plain_encoder_call_on_the_window_kernels(P, L, sigma, monkeypatch):
     assert _maxabs(ga.cpu().numpy(), ref[3]) <= 2e-5 * scale(ref[3])
 
 
+@pytest.mark.parametrize("layout", ["padded", "head-major"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1e-2)], ids=["f32", "bf16"])
+def test_window_kernels_take_the_other_value_layouts(layout, dtype, tol, monkeypatch):
+    """`value` with one spare head slot per pixel row (what the modules' value_proj writes) and head-major `value`: the
+    window staging and the second pass address pixels through the strides."""
+    from devis_amd import _native
+    from devis_amd.functions import MSDeformAttnTemporalFunction
+    _force(monkeypatch)
+    shapes, T = PYR_S, 3
+    S = int(sum(h * w for h, w in shapes))
+    d = make_temporal_inputs(21, T=T, W=T - 1, M=8, D=32, Lq=S, shapes=shapes, Pc=4, Pt=4)
+    d["loc_c"] = localise(d["loc_c"], shapes, 4.0, 1)
+    d["loc_t"] = localise(d["loc_t"], shapes, 4.0, 2)
+    d = round_to({k: (np.asarray(v, dtype=np.float64) if v.dtype.kind == "f" else v) for k, v in d.items()}, dtype)
+    keys = ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")
+    ref = temporal_reference(*(d[k] for k in keys))
+    f = lambda k: torch.from_numpy(d[k]).to(DEV, dtype)
+    v = f("value")
+    if layout == "padded":
+        buf = torch.full((T, S, 9, 32), float("nan"), dtype=dtype, device=DEV)
+        buf[:, :, :8] = v
+        v = buf[:, :, :8]
+    else:
+        v = _native.head_major(v)
+    v = v.requires_grad_(True)
+    leaves = [v] + [f(k).requires_grad_(True) for k in ("loc_c", "aw_c", "loc_t", "aw_t")]
+    out = MSDeformAttnTemporalFunction.apply(v, torch.from_numpy(d["shapes"]).to(DEV), torch.from_numpy(d["lsi"]).to(DEV),
+                                             torch.from_numpy(d["ftab"]).to(DEV), *leaves[1:], 1)
+    assert "resident-window" in _route(), _route()
+    scale = lambda x: max(1.0, float(np.abs(x).max()))
+    assert _maxabs(out.detach().double().cpu().numpy(), ref[0]) <= tol * scale(ref[0])
+    grads = torch.autograd.grad(out, leaves, f("grad_out"))
+    for i in (0, 2, 4):         # grad_value, grad_attn (current / temporal)
+        assert _maxabs(grads[i].double().cpu().numpy(), ref[1 + i]) <= (2e-5 if dtype == torch.float32 else 3 * tol) * scale(ref[1 + i]), i
+
+
 def test_window_route_is_automatic_where_the_slab_holds_the_last_level_only():
     """Automatic route: one query per pixel AND a pyramid of which the resident-slab kernels could keep the last level at most
     (fp32 at 800x1333).  (The gather pass follows the same rule; the backward runs on an autograd thread, whose route string
