@@ -741,10 +741,18 @@ def main():
             line["other_configs"] = others
         if padded_line is not None:
             line["padded_value_layout"] = padded_line
-        print(json.dumps(line), flush=True)
     if world > 1 or args.mode == "sharded":
         import torch.distributed as dist
-        dist.destroy_process_group()
+        dist.destroy_process_group()            # (before the line: RCCL logs its library path when the group goes down)
+        sys.stdout.flush(); sys.stderr.flush()
+        if rank == 0 and world > 1:
+            time.sleep(1.0)                     # (the other ranks' teardown messages first)
+    if rank == 0:
+        print(json.dumps(line), flush=True)     # the ONE JSON line, last thing on stdout
+    if world > 1 or args.mode == "sharded":
+        # RCCL logs "Librccl path : ..." when the process exits; nothing may follow the JSON line on stdout
+        sys.stdout.flush()
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
 
 
 if __name__ == "__main__":
