@@ -439,7 +439,7 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
         // owner-computes scatter: no float atomics; pixels outside its bands are zero-filled first
         rc = launch_zero_unowned(p, kOwnPix * p.D, p.gv_storage ? 2 : 4, stream);
         if (rc) return rc;
-        return launch_scatter_grp(dtype, p.gv_storage != 0, p, grid, knobs().scatter_dbg & 255, stream);
+        return launch_scatter_grp(dtype, p.gv_storage != 0, p, grid, knobs().scatter_dbg & 511, stream);
     }
     if (p.gv_storage) return fail(MSDA_ERR_ARG, "msda backward: this call needs grad_value in the arithmetic type (see msda_grad_value_dtype)%s");
     // LDS-atomic scatter: 144 KiB of 8-byte accumulators per workgroup

@@ -324,6 +324,7 @@ typedef unsigned long long u64;
 constexpr int kNoRow16 = -32768;            // culling record of a point that touches no row (see the gather passes)
 constexpr int kSlabMaxLevels = 32;          // levels the resident-slab kernels keep tables for
 constexpr int kScatterMaxLevels = 32;
+constexpr int kOwnMaxSorted = 256;            // (level, band) pairs the owner-computes scatter sorts by position (more: level order)
 constexpr int kScatterMaxSources = 64;      // 1 + frames * window must fit
 constexpr int kCullBlock = 64;              // queries per block summary of the culling records
 constexpr int kLiveWords = 64;              // up to 2048 cull batches per item take the block-summary pre-pass

@@ -1,5 +1,6 @@
 // msda_scatter.hip -- grad_value: the scatter half of the backward.
 #include "msda_common.h"
+#include <algorithm>
 
 #ifndef MSDA_GRP_F32
 #define MSDA_GRP_F32 512
@@ -467,7 +468,7 @@ __device__ __forceinline__ int per_item(int x)
     return x;
 }
 
-template <typename T, typename TL, typename GV>        // TL: storage type of sampling_loc / attn_weight (T, or float with a 16-bit T)
+template <typename T, typename TL, typename GV, bool SORTED>        // SORTED: items in image order (long candidate ranges); TL: storage type of sampling_loc / attn_weight (T, or float with a 16-bit T)
 __global__ void __launch_bounds__(kOwnThreads)
 msda_bwd_value_grp_kernel(const Params p, int dbg)
 {
@@ -491,6 +492,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
     __shared__ unsigned s_live[kLiveWords];            // bitmap of the cull batches that hold a live 64-query block
     __shared__ long long s_item;
     __shared__ int s_ftab[kWave];                      // the frame table (<= 64 slots: scatter_applicable), read once
+    __shared__ unsigned short s_order[SORTED ? kOwnMaxSorted : 1];  // bands of all levels sorted by where they start in the image (see below)
 
     const int tid = threadIdx.x, lane = tid % kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -506,6 +508,30 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         }
         s_first[L] = first;
         s_cnt[0] = s_cnt[1] = s_cnt[2] = 0;
+        // Long candidate ranges (encoder shapes): the dynamic schedule deals the bands of ALL levels in the order of their
+        // position in the image, frames innermost, so that the items an XCD runs at one time read the grad_out rows and the
+        // points of the SAME queries (those near that part of the image) from its L2 -- with the bands of one level and frame
+        // after another every item fetched them from memory again: FETCH_SIZE 4.5 GB for 1.6 GB of inputs on the 800x1333
+        // encoder call (profiles/r03_logs/pmc_enc_hbm.txt).  Insertion sort of <= kOwnMaxSorted (level, band) pairs by
+        // start row / level height.
+        if constexpr (SORTED) {                     // (host: at most kOwnMaxSorted bands)
+            int n = 0;
+            for (int l = 0; l < L; ++l)
+                for (int b = s_first[l]; b < s_first[l + 1]; ++b) {
+                    const float key = s_R[l] > 0 ? (float)((b - s_first[l]) * s_R[l]) / (float)s_H[l] : 0.f;
+                    int j = n++;
+                    while (j > 0) {
+                        const int o = s_order[j - 1];
+                        int lo = 0;
+                        while (lo + 1 < L && s_first[lo + 1] <= o) ++lo;
+                        const float ko = s_R[lo] > 0 ? (float)((o - s_first[lo]) * s_R[lo]) / (float)s_H[lo] : 0.f;
+                        if (ko <= key) break;
+                        s_order[j] = (unsigned short)o;
+                        --j;
+                    }
+                    s_order[j] = (unsigned short)b;
+                }
+        }
     }
     if (tid < kWave) s_ftab[tid] = tid < p.frames * p.window ? p.ftab[tid] : -1;
     int ci = 0;                             // counter of the current cull batch
@@ -522,7 +548,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
     // in the forward); 2-byte types: the 8 channels [8c, 8c+8) = one 16-byte slice of the 64-byte row.
     const int Q = tid / 4, cq = tid & 3, hsw = Q & 1;
     const int off1 = cq * 16 + hsw * 64;
-    const int ch1 = off1 / 4, ch2 = (off1 ^ 64) / 4;           // channels of acc[0..3] / acc[4..7]
+    // (channels of acc[0..3] / acc[4..7]: off1 / 4 and (off1 ^ 64) / 4, formed where they are used)
     const unsigned ents_lds = lds_addr(ents);
 
     for (int64_t it = blockIdx.x;; it += gridDim.x) {
@@ -534,7 +560,15 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         }
         if (item >= n_items) break;
         int l, part, m, f, clip;
-        if (dynamic) {      // heaviest first: levels from the last to the first (see msda_bwd_value_lds_kernel)
+        if (SORTED && dynamic) {      // bands by position in the image, frames innermost (see s_order)
+            m = (int)(item % p.M);
+            int64_t rest = item / p.M;
+            f = (int)(rest % p.frames); rest /= p.frames;
+            part = s_order[rest % NB];
+            clip = (int)(rest / NB);
+            l = 0;
+            while (l + 1 < L && s_first[l + 1] <= part) ++l;
+        } else if (dynamic) {      // heaviest first: levels from the last to the first (see msda_bwd_value_lds_kernel)
             const int64_t ctm = (int64_t)clips * p.frames * p.M;
             l = L - 1;
             int64_t local = item;
@@ -557,7 +591,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             l = 0;
             while (l + 1 < L && s_first[l + 1] <= part) ++l;
         }
-        if ((dbg >> 5) != 0 && l != (dbg >> 5) - 1) continue;       // (measurement: MSDA_SCATTER_DBG = 32 * (level + 1): that level only)
+        if (((dbg >> 5) & 7) != 0 && l != ((dbg >> 5) & 7) - 1) continue;       // (measurement: MSDA_SCATTER_DBG = 32 * (level + 1): that level only)
         const int H = s_H[l], W = s_W[l], R = s_R[l];
         const bool direct = (R == 0);
         const int r0 = direct ? 0 : (part - s_first[l]) * R;
@@ -577,7 +611,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         // frame_table[t, w] == f; per source the first culling-table entry, first loc/attn element, first query row
         if (wave == 0) {
             const int n_tw = p.frames * p.window;
-            const bool hit = lane < n_tw && s_ftab[lane] == f;
+            const bool hit = lane < n_tw && s_ftab[per_item(lane)] == f;
             const u64 bal = __ballot(hit);
             if (lane == 0) {
                 const int64_t g = (int64_t)clip * p.frames + f;
@@ -664,7 +698,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                     if (r0w < n) {
                         float v[8];
                         unpack_raw(static_cast<const T *>(nullptr), raw_rows[i], v);
-                        float4 *dst = reinterpret_cast<float4 *>(rows + (r0w + lane / LPR) * kRowB + (lane % LPR) * 32);
+                        float4 *dst = reinterpret_cast<float4 *>(rows + (r0w + per_item(lane) / LPR) * kRowB + (lane % LPR) * 32);
                         dst[0] = make_float4(v[0], v[1], v[2], v[3]);
                         dst[1] = make_float4(v[4], v[5], v[6], v[7]);
                     }
@@ -782,7 +816,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         const int nbat = (ng + kOwnThreads - 1) / kOwnThreads;
         const bool skipping = p.bsum != nullptr && nbat > 4 && nbat <= 32 * kLiveWords;
         if (skipping) {
-            if (tid < kLiveWords) s_live[tid] = 0u;
+            if (tid < kLiveWords) s_live[per_item(tid)] = 0u;
             __syncthreads();
             const int nblk = (p.Lq + kCullBlock - 1) / kCullBlock, nb_tot = s_nsrc * nblk;
             for (int bk = tid; bk < nb_tot; bk += kOwnThreads) {
@@ -877,8 +911,8 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                 if constexpr (std::is_same<GV, float>::value) {
                     if (pix < npix) {
                         GV *o = gquad + (int64_t)s * kOwnQuads * MD;
-                        put4(o + ch1, acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
-                        put4(o + ch2, acc[s][4], acc[s][5], acc[s][6], acc[s][7]);
+                        put4(o + off1 / 4, acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
+                        put4(o + (off1 ^ 64) / 4, acc[s][4], acc[s][5], acc[s][6], acc[s][7]);
                     }
                 } else {
                     // 16-bit grad_value: lane c of the quad gathers channels [8c, 8c+8) -- the first four from lane 2c mod 4, the
@@ -916,8 +950,8 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             float *part = reinterpret_cast<float *>(rows);
             if (Q < nvpix) {
                 float *mine = part + per_item(Q) * D;
-                *reinterpret_cast<float4 *>(mine + ch1) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
-                *reinterpret_cast<float4 *>(mine + ch2) = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
+                *reinterpret_cast<float4 *>(mine + per_item(off1) / 4) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+                *reinterpret_cast<float4 *>(mine + (per_item(off1) ^ 64) / 4) = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
             }
             __syncthreads();
             GV *gband = gmap + (int64_t)r0 * W * MD;
@@ -982,11 +1016,11 @@ int scatter_lds_g(int G, const Params &p, unsigned grid, int cap_bytes, int dbg,
     }
 }
 
-template <typename T, typename TL, typename GV>
+template <typename T, typename TL, typename GV, bool SORTED>
 int scatter_grp(const Params &p, unsigned grid, int dbg, hipStream_t stream)
 {
     static LdsGrant granted;
-    const auto kern = &msda_bwd_value_grp_kernel<T, TL, GV>;
+    const auto kern = &msda_bwd_value_grp_kernel<T, TL, GV, SORTED>;
     if (const int rc = grant_lds(reinterpret_cast<const void *>(kern), (size_t)grp_lds_bytes<T>(), granted,
                                  "the group-granular owner-computes scatter kernel")) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kOwnThreads), (size_t)grp_lds_bytes<T>(), stream, p, dbg);
@@ -1024,10 +1058,20 @@ int launch_scatter_grp(int dtype, bool storage_typed, const Params &p, unsigned 
     return dispatch_types(dtype, [&](auto t, auto tl) {
         using T = typename decltype(t)::type;
         using TL = typename decltype(tl)::type;
-        if constexpr (sizeof(T) == 2) {
-            if (storage_typed) return scatter_grp<T, TL, T>(p, grid, dbg, stream);
+        // items in image order for long candidate ranges (encoder shapes), when the host knows the band count (MSDA_SCATTER_DBG
+        // = 256: the level-by-level order)
+        bool sorted = p.Lq >= 2048 && p.shapes_host != nullptr && (dbg & 256) == 0;
+        int bands = 0;
+        for (int l = 0; sorted && l < p.L; ++l) {
+            const long long H = p.shapes_host[2 * l], W = p.shapes_host[2 * l + 1];
+            const long long R = W > 0 ? std::min<long long>(H, kOwnPix / W) : 0;
+            bands += R > 0 ? (int)((H + R - 1) / R) : 1;
         }
-        return scatter_grp<T, TL, float>(p, grid, dbg, stream);
+        sorted = sorted && bands <= kOwnMaxSorted;
+        if constexpr (sizeof(T) == 2) {
+            if (storage_typed) return sorted ? scatter_grp<T, TL, T, true>(p, grid, dbg, stream) : scatter_grp<T, TL, T, false>(p, grid, dbg, stream);
+        }
+        return sorted ? scatter_grp<T, TL, float, true>(p, grid, dbg, stream) : scatter_grp<T, TL, float, false>(p, grid, dbg, stream);
     });
 }
 
