@@ -212,8 +212,9 @@ bool scatter_applicable(const Params &p)
 // culling records (or no records at all).
 bool owner_scatter_applicable(const Params &p, int esz)
 {
+    // (work items -- (clip, frame, head, band) with at most one band per pixel row -- are counted in 32 bits)
     return p.D == 32 && (esz == 4 || esz == 2) && p.PA <= 4 && p.PB <= 4 && p.Lq < (1 << 22) && knobs().scatter_own != 0 &&
-           knobs().scatter_lds_kb == 144 && scatter_applicable(p);
+           knobs().scatter_lds_kb == 144 && (int64_t)p.groups * p.M * ((int64_t)p.S + p.L) < 0x7fffffffLL && scatter_applicable(p);
 }
 
 // The resident-slab kernels take D = 32 in 2- / 4-byte types when the index arithmetic fits and at least the last
@@ -439,7 +440,7 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
         // owner-computes scatter: no float atomics; pixels outside its bands are zero-filled first
         rc = launch_zero_unowned(p, kOwnPix * p.D, p.gv_storage ? 2 : 4, stream);
         if (rc) return rc;
-        return launch_scatter_grp(dtype, p.gv_storage != 0, p, grid, knobs().scatter_dbg & 511, stream);
+        return launch_scatter_grp(dtype, p.gv_storage != 0, p, grid * (1024 / kOwnThreads), knobs().scatter_dbg & 511, stream);
     }
     if (p.gv_storage) return fail(MSDA_ERR_ARG, "msda backward: this call needs grad_value in the arithmetic type (see msda_grad_value_dtype)%s");
     // LDS-atomic scatter: 144 KiB of 8-byte accumulators per workgroup

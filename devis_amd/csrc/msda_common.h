@@ -377,9 +377,15 @@ __device__ __forceinline__ void load_xy(const f16_t *loc2, float &x, float &y)
 // ------------------------------------------------------------------------------------------------
 constexpr int kRowSlots = kPch + 1;         // tile kernels: 16-byte record slots per row (odd: LDS banks)
 // owner-computes scatter
-constexpr int kOwnThreads = 1024;
+#ifndef MSDA_OWN_THREADS
+#define MSDA_OWN_THREADS 1024
+#endif
+#ifndef MSDA_OWN_SLOTS
+#define MSDA_OWN_SLOTS 4
+#endif
+constexpr int kOwnThreads = MSDA_OWN_THREADS;       // (512: two workgroups per CU out of phase with each other)
 constexpr int kOwnQuads = kOwnThreads / 4;
-constexpr int kOwnSlots = 4;                        // pixels per owner quad
+constexpr int kOwnSlots = MSDA_OWN_SLOTS;           // pixels per owner quad
 constexpr int kOwnPix = kOwnQuads * kOwnSlots;      // pixels per band
 // resident-slab kernels
 #ifndef MSDA_RS_THREADS

@@ -441,6 +441,17 @@ msda_cull_summary_kernel(const Params p)
 // cuh:125-152); terms are the products (w_corner * attn) * grad_out[c].
 constexpr unsigned kOwnNil = 0xffffffffu;
 
+// Timeline probe (-DMSDA_SCATTER_TRACE, experimental builds only): lane 0 of wave 1 of the first 8 workgroups stamps the shader
+// clock at phase boundaries; scripts/scatter_trace.py reads the stamps back through msda_debug_trace and sums the phases.
+#ifdef MSDA_SCATTER_TRACE
+constexpr int kTraceLen = 8192;
+__device__ unsigned long long g_trace[8][kTraceLen];
+__device__ int g_trace_n[8];
+#define MSDA_TR(id) do { if (tr_on && tr_n < kTraceLen) g_trace[blockIdx.x][tr_n++] = ((unsigned long long)__builtin_readcyclecounter() << 8) | (unsigned)(id); } while (0)
+#else
+#define MSDA_TR(id) do { } while (0)
+#endif
+
 // ---- group-granular variant -------------------------------------------------------------------------------------
 // A chunk is kGrpChunk (row, level) GROUPS -- the <= 4 sampling points one query puts on one level of one source frame --
 // instead of 768 single points: the points of a group share their grad_out row, so the row is staged ONCE per group
@@ -469,7 +480,7 @@ __device__ __forceinline__ int per_item(int x)
 }
 
 template <typename T, typename TL, typename GV, bool SORTED>        // SORTED: items in image order (long candidate ranges); TL: storage type of sampling_loc / attn_weight (T, or float with a 16-bit T)
-__global__ void __launch_bounds__(kOwnThreads)
+__global__ void __launch_bounds__(kOwnThreads, 4)
 msda_bwd_value_grp_kernel(const Params p, int dbg)
 {
     constexpr int D = 32, kRowB = D * 4;                        // bytes of one staged grad_out row (fp32)
@@ -486,17 +497,24 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
     unsigned *list = head + kOwnPix;                                            // [kGrpList] (k:6 | points:4 | q:22)
     __shared__ int s_H[kScatterMaxLevels], s_W[kScatterMaxLevels], s_R[kScatterMaxLevels],
         s_first[kScatterMaxLevels + 1], s_lsi[kScatterMaxLevels];
-    __shared__ int s_nsrc, s_cnt[3];     // survivor counters rotate: slot j is reset two barriers before it is used again
-    __shared__ long long s_src_tab[kScatterMaxSources], s_src_loc[kScatterMaxSources];
-    __shared__ int s_src_q0[kScatterMaxSources], s_src_gmv[kScatterMaxSources];
+    __shared__ int s_cnt[3];             // survivor counters rotate: slot j is reset two barriers before it is used again
+    // Item descriptors and source tables are double-buffered: wave 0 prepares item n + 1 (ticket, decode, tables) in the shadow
+    // of item n's first culling records, so an item starts without a barrier or a division of its own.
+    __shared__ int s_desc2[2][8];        // valid, level, band, head, frame, clip
+    __shared__ int s_nsrc2[2];
+    __shared__ long long s_src_tab2[2][kScatterMaxSources], s_src_loc2[2][kScatterMaxSources];
+    __shared__ int s_src_q02[2][kScatterMaxSources], s_src_gmv2[2][kScatterMaxSources];
     __shared__ unsigned s_live[kLiveWords];            // bitmap of the cull batches that hold a live 64-query block
-    __shared__ long long s_item;
     __shared__ int s_ftab[kWave];                      // the frame table (<= 64 slots: scatter_applicable), read once
     __shared__ unsigned short s_order[SORTED ? kOwnMaxSorted : 1];  // bands of all levels sorted by where they start in the image (see below)
 
     const int tid = threadIdx.x, lane = tid % kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int MD = p.M * D, L = p.L, VL = p.LA + p.LB;
+#ifdef MSDA_SCATTER_TRACE
+    const bool tr_on = blockIdx.x < 8 && tid == 64;
+    int tr_n = 0;
+#endif
     if (tid == 0) {
         int first = 0;
         for (int l = 0; l < L; ++l) {
@@ -539,8 +557,8 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
     __syncthreads();
     const int NB = s_first[L];
     const int clips = p.groups / p.frames;
-    const int64_t n_items = (int64_t)clips * p.frames * p.M * NB;
-    const bool dynamic = p.workspace != nullptr && (dbg & 16) == 0 && n_items < (int64_t)16 * gridDim.x;
+    const unsigned n_items = (unsigned)clips * (unsigned)p.frames * (unsigned)p.M * (unsigned)NB;      // (< 2^31: host)
+    const bool dynamic = p.workspace != nullptr && (dbg & 16) == 0 && n_items < 16u * gridDim.x;
     const int lane8 = blockIdx.x % 8;
     const int strideA = p.M * p.LA * p.PA, strideB = p.M * p.LB * p.PB;      // loc/attn elements per query
     // owner side: quad Q owns pixels s * kOwnQuads + Q of the band.  4-byte types: lane c of the quad holds the
@@ -551,47 +569,95 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
     // (channels of acc[0..3] / acc[4..7]: off1 / 4 and (off1 ^ 64) / 4, formed where they are used)
     const unsigned ents_lds = lds_addr(ents);
 
-    for (int64_t it = blockIdx.x;; it += gridDim.x) {
-        int64_t item = it;
+    // Wave 0: the workgroup's n-th item -> descriptor + source tables in buffer `buf`.  Static stride or one ticket per item
+    // (dynamic); 32-bit arithmetic throughout.
+    auto prepare = [&](unsigned n, int buf) {
+        unsigned item;
         if (dynamic) {
-            if (tid == 0) s_item = (long long)atomicAdd(p.workspace + lane8, 1u) * 8 + lane8;
-            __syncthreads();
-            item = s_item;
-        }
-        if (item >= n_items) break;
-        int l, part, m, f, clip;
-        if (SORTED && dynamic) {      // bands by position in the image, frames innermost (see s_order)
-            m = (int)(item % p.M);
-            int64_t rest = item / p.M;
-            f = (int)(rest % p.frames); rest /= p.frames;
-            part = s_order[rest % NB];
-            clip = (int)(rest / NB);
-            l = 0;
-            while (l + 1 < L && s_first[l + 1] <= part) ++l;
-        } else if (dynamic) {      // heaviest first: levels from the last to the first (see msda_bwd_value_lds_kernel)
-            const int64_t ctm = (int64_t)clips * p.frames * p.M;
-            l = L - 1;
-            int64_t local = item;
-            while (l > 0 && local >= ctm * (s_first[l + 1] - s_first[l])) {
-                local -= ctm * (s_first[l + 1] - s_first[l]);
-                --l;
-            }
-            const int nb_l = s_first[l + 1] - s_first[l];
-            m = (int)(local % p.M);
-            int64_t rest = local / p.M;
-            part = s_first[l] + (int)(rest % nb_l); rest /= nb_l;
-            f = (int)(rest % p.frames);
-            clip = (int)(rest / p.frames);
+            unsigned tk = 0u;
+            if (lane == 0) tk = atomicAdd(p.workspace + lane8, 1u);
+            item = (unsigned)__builtin_amdgcn_readfirstlane((int)tk) * 8u + (unsigned)lane8;
         } else {
-            m = (int)(item % p.M);
-            int64_t rest = item / p.M;
-            part = (int)(rest % NB); rest /= NB;
-            f = (int)(rest % p.frames);
-            clip = (int)(rest / p.frames);
-            l = 0;
-            while (l + 1 < L && s_first[l + 1] <= part) ++l;
+            item = blockIdx.x + n * gridDim.x;
         }
-        if (((dbg >> 5) & 7) != 0 && l != ((dbg >> 5) & 7) - 1) continue;       // (measurement: MSDA_SCATTER_DBG = 32 * (level + 1): that level only)
+        const bool valid = item < n_items;
+        int l = 0, part = 0, m = 0, f = 0, clip = 0;
+        if (valid) {
+            const unsigned M = (unsigned)p.M, F = (unsigned)p.frames;
+            if (SORTED && dynamic) {      // bands by position in the image, frames innermost (see s_order)
+                m = (int)(item % M);
+                unsigned rest = item / M;
+                f = (int)(rest % F); rest /= F;
+                part = s_order[rest % (unsigned)NB];
+                clip = (int)(rest / (unsigned)NB);
+                while (l + 1 < L && s_first[l + 1] <= part) ++l;
+            } else if (dynamic) {      // heaviest first: levels from the last to the first (see msda_bwd_value_lds_kernel)
+                const unsigned ctm = (unsigned)clips * F * M;
+                l = L - 1;
+                unsigned local = item;
+                while (l > 0 && local >= ctm * (unsigned)(s_first[l + 1] - s_first[l])) {
+                    local -= ctm * (unsigned)(s_first[l + 1] - s_first[l]);
+                    --l;
+                }
+                const unsigned nb_l = (unsigned)(s_first[l + 1] - s_first[l]);
+                m = (int)(local % M);
+                unsigned rest = local / M;
+                part = s_first[l] + (int)(rest % nb_l); rest /= nb_l;
+                f = (int)(rest % F);
+                clip = (int)(rest / F);
+            } else {
+                m = (int)(item % M);
+                unsigned rest = item / M;
+                part = (int)(rest % (unsigned)NB); rest /= (unsigned)NB;
+                f = (int)(rest % F);
+                clip = (int)(rest / F);
+                while (l + 1 < L && s_first[l + 1] <= part) ++l;
+            }
+        }
+        if (lane == 0) {
+            int *d = s_desc2[buf];
+            d[0] = valid ? 1 : 0; d[1] = l; d[2] = part; d[3] = m; d[4] = f; d[5] = clip;
+        }
+        if (!valid) return;
+        // sources that read frame f: the current-frame points of frame f, then every temporal slot (t, w) with
+        // frame_table[t, w] == f; per source the first culling-table entry, first loc/attn element, first query row
+        const int n_tw = p.frames * p.window;
+        const bool hit = lane < n_tw && s_ftab[lane] == f;
+        const u64 bal = __ballot(hit);
+        if (lane == 0) {
+            const int64_t g = (int64_t)clip * p.frames + f;
+            s_src_tab2[buf][0] = ((g * p.M + m) * VL + l) * p.Lq;
+            s_src_loc2[buf][0] = (g * p.Lq * p.M + m) * ((int64_t)p.LA * p.PA) + l * p.PA;
+            s_src_q02[buf][0] = (int)(g * p.Lq);
+            s_src_gmv2[buf][0] = (int)((g * p.M + m) * VL + l);
+            s_nsrc2[buf] = 1 + (int)__popcll(bal);
+        }
+        if (hit) {
+            const int k = 1 + (int)__popcll(bal & ((1ull << lane) - 1ull)), t = lane / p.window;
+            const int vl = (lane - t * p.window) * L + l;
+            const int64_t g = (int64_t)clip * p.frames + t;
+            s_src_tab2[buf][k] = ((g * p.M + m) * VL + p.LA + vl) * p.Lq;
+            s_src_loc2[buf][k] = (g * p.Lq * p.M + m) * ((int64_t)p.LB * p.PB) + vl * p.PB;
+            s_src_q02[buf][k] = (int)(g * p.Lq);
+            s_src_gmv2[buf][k] = (int)((g * p.M + m) * VL + p.LA + vl);
+        }
+    };
+    if (wave == 0) prepare(0u, 0);
+    __syncthreads();
+
+    for (unsigned it = 0;; ++it) {
+        const int cur = (int)(it & 1u);
+        if (!s_desc2[cur][0]) break;
+        MSDA_TR(1);                 // item start
+        const int l = s_desc2[cur][1], part = s_desc2[cur][2], m = s_desc2[cur][3], f = s_desc2[cur][4], clip = s_desc2[cur][5];
+        const long long *s_src_tab = s_src_tab2[cur], *s_src_loc = s_src_loc2[cur];
+        const int *s_src_q0 = s_src_q02[cur], *s_src_gmv = s_src_gmv2[cur];
+        const int s_nsrc = s_nsrc2[cur];
+        if (((dbg >> 5) & 7) != 0 && l != ((dbg >> 5) & 7) - 1) {       // (measurement: MSDA_SCATTER_DBG = 32 * (level + 1): that level only)
+            if (wave == 0) prepare(it + 1u, cur ^ 1);
+            __syncthreads();
+            continue;
+        }
         const int H = s_H[l], W = s_W[l], R = s_R[l];
         const bool direct = (R == 0);
         const int r0 = direct ? 0 : (part - s_first[l]) * R;
@@ -606,32 +672,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         const int SF = 1 << sfs, nvpix = npix << sfs;
         GV *gmap = static_cast<GV *>(p.grad_value) +
                    (((int64_t)clip * p.frames + f) * p.S + s_lsi[l]) * MD + m * D;        // pixel (0, 0) of the level, head m
-
-        // sources that read frame f: the current-frame points of frame f, then every temporal slot (t, w) with
-        // frame_table[t, w] == f; per source the first culling-table entry, first loc/attn element, first query row
-        if (wave == 0) {
-            const int n_tw = p.frames * p.window;
-            const bool hit = lane < n_tw && s_ftab[per_item(lane)] == f;
-            const u64 bal = __ballot(hit);
-            if (lane == 0) {
-                const int64_t g = (int64_t)clip * p.frames + f;
-                s_src_tab[0] = ((g * p.M + m) * VL + l) * p.Lq;
-                s_src_loc[0] = (g * p.Lq * p.M + m) * ((int64_t)p.LA * p.PA) + l * p.PA;
-                s_src_q0[0] = (int)(g * p.Lq);
-                s_src_gmv[0] = (int)((g * p.M + m) * VL + l);
-                s_nsrc = 1 + (int)__popcll(bal);
-            }
-            if (hit) {
-                const int n = 1 + (int)__popcll(bal & ((1ull << per_item(lane)) - 1ull)), t = lane / p.window;
-                const int vl = (lane - t * p.window) * L + l;
-                const int64_t g = (int64_t)clip * p.frames + t;
-                s_src_tab[n] = ((g * p.M + m) * VL + p.LA + vl) * p.Lq;
-                s_src_loc[n] = (g * p.Lq * p.M + m) * ((int64_t)p.LB * p.PB) + vl * p.PB;
-                s_src_q0[n] = (int)(g * p.Lq);
-                s_src_gmv[n] = (int)((g * p.M + m) * VL + p.LA + vl);
-            }
-        }
-        __syncthreads();
+        MSDA_TR(2);                 // item decoded
         const int ng = s_nsrc * p.Lq;              // candidate groups: (source, query) pairs, <= 4 points each
 
         float acc[kOwnSlots][8];
@@ -670,12 +711,19 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         auto stage_rows = [&](int base, int n) {
             if (direct || (dbg & 4)) return;
             const T *go = static_cast<const T *>(p.grad_out) + m * D + per_item(lane % LPR) * (16 / (int)sizeof(T));
+            // (all list entries, then all first-query rows, then the loads: read one by one inside the per-instruction branches
+            // below, the two dependent LDS round trips of every instruction ran back to back)
+            unsigned es[RPWV / HPI];
+            int qrs[RPWV / HPI];
+#pragma unroll
+            for (int i = 0; i < RPWV / HPI; ++i) es[i] = list[base + min(wave * RPWV + HPI * i + lane / LPR, n - 1)];
+#pragma unroll
+            for (int i = 0; i < RPWV / HPI; ++i) qrs[i] = s_src_q0[es[i] >> 26] + (int)(es[i] & 0x3fffffu);
 #pragma unroll
             for (int i = 0; i < RPWV / HPI; ++i) {
                 const int r0w = wave * RPWV + HPI * i;
                 if (r0w < n) {                                      // uniform: this instruction has at least one live row
-                    const unsigned e = list[base + min(r0w + lane / LPR, n - 1)];
-                    const int qr = s_src_q0[e >> 26] + (int)(e & 0x3fffffu);
+                    const int qr = qrs[i];
                     const T *gp = go + (int64_t)qr * MD;
                     if constexpr (kHalf) {
                         raw_rows[i] = *reinterpret_cast<const u32x4 *>(gp);
@@ -783,17 +831,24 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             }
         };
         auto process_chunk = [&](int base, int n, bool primed, int nbase, int nn) {
+            MSDA_TR(10);            // chunk start
             stage_rows(base, n);
             if (!primed) fetch_chunk(base, n);
+            MSDA_TR(11);            // rows / points issued
 #pragma unroll
             for (int j = 0; j < kPasses; ++j)
                 if (j == 0 || n > j * (kOwnThreads / 4)) taps_link(j, hact[j], hx[j], hy[j], ha[j], hq[j]);
+            MSDA_TR(12);            // taps + links done
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's rows have landed
             stage_rows_finish(n);
+            MSDA_TR(13);            // rows landed
             __syncthreads();
+            MSDA_TR(14);            // barrier 1
             if (nn > 0) fetch_chunk(nbase, nn);
             walk();
+            MSDA_TR(15);            // walk done
             __syncthreads();
+            MSDA_TR(16);            // barrier 2
         };
 
         // ---- cull the candidate groups in batches of one per thread against the band; chunks are cut from the END
@@ -844,6 +899,10 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         bool live;
         int bcur = next_live(0);
         if (bcur < nbat) load_records(bcur * kOwnThreads, iv, ent, live);
+        // the next item's descriptor and tables, while the records fly -- with a static stride; a dynamic schedule draws its
+        // ticket as late as it can (below): a workgroup that commits itself to a heavy item one item early is missing at the tail
+        // (measured: 800x1333 encoder call 2.76 -> 3.58 ms with early tickets)
+        if (wave == 0 && !dynamic) prepare(it + 1u, cur ^ 1);
         while (bcur < nbat) {
             const int bnext = next_live(bcur + 1);
             unsigned pm = 0u;
@@ -874,7 +933,9 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             if (lane == 0 && total) wbase = atomicAdd(&s_cnt[ci], total);
             wbase = __shfl(wbase, 0, kWave);
             if (cnt) list[listed + wbase + v - cnt] = ent_now | (pm << 22);
+            MSDA_TR(3);             // cull batch: records consumed, survivors listed
             __syncthreads();
+            MSDA_TR(4);             // cull batch barrier
             listed += s_cnt[ci];
             ci = (ci + 1) % 3;
             if (dbg & 8) listed = 0;                    // measurement: cull only
@@ -892,6 +953,8 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             }
             bcur = bnext;
         }
+        MSDA_TR(5);                 // all chunks done
+        if (wave == 0 && dynamic) prepare(it + 1u, cur ^ 1);
         // ---- owners store their pixels: grad_value is overwritten, every pixel of the band exactly once
         auto put4 = [&](GV *dst, float a, float b, float c, float d) {      // 4 consecutive channels, non-temporal
             if constexpr (std::is_same<GV, float>::value) {
@@ -965,8 +1028,13 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                 put4(gband + (int64_t)pix * MD + c4, sum.x, sum.y, sum.z, sum.w);
             }
         }
+        MSDA_TR(6);                 // stores issued
         __syncthreads();
+        MSDA_TR(7);                 // item end
     }
+#ifdef MSDA_SCATTER_TRACE
+    if (tr_on) g_trace_n[blockIdx.x] = tr_n;
+#endif
 }
 
 // The LDS scatter kernels OVERWRITE every pixel of a level whose row fits the band budget.  Pixels they
@@ -1058,9 +1126,14 @@ int launch_scatter_grp(int dtype, bool storage_typed, const Params &p, unsigned 
     return dispatch_types(dtype, [&](auto t, auto tl) {
         using T = typename decltype(t)::type;
         using TL = typename decltype(tl)::type;
-        // items in image order for long candidate ranges (encoder shapes), when the host knows the band count (MSDA_SCATTER_DBG
-        // = 256: the level-by-level order)
-        bool sorted = p.Lq >= 2048 && p.shapes_host != nullptr && (dbg & 256) == 0;
+        // items in image order for long candidate ranges of a TEMPORAL call (the encoder's fused call: the frames of one band
+        // run side by side and share the rows and points of the queries near it), when the host knows the band count
+        // (MSDA_SCATTER_DBG = 256: the level-by-level order).  Plain calls keep the heaviest-first order: measured on one box,
+        // image order / level order: 800x1333 T = 6 one clip 2.76 / 2.86 ms, 360x640 T = 6 0.54 / 0.55, but the single-frame
+        // encoder call of BASELINE configs[1] (N = 8, bf16) 0.92 / 0.63 and the SwinL one (N = 6, fp16) 0.23 / 0.17 -- with
+        // `clip` outermost the batch is 8 serial tails.
+        // (round 4, after the per-item fixed costs shrank: at 360x640, Lq = 4820, image order is now the slower one, 0.555 / 0.529)
+        bool sorted = p.Lq >= 8192 && p.frames > 1 && p.shapes_host != nullptr && (dbg & 256) == 0;
         int bands = 0;
         for (int l = 0; sorted && l < p.L; ++l) {
             const long long H = p.shapes_host[2 * l], W = p.shapes_host[2 * l + 1];
@@ -1076,3 +1149,12 @@ int launch_scatter_grp(int dtype, bool storage_typed, const Params &p, unsigned 
 }
 
 }  // namespace msda
+
+#ifdef MSDA_SCATTER_TRACE
+extern "C" int msda_debug_trace(unsigned long long *dst, int *counts)
+{
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(msda::g_trace), sizeof(unsigned long long) * 8 * msda::kTraceLen) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(counts, HIP_SYMBOL(msda::g_trace_n), sizeof(int) * 8) != hipSuccess) return -2;
+    return msda::kTraceLen;
+}
+#endif
