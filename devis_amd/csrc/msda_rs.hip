@@ -30,6 +30,36 @@ namespace {
 #endif
 #include "msda_rs_common.inc"
 
+// Timeline probe (-DMSDA_RS_TRACE, experimental builds only; scripts/rs_trace.py): lane 0 of one wave of the first 8 workgroups
+// stamps the shader clock at phase boundaries of the forward.
+#ifdef MSDA_RS_TRACE
+constexpr int kRsTraceLen = 4096;
+__device__ unsigned long long g_rs_trace[8][kRsTraceLen];
+__device__ int g_rs_trace_n[8];
+#define MSDA_RTR(id) do { if (tr_on && tr_n < kRsTraceLen) g_rs_trace[blockIdx.x][tr_n++] = ((unsigned long long)__builtin_readcyclecounter() << 8) | (unsigned)(id); } while (0)
+#else
+#define MSDA_RTR(id) do { } while (0)
+#endif
+
+// Static issue priority by wave index: the waves of a workgroup share their SIMD's issue slots by priority, then AGE, so the
+// last-dispatched waves of a 16-wave workgroup lose every arbitration and set the time of each frame's barrier (timeline probe,
+// profiles/r04_logs/rs_trace_*.txt: the last wave's slots took twice as long as wave 1's).  MSDA_RS_PRIO = 1: priority 0..3 by
+// quarter of the workgroup, youngest highest.
+#ifndef MSDA_RS_PRIO
+#define MSDA_RS_PRIO 0
+#endif
+__device__ __forceinline__ void rs_wave_priority(int wave)
+{
+#if MSDA_RS_PRIO
+    const int q = wave * 4 / kRsWaves;
+    if (q == 1) __builtin_amdgcn_s_setprio(1);
+    else if (q == 2) __builtin_amdgcn_s_setprio(2);
+    else if (q == 3) __builtin_amdgcn_s_setprio(3);
+#else
+    (void)wave;
+#endif
+}
+
 // levels >= l0 of source frame f (head m) -> LDS slab, 16 bytes per lane by LDS-DMA (8 lanes per pixel)
 template <typename T>
 __device__ __forceinline__ void rs_stage_slab(const Params &p, T *slab, int clip, int m, int f, int px0, int npx,
@@ -212,13 +242,22 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
     for (int k = 0; k < NT; ++k)
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[k][c] = 0.f;
+#ifdef MSDA_RS_TRACE
+    const bool tr_on = blockIdx.x < 8 && tid == (blockIdx.x < 4 ? 64 : kRsThreads - 64);
+    int tr_n = 0;
+#endif
+    rs_wave_priority(wave);
+    MSDA_RTR(9);                    // prologue done
 
     for (int f = 0; f < p.frames; ++f) {
         __syncthreads();                                   // every wave is done with the previous slab
+        MSDA_RTR(1);                // barrier: previous slab free
 #if !defined(MSDA_RS_EXP) || MSDA_RS_EXP != 3
         if (l0 < L) rs_stage_slab<T>(p, slab, clip, m, f, sh.px0, sh.npx, wave, lane);
 #endif
+        MSDA_RTR(2);                // slab pieces issued and landed
         __syncthreads();
+        MSDA_RTR(3);                // barrier: slab complete
         const int fS = f * p.S;
 #pragma unroll 1
         for (int k = 0; k < my_tiles; ++k) {
@@ -282,6 +321,7 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                 const bool wide = p.wide_loads && P == 4 && npts == 16;           // (uniform) see load_slot_points
                 float xs[4], ys[4], as[4];
                 if (wide) load_slot_points<TL>(loc, aw, idx0, cor, live, xs, ys, as);
+                MSDA_RTR(4);        // slot: points loaded (first use waits)
 #if MSDA_RS_PIPE
                 if (wide && l0 == PL0) {
                     // 4 levels x 4 points, levels < l0 outside the slab.  Work units are corner PAIRS: 8 * l0 memory pairs (4
@@ -361,6 +401,7 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                     }
                 }
             }
+            MSDA_RTR(5);            // tile done for this frame
             static_for<NT>([&](auto Kc) {
                 constexpr int K = decltype(Kc)::value;
                 if (k == K) {
@@ -370,6 +411,7 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
             });
         }
     }
+    MSDA_RTR(6);
     static_for<NT>([&](auto Kc) {
         constexpr int K = decltype(Kc)::value;
         if (K >= my_tiles) return;
@@ -387,6 +429,9 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
             }
         }
     });
+#ifdef MSDA_RS_TRACE
+    if (tr_on) g_rs_trace_n[blockIdx.x] = tr_n;
+#endif
 }
 
 // Backward gather pass (grad_loc / grad_attn) on the resident slab: same workgroup / tile / quad geometry as
@@ -430,6 +475,7 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(vbase), 0, (int)vbytes, 0x00020000);
 #endif
     const bool records = p.bbox != nullptr;        // per-point culling records (host: only with cull_points)
+    rs_wave_priority(wave);
 
     for (int f = 0; f < p.frames; ++f) {
         __syncthreads();                                   // every wave is done with the previous slab
@@ -727,3 +773,12 @@ int launch_bwd_rs(int dtype, int first_slab_level, const Params &p, int parts, u
 }
 
 }  // namespace msda
+
+#ifdef MSDA_RS_TRACE
+extern "C" int msda_debug_trace_rs(unsigned long long *dst, int *counts)
+{
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(msda::g_rs_trace), sizeof(unsigned long long) * 8 * msda::kRsTraceLen) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(counts, HIP_SYMBOL(msda::g_rs_trace_n), sizeof(int) * 8) != hipSuccess) return -2;
+    return msda::kRsTraceLen;
+}
+#endif

@@ -1092,6 +1092,9 @@ int scatter_grp(const Params &p, unsigned grid, int dbg, hipStream_t stream)
     if (const int rc = grant_lds(reinterpret_cast<const void *>(kern), (size_t)grp_lds_bytes<T>(), granted,
                                  "the group-granular owner-computes scatter kernel")) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kOwnThreads), (size_t)grp_lds_bytes<T>(), stream, p, dbg);
+    if (SORTED)
+        return check_launch(std::is_same<GV, float>::value ? "msda backward (owner-computes scatter kernel, group-granular, items in image order)"
+                                                           : "msda backward (owner-computes scatter kernel, group-granular, items in image order, grad_value in the storage type)");
     return check_launch(std::is_same<GV, float>::value ? "msda backward (owner-computes scatter kernel, group-granular)"
                                                        : "msda backward (owner-computes scatter kernel, group-granular, grad_value in the storage type)");
 }

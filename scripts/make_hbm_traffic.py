@@ -1,5 +1,7 @@
 """profiles/hbm_traffic.json from the HBM PMC summary of a profiling round (scripts/profile_round.sh):
-    python scripts/make_hbm_traffic.py profiles/r03_x_pmc_hbm_traffic.txt
+    python scripts/make_hbm_traffic.py profiles/r03_x_pmc_hbm_traffic.txt [path to record as the source]
+(the second argument: on the GPU box the summary still sits in the scratch directory gpurun_out/; the file records the
+tracked name it is committed under by scripts/collect_round.sh, so that `roofline.traffic_source` resolves in the repository)
 FETCH_SIZE / WRITE_SIZE are in KB per launch (separate rocprofv3 --pmc passes over scripts/step_only.py, the default
 bench.py workload).  The file records the content hash of the kernel sources it was measured on; bench.py quotes it as
 `roofline.traffic` only while that hash is the hash of the build it runs."""
@@ -24,7 +26,7 @@ out = {
                 "f32, uniform locations, fused pattern. FETCH_SIZE is reported raw (= TCC_EA0_RDREQ x 64 B; MI355X_MICROARCH.md: wide "
                 "streaming reads are 128-byte requests tallied at 64, so the true read volume lies between 1x and 2x this figure). "
                 "WRITE_SIZE calibrates exactly on the known output sizes.",
-    "source": os.path.relpath(os.path.abspath(src), ROOT),
+    "source": sys.argv[2] if len(sys.argv) > 2 else os.path.relpath(os.path.abspath(src), ROOT),
     "source_hash": build._source_hash(),
     "workload": {"clips": 16, "frames": 6, "queries": 300, "pyramid": "A", "dtype": "f32", "locs": "uniform", "pattern": "fused"},
     "kernels": {k: {"fetch_bytes": v.get("FETCH_SIZE", 0), "write_bytes": v.get("WRITE_SIZE", 0)} for k, v in vals.items() if "zero" not in k},

@@ -1,7 +1,9 @@
 #!/bin/bash
 # One profiling round on the GPU box: bench line, rocprofv3 kernel-trace stats of the same command, and the HBM-traffic
 # PMC passes (FETCH_SIZE / WRITE_SIZE / L2 hit-miss, separate passes, never combined with a trace).
-# usage: scripts/profile_round.sh <tag>     -> gpurun_out/<tag>/{bench.json,kernel_stats.csv,pmc_hbm.txt}
+# usage: scripts/profile_round.sh <tag> [previous bench.json]    -> gpurun_out/<tag>/{bench.json,kernel_stats.csv,pmc_hbm.txt,compare.txt}
+# Ends with scripts/compare_bench.py against the previous file (default: the newest profiles/r*_bench.json): every kernel and
+# every other_configs time, exit status 1 when one grew by more than 5 %.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$1
@@ -20,5 +22,12 @@ for grp in hbm sq mem; do
   rm -rf "$O/pmc"
 done
 # profiles/hbm_traffic.json for this very build (bench.py quotes it only while the kernel sources are unchanged)
-python3 scripts/make_hbm_traffic.py "$O/pmc_hbm.txt" > /dev/null && cp profiles/hbm_traffic.json "$O/hbm_traffic.json"
+python3 scripts/make_hbm_traffic.py "$O/pmc_hbm.txt" "profiles/$1_pmc_hbm_traffic.txt" > /dev/null && cp profiles/hbm_traffic.json "$O/hbm_traffic.json"
 tail -c 400 "$O/bench.json"; echo; head -12 "$O/kernel_stats.csv"; cat "$O/pmc_hbm.txt"
+prev=${2:-$(ls -t profiles/r*_bench.json 2>/dev/null | head -1)}
+if [ -n "$prev" ] && [ -f "$prev" ]; then
+  echo "---- against $prev"
+  python3 scripts/compare_bench.py "$prev" "$O/bench.json" > "$O/compare.txt"; rc=$?
+  grep -E "SLOWER|grew|no time grew" "$O/compare.txt"
+  exit $rc
+fi

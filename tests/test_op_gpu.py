@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from conftest import OP_FIXTURES, golden
-from helpers import (PYR_A, make_inputs, make_temporal_inputs, oracle_fwd_bwd, round_to,
+from helpers import (PYR_A, localise, make_inputs, make_temporal_inputs, oracle_fwd_bwd, round_to,
                      temporal_reference)
 
 pytestmark = pytest.mark.gpu
@@ -29,6 +29,21 @@ def _run_op(d, dtype, step=64):
     gv, gl, ga = torch.autograd.grad(out, (v, l, a), go)
     torch.cuda.synchronize()
     return [t.detach().double().cpu().numpy() for t in (out, gv, gl, ga)]
+
+
+def _direct_temporal_backward_route(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, grad_out, clips):
+    """msda_last_route() of the backward of a fused temporal call (the route string is per thread, and autograd runs the
+    backward on a thread of its own: the call is repeated here, on this thread, with buffers as the autograd function
+    allocates them)."""
+    from devis_amd import _native
+    t = [x.detach() for x in (value, loc_c, aw_c, loc_t, aw_t)]
+    L, P, W = loc_c.shape[3], loc_c.shape[4], ftab.shape[1]
+    gv = torch.empty(value.shape, device=value.device,
+                     dtype=_native.grad_value_dtype(t[0], shapes, loc_c.shape[1], L, P, clips=clips, window=W, Pt=loc_t.shape[4]))
+    grads = [torch.empty_like(x) for x in t[1:]]
+    _native.temporal_backward(t[0], shapes, lsi, ftab, t[1], t[2], t[3], t[4], grad_out, clips, gv, *grads)
+    torch.cuda.synchronize()
+    return _native.last_route()
 
 
 def _golden_dict(name):
@@ -352,7 +367,8 @@ def test_full_size_temporal_encoder_800x1333():
     """Largest realistic call: fused temporal ENCODER attention on the 800x1333 pyramid, T=6, Lq = S = 22223
     per frame (133 338 rows, 96 taps each), local sampling.  Forward / grad_loc / grad_attn are row-local and
     are compared with the oracle (reference call pattern) on sampled rows; grad_value through adjointness
-    and a direct oracle comparison of one frame's gradient restricted to the sampled rows' contribution."""
+    AND directly: the oracle's grad_value of ONE head (all frames, all 133 k rows; the heads are independent), on the
+    scatter's image-order item schedule."""
     from devis_amd.functions import MSDeformAttnTemporalFunction
     from helpers import PYR_B
     from oracle import msda_oracle as O
@@ -395,6 +411,55 @@ def test_full_size_temporal_encoder_800x1333():
     lhs = (out.detach().double() * go.to(DEV).double()).sum().item()
     rhs = (v.detach().double() * gv.double()).sum().item()
     assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+    # grad_value of head 5 against the oracle run on that head alone (value / points / grad_out channels of the head)
+    assert "items in image order" in _direct_temporal_backward_route(v, shapes, torch.from_numpy(lsi_np).to(DEV), torch.from_numpy(ftab_np).to(DEV),
+                                                                     lc, ac, lt, at, go.to(DEV), 1)
+    h = 5
+    one = lambda x: np.ascontiguousarray(x[:, :, h:h + 1].double().numpy())
+    rh = temporal_reference(one(value), shapes_np, lsi_np, ftab_np, one(loc_c), one(aw_c), one(loc_t), one(aw_t),
+                            np.ascontiguousarray(go[:, :, h * D:(h + 1) * D].double().numpy()))
+    err = _maxabs(gv[:, :, h].double().cpu().numpy(), rh[1][:, :, 0])
+    assert err <= 2e-5 * max(1.0, np.abs(rh[1]).max()), err
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3), (torch.float32, 2e-5)], ids=["bf16", "f16", "f32"])
+def test_image_order_scatter_on_a_batch_of_clips(dtype, tol):
+    """The scatter's image-order item schedule (long temporal calls: Lq >= 8192, frames > 1) on a BATCH of 4 clips in the
+    16-bit storage types (grad_value written in the storage type) and in fp32: grad_value, outputs and the other gradients
+    directly against the oracle, clip by clip."""
+    from devis_amd.functions import MSDeformAttnTemporalFunction
+    shapes = [(66, 96), (33, 48), (17, 24), (9, 12)]          # S = 8436 >= 8192
+    S = int(sum(hh * ww for hh, ww in shapes))
+    clips, T, M = 4, 2, 2
+    keys = ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")
+    ds, refs = [], []
+    for c in range(clips):
+        d = make_temporal_inputs(100 + c, T=T, W=T - 1, M=M, D=32, Lq=S, shapes=shapes, Pc=4, Pt=4)
+        if c % 2 == 0:      # encoder-like locality for half of the clips, range-wide sampling for the others
+            d["loc_c"] = localise(d["loc_c"], shapes, 2.0, 1 + c)
+            d["loc_t"] = localise(d["loc_t"], shapes, 2.0, 50 + c)
+        d = round_to({k: (np.asarray(v, dtype=np.float64) if v.dtype.kind == "f" else v) for k, v in d.items()}, dtype)
+        ds.append(d)
+        refs.append(temporal_reference(*(d[k] for k in keys)))
+    cat = lambda k: torch.from_numpy(np.concatenate([d[k] for d in ds], 0)).to(DEV, dtype).requires_grad_(True)
+    leaves = [cat(k) for k in ("value", "loc_c", "aw_c", "loc_t", "aw_t")]
+    d0 = ds[0]
+    out = MSDeformAttnTemporalFunction.apply(leaves[0], torch.from_numpy(d0["shapes"]).to(DEV), torch.from_numpy(d0["lsi"]).to(DEV),
+                                             torch.from_numpy(d0["ftab"]).to(DEV), *leaves[1:], clips)
+    grads = torch.autograd.grad(out, leaves, cat("grad_out").detach())
+    route = _direct_temporal_backward_route(leaves[0], torch.from_numpy(d0["shapes"]).to(DEV), torch.from_numpy(d0["lsi"]).to(DEV),
+                                            torch.from_numpy(d0["ftab"]).to(DEV), *leaves[1:], cat("grad_out").detach(), clips)
+    assert "items in image order" in route and ("storage type" in route) == (dtype != torch.float32), route
+    scale = lambda x: max(1.0, float(np.abs(x).max()))
+    for c in range(clips):
+        sl = slice(c * T, (c + 1) * T)
+        assert _maxabs(out.detach()[sl].double().cpu().numpy(), refs[c][0]) <= tol * scale(refs[c][0]), c
+        # grad_value DIRECTLY (not through adjointness), then grad_attn of both point sets
+        err = _maxabs(grads[0][sl].double().cpu().numpy(), refs[c][1])
+        assert err <= 2 * tol * scale(refs[c][1]), (c, err)
+        for i in (2, 4):
+            err = _maxabs(grads[i][sl].double().cpu().numpy(), refs[c][1 + i])
+            assert err <= 3 * tol * scale(refs[c][1 + i]), (c, i, err)
 
 
 def test_forward_resident_slab_kernel_forced(monkeypatch):
