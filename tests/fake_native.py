@@ -12,10 +12,18 @@ def _np(t):
     return t.detach().double().cpu().numpy()
 
 
-def install(monkeypatch):
-    """Patch devis_amd so CPU tensors are accepted and routed to the oracle."""
-    from devis_amd import _native
-    from devis_amd.functions import ms_deform_attn_func as F
+def install(monkeypatch, native=None, functions=None):
+    """Patch devis_amd so CPU tensors are accepted and routed to the oracle.  `native` / `functions`: the `_native` and
+    `functions.ms_deform_attn_func` module objects to patch when the package was imported under another name (as
+    `src.models.ops`: tests/test_reference_stack_cpu.py)."""
+    if native is None:
+        from devis_amd import _native
+    else:
+        _native = native
+    if functions is None:
+        from devis_amd.functions import ms_deform_attn_func as F
+    else:
+        F = functions
 
     def _check_inputs(named):
         for name, t in named:
