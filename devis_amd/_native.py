@@ -118,13 +118,20 @@ def acc_dtype(dtype):
 _CODE_DTYPE = {v: k for k, v in _DTYPE_CODE.items()}
 
 
-def grad_value_dtype(value, shapes, Lq, L, Pc, clips=None, window=0, Pt=1):
+def grad_value_dtype(value, shapes, Lq, L, Pc, clips=None, window=0, Pt=1, grad_out=None):
     """torch dtype the grad_value buffer of a backward call on ``value [G, S, M, D]`` should have (include/msda.h
     msda_grad_value_dtype): the 16-bit storage type itself when the owner-computes scatter will write it -- no fp32
-    buffer and no conversion pass -- else the arithmetic type."""
+    buffer and no conversion pass -- else the arithmetic type.  The library answers from the shapes; what it can only see
+    at the call -- 16-byte alignment of ``value`` / ``grad_out`` (a contiguous view at an odd storage offset) and value
+    strides that are multiples of 8 elements -- is checked here, so that such a call takes the arithmetic type (and the
+    generic kernels) instead of being refused."""
     G, S, M, D = value.shape
     clips = G if clips is None else clips
     if value.dtype not in (torch.bfloat16, torch.float16) or G == 0 or clips == 0:
+        return acc_dtype(value.dtype)
+    if value.data_ptr() % 16 or (grad_out is not None and grad_out.data_ptr() % 16):
+        return acc_dtype(value.dtype)
+    if not value.is_contiguous() and any(st % 8 for st in (value.stride(0), value.stride(1), value.stride(2))):
         return acc_dtype(value.dtype)
     code = load().msda_grad_value_dtype(dtype_code(value.dtype), clips, G // clips, window, S, M, D, L, Lq, Pc, Pt,
                                         shapes_hint(shapes))

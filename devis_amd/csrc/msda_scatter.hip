@@ -507,6 +507,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
     __shared__ unsigned s_live[kLiveWords];            // bitmap of the cull batches that hold a live 64-query block
     __shared__ int s_ftab[kWave];                      // the frame table (<= 64 slots: scatter_applicable), read once
     __shared__ unsigned short s_order[SORTED ? kOwnMaxSorted : 1];  // bands of all levels sorted by where they start in the image (see below)
+    __shared__ float s_key[SORTED ? kOwnMaxSorted : 1];
 
     const int tid = threadIdx.x, lane = tid % kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -526,36 +527,36 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         }
         s_first[L] = first;
         s_cnt[0] = s_cnt[1] = s_cnt[2] = 0;
-        // Long candidate ranges (encoder shapes): the dynamic schedule deals the bands of ALL levels in the order of their
-        // position in the image, frames innermost, so that the items an XCD runs at one time read the grad_out rows and the
-        // points of the SAME queries (those near that part of the image) from its L2 -- with the bands of one level and frame
-        // after another every item fetched them from memory again: FETCH_SIZE 4.5 GB for 1.6 GB of inputs on the 800x1333
-        // encoder call (profiles/r03_logs/pmc_enc_hbm.txt).  Insertion sort of <= kOwnMaxSorted (level, band) pairs by
-        // start row / level height.
-        if constexpr (SORTED) {                     // (host: at most kOwnMaxSorted bands)
-            int n = 0;
-            for (int l = 0; l < L; ++l)
-                for (int b = s_first[l]; b < s_first[l + 1]; ++b) {
-                    const float key = s_R[l] > 0 ? (float)((b - s_first[l]) * s_R[l]) / (float)s_H[l] : 0.f;
-                    int j = n++;
-                    while (j > 0) {
-                        const int o = s_order[j - 1];
-                        int lo = 0;
-                        while (lo + 1 < L && s_first[lo + 1] <= o) ++lo;
-                        const float ko = s_R[lo] > 0 ? (float)((o - s_first[lo]) * s_R[lo]) / (float)s_H[lo] : 0.f;
-                        if (ko <= key) break;
-                        s_order[j] = (unsigned short)o;
-                        --j;
-                    }
-                    s_order[j] = (unsigned short)b;
-                }
-        }
     }
     if (tid < kWave) s_ftab[tid] = tid < p.frames * p.window ? p.ftab[tid] : -1;
     int ci = 0;                             // counter of the current cull batch
     for (int i = tid; i < kOwnPix; i += kOwnThreads) head[i] = kOwnNil;
     __syncthreads();
     const int NB = s_first[L];
+    // Long candidate ranges (encoder shapes): the dynamic schedule deals the bands of ALL levels in the order of their
+    // position in the image, frames innermost, so that the items an XCD runs at one time read the grad_out rows and the
+    // points of the SAME queries (those near that part of the image) from its L2 -- with the bands of one level and frame
+    // after another every item fetched them from memory again: FETCH_SIZE 4.5 GB for 1.6 GB of inputs on the 800x1333
+    // encoder call (profiles/r03_logs/pmc_enc_hbm.txt).  Band b's key = start row / level height, its place = the number of
+    // bands with a smaller (key, index): one thread per band, keys computed once (round 3: an insertion sort on one lane).
+    const bool image_order = SORTED && NB <= kOwnMaxSorted;      // (the host counts the bands the same way; never trusted)
+    if constexpr (SORTED) {
+        if (image_order) {
+            if (tid < NB) {
+                int l = 0;
+                while (l + 1 < L && s_first[l + 1] <= tid) ++l;
+                s_key[tid] = s_R[l] > 0 ? (float)((tid - s_first[l]) * s_R[l]) / (float)s_H[l] : 0.f;
+            }
+            __syncthreads();
+            if (tid < NB) {
+                const float key = s_key[tid];
+                int place = 0;
+                for (int o = 0; o < NB; ++o) place += (s_key[o] < key || (s_key[o] == key && o < tid)) ? 1 : 0;
+                s_order[place] = (unsigned short)tid;
+            }
+            __syncthreads();
+        }
+    }
     const int clips = p.groups / p.frames;
     const unsigned n_items = (unsigned)clips * (unsigned)p.frames * (unsigned)p.M * (unsigned)NB;      // (< 2^31: host)
     const bool dynamic = p.workspace != nullptr && (dbg & 16) == 0 && n_items < 16u * gridDim.x;
@@ -584,7 +585,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         int l = 0, part = 0, m = 0, f = 0, clip = 0;
         if (valid) {
             const unsigned M = (unsigned)p.M, F = (unsigned)p.frames;
-            if (SORTED && dynamic) {      // bands by position in the image, frames innermost (see s_order)
+            if (image_order && dynamic) {      // bands by position in the image, frames innermost (see s_order)
                 m = (int)(item % M);
                 unsigned rest = item / M;
                 f = (int)(rest % F); rest /= F;
@@ -1140,6 +1141,7 @@ int launch_scatter_grp(int dtype, bool storage_typed, const Params &p, unsigned 
         int bands = 0;
         for (int l = 0; sorted && l < p.L; ++l) {
             const long long H = p.shapes_host[2 * l], W = p.shapes_host[2 * l + 1];
+            if (H <= 0 || W <= 0) { sorted = false; break; }         // (degenerate level: the device counts its bands differently)
             const long long R = W > 0 ? std::min<long long>(H, kOwnPix / W) : 0;
             bands += R > 0 ? (int)((H + R - 1) / R) : 1;
         }

@@ -101,7 +101,7 @@ class MSDeformAttnFunction(Function):
         # storage: grad_value comes back in the storage type where the library can write it so (ABI v10), else in fp32
         live = N > 0 and loc.shape[1] > 0
         step = _im2col_step(N, ctx.im2col_step) if live else 0
-        acc = _native.grad_value_dtype(value[:step], shapes, loc.shape[1], loc.shape[3], loc.shape[4]) if live else value.dtype
+        acc = _native.grad_value_dtype(value[:step], shapes, loc.shape[1], loc.shape[3], loc.shape[4], grad_out=grad_output) if live else value.dtype
         grad_value = (torch.empty if live else torch.zeros)(value.shape, dtype=acc, device=value.device)
         grad_loc = torch.empty_like(loc)
         grad_aw = torch.empty_like(aw)
@@ -170,7 +170,7 @@ class MSDeformAttnTemporalFunction(Function):
         grad_output = grad_output.contiguous()
         W = ftab.shape[1]
         acc = _native.grad_value_dtype(value, shapes, loc_c.shape[1], loc_c.shape[3], loc_c.shape[4], clips=ctx.clips,
-                                       window=W, Pt=loc_t.shape[4])
+                                       window=W, Pt=loc_t.shape[4], grad_out=grad_output)
         grad_value = torch.empty(value.shape, dtype=acc, device=value.device)      # overwritten (ABI v4)
         gloc_c, gaw_c = torch.empty_like(loc_c), torch.empty_like(aw_c)
         gloc_t, gaw_t = torch.empty_like(loc_t), torch.empty_like(aw_t)

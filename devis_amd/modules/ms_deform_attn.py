@@ -57,10 +57,16 @@ def _fused_linear_params(module, linears):
     """Weight / bias of several Linears on the same input as ONE [sum(out), in] matrix (a single GEMM forward, one dgrad
     and one wgrad GEMM backward).  While autograd is recording (training) the concatenation is part of the graph, so the
     gradients flow back to the individual parameters; without grad (inference: the call DeVIS's tracker times,
-    tracker.py:320-323) the concatenated tensors are cached on the module and rebuilt only when a parameter changed
-    (``_version``) or moved (``data_ptr`` / dtype)."""
+    tracker.py:320-323) the concatenated tensors are cached on the module and rebuilt when a parameter changed
+    (``_version``) or moved (``data_ptr`` / dtype).  Writes through ``.data`` do not bump ``_version`` (the reference's own
+    ``_reset_parameters`` initialises that way, EMA code updates that way): the cache is therefore also dropped by
+    ``train()``, ``_apply()`` (``.to`` / ``.half`` / ``.cuda``), ``load_state_dict`` and ``_reset_parameters`` (``_FusedParamsCache``),
+    and code that writes ``p.data`` of a live model calls ``module.invalidate_fused_params()``.  Under
+    ``torch.inference_mode()`` nothing is cached (inference tensors could not be saved for a later backward)."""
     params = [q for lin in linears for q in (lin.weight, lin.bias)]
     if torch.is_grad_enabled() and any(q.requires_grad for q in params):
+        return torch.cat([l.weight for l in linears]), torch.cat([l.bias for l in linears])
+    if torch.is_inference_mode_enabled():
         return torch.cat([l.weight for l in linears]), torch.cat([l.bias for l in linears])
     key = tuple((q.data_ptr(), q._version, q.dtype) for q in params)
     cached = module.__dict__.get("_fused_params")
@@ -69,6 +75,26 @@ def _fused_linear_params(module, linears):
             cached = (key, torch.cat([l.weight for l in linears]), torch.cat([l.bias for l in linears]))
         module.__dict__["_fused_params"] = cached
     return cached[1], cached[2]
+
+
+class _FusedParamsCache:
+    """Mixin: drops the cached concatenation of ``_fused_linear_params`` wherever parameters are rewritten without a
+    ``_version`` bump or replaced."""
+
+    def invalidate_fused_params(self):
+        self.__dict__.pop("_fused_params", None)
+
+    def train(self, mode=True):
+        self.invalidate_fused_params()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_fused_params()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_fused_params()
+        return super()._load_from_state_dict(*args, **kwargs)
 
 
 def _normalizer(spatial_shapes):
@@ -88,7 +114,7 @@ def _locations(reference, offsets, normalizer, n_points):
         reference.shape[-1]))
 
 
-class MSDeformAttn(nn.Module):
+class MSDeformAttn(_FusedParamsCache, nn.Module):
     value_pad_heads = 1     # spare head slots per pixel row of `value` (0 = the reference's dense layout)
     fused_prep = True       # softmax + sampling-location arithmetic in one fused pass (False: torch ops)
     sampling_fp32 = True    # 16-bit modules: the fused pass hands sampling locations / weights to the operator in float32
@@ -125,6 +151,7 @@ class MSDeformAttn(nn.Module):
         constant_(self.value_proj.bias.data, 0.)
         xavier_uniform_(self.output_proj.weight.data)
         constant_(self.output_proj.bias.data, 0.)
+        self.invalidate_fused_params()
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
                 input_level_start_index, input_padding_mask):
@@ -168,7 +195,7 @@ class MSDeformAttn(nn.Module):
         return self.output_proj(output), None
 
 
-class TemporalMSDeformAttnBase(nn.Module):
+class TemporalMSDeformAttnBase(_FusedParamsCache, nn.Module):
     """Shared part of the temporal modules (ref ``:137-285``)."""
 
     fused = True   # False: replay the reference's 2*T-call pattern (same results)
@@ -217,6 +244,7 @@ class TemporalMSDeformAttnBase(nn.Module):
         for lin in (self.value_proj, self.output_proj):
             xavier_uniform_(lin.weight.data)
             constant_(lin.bias.data, 0.)
+        self.invalidate_fused_params()
 
     def _compute_deformable_attention(self, query, input_flatten):
         """value [T,S,M,D]; current offsets [T,Lq,M,L,Pc,2]; temporal offsets [T,Lq,M,W*L,Pt,2]
@@ -272,6 +300,25 @@ class TemporalMSDeformAttnBase(nn.Module):
         return 0 if 1 + n_frames * self.t_window > 63 else self.value_pad_heads
 
     _table_cache = None     # (offset tensors, n_frames, device, table): shared by all layers of a transformer
+    _pending_range_checks = []      # (pinned verdict, event, n_frames) of device-side offset checks not yet read
+
+    @staticmethod
+    def _raise_on_bad_offsets(wait=False):
+        """Deferred range checks of device-side temporal offsets (see _frame_table): raises IndexError for the first one
+        whose verdict has arrived (``wait``: synchronise on the outstanding ones first -- tests, debugging)."""
+        pending = TemporalMSDeformAttnBase._pending_range_checks
+        keep, bad = [], None
+        for host, done, n_frames in pending:
+            if wait:
+                done.synchronize()
+            if not done.query():
+                keep.append((host, done, n_frames))
+            elif not bool(host) and bad is None:
+                bad = n_frames
+        TemporalMSDeformAttnBase._pending_range_checks = keep
+        if bad is not None:
+            TemporalMSDeformAttnBase._table_cache = None
+            raise IndexError("temporal_offsets point outside the clip's %d frames" % bad)
 
     @staticmethod
     def _frame_table(temporal_offsets, n_frames, device):
@@ -283,8 +330,10 @@ class TemporalMSDeformAttnBase(nn.Module):
 
         The reference indexes value[temporal_offsets[t] + t] with torch semantics: a negative index wraps once,
         anything else out of range trips the indexing kernel's device-side assert.  The kernels take absolute frame ids
-        in [0, T), so the table is normalised here and the range check is the same kind of asynchronous device-side
-        assert (``torch._assert_async``; on CPU tensors it raises at once)."""
+        in [0, T), so the table is normalised here; the range check raises IndexError at once for CPU offsets and, for
+        device offsets, at the first call made after its verdict has reached the host (no synchronisation; at the latest
+        the next forward of the stack -- ``_raise_on_bad_offsets``)."""
+        TemporalMSDeformAttnBase._raise_on_bad_offsets()
         cached = TemporalMSDeformAttnBase._table_cache
         if cached is not None and cached[1] == n_frames and cached[2] == device and \
                 len(cached[0]) == len(temporal_offsets) and \
@@ -293,10 +342,19 @@ class TemporalMSDeformAttnBase(nn.Module):
         table = torch.stack([o.to(device) for o in temporal_offsets]) \
             + torch.arange(n_frames, device=device)[:, None]
         in_range = ((table >= -n_frames) & (table < n_frames)).all()
-        if in_range.is_cuda:
-            torch._assert_async(in_range)
-        elif not bool(in_range):
-            raise IndexError("temporal_offsets point outside the clip's %d frames" % n_frames)
+        if not in_range.is_cuda:
+            if not bool(in_range):
+                raise IndexError("temporal_offsets point outside the clip's %d frames" % n_frames)
+        elif not torch.cuda.is_current_stream_capturing():
+            # no synchronisation here: the verdict travels to pinned memory behind the work already queued and is read by a
+            # LATER call (_raise_on_bad_offsets) -- the table below is wrapped into range either way, so a bad offset reads
+            # a wrong frame but never memory outside the clip.  (torch._assert_async would abort the process on this
+            # ROCm build: no message, nothing to catch.)
+            host = torch.empty((), dtype=torch.bool, pin_memory=True)
+            host.copy_(in_range, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            TemporalMSDeformAttnBase._pending_range_checks.append((host, done, n_frames))
         table = torch.remainder(table, n_frames).to(torch.int32).contiguous()
         TemporalMSDeformAttnBase._table_cache = ([(o, o._version) for o in temporal_offsets], n_frames, device, table)
         return table

@@ -228,9 +228,8 @@ def test_fused_prep_takes_reference_points_of_another_dtype():
 
 def test_frame_table_wraps_negative_offsets_on_the_device():
     """temporal_offsets[t] + t indexes `value` with Python semantics in the reference (ms_deform_attn.py:339,445):
-    a negative index wraps once.  (Out-of-range offsets: tests/test_host_cpu.py -- on device tensors they trip an
-    asynchronous device-side assert, like the reference's indexing, which a test process cannot survive.)  The table is
-    built without a host synchronisation."""
+    a negative index wraps once.  The table is built without a host synchronisation (out-of-range offsets: the next
+    test)."""
     from devis_amd.modules.ms_deform_attn import TemporalMSDeformAttnBase
     T = 4
     offs = [torch.tensor([-1, 1], device=DEV) for _ in range(T)]
@@ -238,6 +237,23 @@ def test_frame_table_wraps_negative_offsets_on_the_device():
     offs[T - 1] = torch.tensor([-1, -2], device=DEV)
     table = TemporalMSDeformAttnBase._frame_table(offs, T, torch.device(DEV)).cpu().tolist()
     assert table[0] == [T - 1, 1] and table[T - 1] == [T - 2, T - 3]
+
+
+def test_frame_table_rejects_out_of_range_offsets_on_the_device_without_a_sync():
+    """Device-side offsets outside the clip (the reference's indexing kernel trips a device-side assert there): the
+    table is still built without waiting -- wrapped into range, so nothing outside the clip is ever read -- and the
+    IndexError surfaces at the first later call that finds the verdict on the host; the process survives."""
+    from devis_amd.modules.ms_deform_attn import TemporalMSDeformAttnBase as B
+    T = 3
+    B._raise_on_bad_offsets(wait=True)                  # (nothing pending from other tests)
+    bad = [torch.tensor([1, 7], device=DEV) for _ in range(T)]
+    table = B._frame_table(bad, T, torch.device(DEV))
+    assert int(table.min()) >= 0 and int(table.max()) < T
+    with pytest.raises(IndexError, match="outside the clip"):
+        B._raise_on_bad_offsets(wait=True)
+    good = [torch.tensor([o for o in range(-f, T - f) if o != 0], device=DEV) for f in range(T)]       # connect-all (devis_transformer.py:103-105)
+    assert B._frame_table(good, T, torch.device(DEV)).shape == (T, 2)      # the module keeps working
+    B._raise_on_bad_offsets(wait=True)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 1e-4)], ids=["f64", "f32"])
