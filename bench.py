@@ -68,6 +68,9 @@ def parse_args():
                     help="clip-parallel: independent clips per GPU, no collective (default, weak scaling); "
                          "sharded: every clip is split over ALL ranks (devis_amd/clip_parallel.py: RCCL all-gather "
                          "of value forward, reduce-scatter of grad_value backward; strong scaling)")
+    ap.add_argument("--transport", choices=["storage", "bf16", "f16"], default="storage",
+                    help="--mode sharded: dtype in which `value` crosses the all-gather and its gradient the reduce-scatter "
+                         "(storage = the model's own; bf16 / f16 with an f32 model: half the xGMI bytes, clip_parallel.py)")
     ap.add_argument("--pattern", choices=["fused", "reference"], default="fused",
                     help="fused: one launch per direction; reference: the 2*T calls per layer of the reference")
     ap.add_argument("--value-layout", choices=["dense", "padded"], default="dense",
@@ -510,11 +513,17 @@ def main():
                               lc=cut("loc_c"), ac=cut("aw_c"), lt=cut("loc_t"), at=cut("aw_t"),
                               go=b["grad_out"][c * T:(c + 1) * T, q0:q1].contiguous()))
 
+        transport = {"storage": None, "bf16": torch.bfloat16, "f16": torch.float16}[args.transport]
+        sh_leaves = [x for sh in shard for x in (sh["v"], sh["lc"], sh["ac"], sh["lt"], sh["at"])]
+        sh_go = [sh["go"] for sh in shard]
+
         def step():  # noqa: F811
-            for sh in shard:
-                out = cp.sharded_temporal_attention(sh["v"], T, S, b["shapes"], b["lsi"], b["ftab"], sh["lc"],
-                                                    sh["ac"], sh["lt"], sh["at"])
-                torch.autograd.grad(out, (sh["v"], sh["lc"], sh["ac"], sh["lt"], sh["at"]), sh["go"])
+            # every clip's all-gather is issued before the first kernel (the collectives of the later clips travel while the
+            # kernels of the earlier ones run), one backward over all clips (their reduce-scatters follow each other on the
+            # communication stream while the next clip's kernels run)
+            outs = cp.sharded_temporal_attention_batch([(sh["v"], sh["lc"], sh["ac"], sh["lt"], sh["at"]) for sh in shard],
+                                                       T, S, b["shapes"], b["lsi"], b["ftab"], transport_dtype=transport)
+            torch.autograd.grad(outs, sh_leaves, sh_go)
 
     def barrier():
         if world > 1:
@@ -556,7 +565,7 @@ def main():
         buf = torch.zeros((dense_value.shape[0], S, M + 1, D), dtype=dtype, device=device)
         buf[:, :, :M] = dense_value.detach()
         padded_value = buf[:, :, :M].requires_grad_(True)
-        block = max(2, args.steps // 8)
+        block = max(8, args.steps // 8)          # (>= 8 steps per block whatever --steps: 2-step blocks measured noise)
 
         def timed_block(v):
             b["value"] = v
@@ -732,7 +741,8 @@ def main():
                                       " in float32" if (args.sampling == "fp32" and args.dtype != "f32") else "", args.value_layout),
                        "clips_per_gpu": args.clips, "query_rows_per_step": rows_per_step,
                        "parallelism": ("clip-parallel x%d (no data-path collective)" % world) if args.mode == "clip-parallel"
-                       else "one clip sharded x%d (all-gather value / reduce-scatter grad_value over RCCL)" % world},
+                       else "one clip sharded x%d (all-gather value / reduce-scatter grad_value over RCCL, all gathers of a step in "
+                            "flight before its first kernel, %s transport)" % (world, args.transport)},
             "roofline": roofline, "cpu_baseline": cpu, "ranks_seen": ranks_seen,
             "prewarm_seconds": args.prewarm_seconds,
         }

@@ -160,3 +160,31 @@ def sharded_temporal_attention(value_chunk, n_frames, spatial_size, spatial_shap
                                              loc_temp.contiguous(), aw_temp.contiguous(), 1)
     return out if out_dtype is None else out.to(out_dtype)
 
+
+
+def sharded_temporal_attention_batch(clips, n_frames, spatial_size, spatial_shapes, level_start_index, frame_table,
+                                     group=None, transport_dtype=None):
+    """Mode 2 for SEVERAL clips at once (a training step's batch, bench.py --mode sharded): every clip's all-gather is
+    issued before the first kernel, so the collectives of clips 1.. travel over xGMI while the kernels of the clips
+    before them run -- xGMI is point-to-point and a ring all-gather of one clip's ``value`` is bound by one link, so
+    the next clip's shards are the cheapest thing to overlap it with.  ``clips``: a list of
+    ``(value_chunk, loc_curr, aw_curr, loc_temp, aw_temp)`` as :func:`sharded_temporal_attention` takes them.
+    Returns the list of this rank's output rows, one ``[T, Lq_local, M*D]`` per clip; backward runs one reduce-scatter
+    per clip (autograd orders them)."""
+    pending, out_dtypes = [], []
+    for value_chunk, *_ in clips:
+        out_dtype = None
+        if transport_dtype is not None and value_chunk.dtype != transport_dtype:
+            if value_chunk.dtype != torch.float32 or transport_dtype not in (torch.bfloat16, torch.float16):
+                raise ValueError("transport_dtype: bfloat16 / float16 for a float32 value")
+            out_dtype = value_chunk.dtype
+            value_chunk = value_chunk.to(transport_dtype)
+        out_dtypes.append(out_dtype)
+        pending.append(start_gather_value(value_chunk, n_frames, spatial_size, group))
+    outs = []
+    for (_, loc_curr, aw_curr, loc_temp, aw_temp), gathered, out_dtype in zip(clips, pending, out_dtypes):
+        out = MSDeformAttnTemporalFunction.apply(gathered.wait().contiguous(), spatial_shapes, level_start_index, frame_table,
+                                                 loc_curr.contiguous(), aw_curr.contiguous(), loc_temp.contiguous(),
+                                                 aw_temp.contiguous(), 1)
+        outs.append(out if out_dtype is None else out.to(out_dtype))
+    return outs

@@ -39,7 +39,7 @@ def main():
     case = sys.argv[2] if len(sys.argv) > 2 else "small"
     if case == "cfg3":      # BASELINE configs[3]: the T = 6 decoder clip (frames do not divide 8 ranks), connect-all window
         from helpers import PYR_A
-        T, W, M, D, Lq = 6, 5, 8, 32, 75
+        T, W, M, D, Lq = 6, 5, 8, 32, 300          # 300 queries per frame: the decoder clip at its full size
         d = make_temporal_inputs(9, T, W, M, D, Lq, PYR_A, 4, 4, dtype=np.float64)
     else:
         T, W, M, D, Lq = 3, 2, 4, 8, 11
@@ -101,6 +101,15 @@ def main():
     near(g3[0], gvb[rank * chunk:(rank + 1) * chunk], 3e-2, "transport grad_value chunk")    # bf16 partial sums over the ranks
     near(g3[2], ref_b[3][:, q0:q1], 1e-2, "transport grad_aw_c")
     near(g3[4], ref_b[5][:, q0:q1], 1e-2, "transport grad_aw_t")
+    # a batch of clips with every all-gather issued up front (clip 1 = clip 0 with other weights): per clip the results of the
+    # one-clip calls
+    ac2 = (ac.detach() * 0.5).requires_grad_(True)
+    outs = cp.sharded_temporal_attention_batch([(v_chunk, lc, ac, lt, at), (v_chunk, lc, ac2, lt, at)], T, S, shapes, lsi, ftab)
+    assert same(outs[0], out)
+    close(outs[1] - 0.0, ref[0][:, q0:q1] - temporal_reference(d["value"], d["shapes"], d["lsi"], d["ftab"], d["loc_c"], 0.5 * d["aw_c"],
+                                                              d["loc_t"], 0.0 * d["aw_t"])[:, q0:q1], "batch clip 1")
+    gb = torch.autograd.grad(outs, (v_chunk, lc, ac, lt, at), [go, 0.0 * go])
+    assert all(same(a, b) for a, b in zip(gb, (gv, glc, gac, glt, gat))), "batched form differs"
     # the ranges tile the query axis
     r = [cp.shard_range(Lq, world, k) for k in range(world)]
     assert r[0][0] == 0 and r[-1][1] == Lq and all(r[i][1] == r[i + 1][0] for i in range(world - 1))
