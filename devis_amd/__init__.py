@@ -8,7 +8,7 @@ same Python surface::
     from devis_amd.modules import MSDeformAttn, TemporalMSDeformAttnEncoder, TemporalMSDeformAttnDecoder
 
 Arithmetic lives in hand-written HIP kernels behind the C ABI of ``include/msda.h``
-(``devis_amd/csrc/msda_hip.hip`` -> ``devis_amd/libmsda_hip.so``); the Python here is the host side.
+(``devis_amd/csrc/*.hip``, one translation unit per kernel family -> ``devis_amd/libmsda_hip.so``); the Python here is the host side.
 There is no CPU fallback: like the reference (``src/ms_deform_attn.h:38,60``) the operator raises on
 CPU tensors, and it raises if the HIP library cannot be loaded.
 """

@@ -46,6 +46,7 @@ size_t tile_lds_bytes(int rpw, int nvl, bool bwd, bool intervals = false)
 struct Knobs {
     int fwd_rs = -1, fwd_rs_nt = 0;     // resident-slab forward: -1 auto, 0 off, 1 force; tiles per wave (0 = auto)
     int bwd_rs = -1, bwd_rs_tpw = 0;    // resident-slab gather pass: -1 auto, 0 off, 1 force; tiles per wave (0 = auto)
+    int bwd_rs_fsplit = -1;             // gather pass with one source frame per workgroup: parts per (clip, head, frame); -1 auto, 0 off
     int fwd_win = -1, bwd_win = -1;     // resident-window kernels (encoder-shaped calls): -1 auto, 0 off, 1 force
     int win_min_halo = 5;               // narrowest halo a window plan may have; one staging phase is preferred from here on (5 holds
                                         // the reference's initial offsets, <= 4 pixels of every level: ms_deform_attn.py:64-76)
@@ -74,6 +75,7 @@ void load_knobs()
     if (env_int("MSDA_ENABLE_HOOKS", 0) == 1) {
         k.fwd_rs = env_int("MSDA_FWD_RS", k.fwd_rs); k.fwd_rs_nt = env_int("MSDA_FWD_RS_NT", k.fwd_rs_nt);
         k.bwd_rs = env_int("MSDA_BWD_RS", k.bwd_rs); k.bwd_rs_tpw = env_int("MSDA_BWD_RS_TPW", k.bwd_rs_tpw);
+        k.bwd_rs_fsplit = env_int("MSDA_BWD_RS_FSPLIT", k.bwd_rs_fsplit);
         k.fwd_win = env_int("MSDA_FWD_WIN", k.fwd_win); k.bwd_win = env_int("MSDA_BWD_WIN", k.bwd_win);
         k.win_min_halo = env_int("MSDA_WIN_MIN_HALO", k.win_min_halo);
         const char *mode = getenv("MSDA_BWD_MODE");
@@ -418,7 +420,18 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             if (knobs().bwd_rs_tpw > 0) tpw = knobs().bwd_rs_tpw;
             const int parts = tpw ? (rs_tiles_per_clip + tpw * kRsWaves - 1) / (tpw * kRsWaves) : 1;       // (L2: see the forward)
             const bool want = mode == 1 || (mode == -1 && tpw && l0_host <= p.L - 1);
-            if (want && clips * p.M * parts <= 0x7fffffffLL) {
+            // One source frame per workgroup (round 4): the gather pass carries nothing from frame to frame, so (clip, head, frame,
+            // half of the clip's tiles) workgroups stage ONE slab each and meet at no barrier afterwards -- a quarter of the staging
+            // traffic of (clip, head, part) workgroups walking the frames.  Pays for 4-byte types from ~8 clips on (same box, fp32:
+            // 8 / 16 / 32 clips 0.245 -> 0.229 / 0.48 -> 0.44 / 0.881 -> 0.874 ms; 4 clips 0.100 -> 0.122: too few workgroups per
+            // frame map in one L2; bf16 0.360 -> 0.354: its workgroups already hold 4 tiles per wave).
+            int fparts = knobs().bwd_rs_fsplit;
+            if (fparts < 0) fparts = (esz == 4 && p.frames > 1 && clips * p.M * p.frames * 2 >= 3LL * device_cus()) ? 2 : 0;
+            if (want && fparts > 0 && p.frames > 1 && clips * p.M * p.frames * fparts <= 0x7fffffffLL) {
+                rc = launch_bwd_rs(dtype, l0_host, p, fparts, (unsigned)(clips * p.M * p.frames * fparts), stream, 1);
+                if (rc) return rc;
+                done = true;
+            } else if (want && clips * p.M * parts <= 0x7fffffffLL) {
                 rc = launch_bwd_rs(dtype, l0_host, p, parts, (unsigned)(clips * p.M * parts), stream);
                 if (rc) return rc;
                 done = true;

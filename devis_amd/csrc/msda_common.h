@@ -483,7 +483,7 @@ int launch_bwd_tile(int dtype, int G, bool atomics, const Params &p, unsigned bl
 // guess of the first pyramid level inside the slab (1 or 2: picks the kernel whose software-pipelined slot body is compiled
 // for it -- speed only: a kernel whose device-side level differs falls back to its plain loop)
 int launch_fwd_rs(int dtype, int nt, int first_slab_level, const Params &p, int parts, unsigned grid, hipStream_t stream);
-int launch_bwd_rs(int dtype, int first_slab_level, const Params &p, int parts, unsigned grid, hipStream_t stream);
+int launch_bwd_rs(int dtype, int first_slab_level, const Params &p, int parts, unsigned grid, hipStream_t stream, int frame_split = 0);
 int launch_fwd_win(int dtype, const Params &p, const WinPlan &w, hipStream_t stream);
 int launch_bwd_win(int dtype, const Params &p, const WinPlan &w, hipStream_t stream);
 // msda_scatter.hip: grad_value

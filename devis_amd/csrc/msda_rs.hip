@@ -25,6 +25,11 @@ namespace {
 //   * a corner outside the map reads a zero row kept in LDS (slab levels) or an out-of-range buffer offset
 //     (other levels: buffer loads return 0 without touching memory), so a non-finite value at an unrelated
 //     pixel can never leak into a row that does not sample it.
+#ifndef MSDA_RS_PAIR
+#define MSDA_RS_PAIR 1       // forward: the two LDS corners of a pair are requested together, then consumed (0: one after the other).
+                             // Same speed on every shape (round 4, same box: 0.375 / 0.376 ms fp32, 0.282 / 0.282 bf16), but the
+                             // production 16-bit kernel (4 tiles per wave) no longer spills VGPRs (6 -> 0; profiles/r04_resource_usage.txt)
+#endif
 #ifndef MSDA_RS_PIPE
 #define MSDA_RS_PIPE 1       // software-pipelined level-0 corners (0: the plain group loop only; A/B builds)
 #endif
@@ -361,8 +366,22 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                             static_for<8>([&](auto Hc) {
                                 constexpr int R = decltype(Hc)::value / 2, S0 = 2 * (decltype(Hc)::value % 2);
                                 constexpr int HS = (GL - L0) * 8 + decltype(Hc)::value;      // LDS pair index
+#if MSDA_RS_PAIR
+                                {   // both corners of the pair requested before either is consumed
+                                    const int A0 = quad_bcast<R>(rl.a[S0]) + off1, A1 = quad_bcast<R>(rl.a[S0 + 1]) + off1;
+                                    const float W0 = quad_bcast<R>(rl.w[S0]), W1 = quad_bcast<R>(rl.w[S0 + 1]);
+#if defined(__HIP_DEVICE_COMPILE__)
+                                    const RsRaw<T> r0 = rs_issue_row<T, true>(rsrc, A0, delta2);
+                                    const RsRaw<T> r1 = rs_issue_row<T, true>(rsrc, A1, delta2);
+                                    rs_fma_row<T>(r0, W0, wacc);
+                                    rs_fma_row<T>(r1, W1, wacc);
+#endif
+                                    asm volatile("" ::: "memory");
+                                }
+#else
                                 corner(std::true_type{}, quad_bcast<R>(rl.a[S0]) + off1, quad_bcast<R>(rl.w[S0]));
                                 corner(std::true_type{}, quad_bcast<R>(rl.a[S0 + 1]) + off1, quad_bcast<R>(rl.w[S0 + 1]));
+#endif
                                 if constexpr ((HS + 1) % PERIOD == 0) {
                                     constexpr int J = (HS + 1) / PERIOD - 1;
                                     consume(std::integral_constant<int, J>{});
@@ -443,7 +462,7 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
 // Also leaves the per-point culling records (top tap row as int16) the scatter pass reads.
 template <typename T, typename TL, int PL0>      // T: value / grad_out, TL: sampling_loc / attn_weight and their gradients
 __global__ void __launch_bounds__(kRsThreads)
-msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
+msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts, int frame_split)
 {
     constexpr int RPW = kRsRows, D = 32, ROWB = rs_row_bytes<T>(), ROWSH = ROWB == 128 ? 7 : 6;
     constexpr bool kHalf = sizeof(T) == 2;
@@ -459,8 +478,15 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
 
     const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u;       // clip-major XCD mapping, as in the forward
     const unsigned lin = xcd * (nwg / 8u) + min(xcd, nwg % 8u) + blockIdx.x / 8u;
-    const int part = (int)(lin % (unsigned)parts), m = (int)((lin / (unsigned)parts) % (unsigned)p.M);
-    const int clip = (int)(lin / ((unsigned)parts * (unsigned)p.M));
+    // frame_split (round 4): a workgroup = (clip, head, SOURCE FRAME, part of the clip's tiles) instead of (clip, head, part)
+    // walking the frames: nothing is carried from one source frame to the next in this pass, so the frame loop can be a grid
+    // dimension -- one slab per workgroup, no barrier or staging between frames
+    const int part = (int)(lin % (unsigned)parts);
+    const unsigned rest = lin / (unsigned)parts;
+    const int f_only = frame_split ? (int)(rest % (unsigned)p.frames) : -1;
+    const unsigned rest2 = frame_split ? rest / (unsigned)p.frames : rest;
+    const int m = (int)(rest2 % (unsigned)p.M);
+    const int clip = (int)(rest2 / (unsigned)p.M);
     const int tiles_per_group = (p.Lq + RPW - 1) / RPW, tiles_per_clip = p.frames * tiles_per_group;
     const int tpw = (tiles_per_clip + parts - 1) / parts;
     const int tile_lo = part * tpw + wave, tile_hi = min((part + 1) * tpw, tiles_per_clip);
@@ -477,7 +503,7 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts)
     const bool records = p.bbox != nullptr;        // per-point culling records (host: only with cull_points)
     rs_wave_priority(wave);
 
-    for (int f = 0; f < p.frames; ++f) {
+    for (int f = frame_split ? f_only : 0; f < (frame_split ? f_only + 1 : p.frames); ++f) {
         __syncthreads();                                   // every wave is done with the previous slab
         if (l0 < L) rs_stage_slab<T>(p, slab, clip, m, f, sh.px0, sh.npx, wave, lane);
         __syncthreads();
@@ -740,20 +766,21 @@ int fwd_rs_l0(int nt, int pl0, const Params &p, int parts, unsigned grid, hipStr
 }
 
 template <typename T, typename TL, int PL0>
-int bwd_rs(const Params &p, int parts, unsigned grid, hipStream_t stream)
+int bwd_rs(const Params &p, int parts, unsigned grid, hipStream_t stream, int frame_split)
 {
     static LdsGrant granted;
     const size_t total = (size_t)kRsSlabBytes + kRsTailBytes;
     const auto kern = &msda_bwd_rs_kernel<T, TL, PL0>;
     if (const int rc = grant_lds(reinterpret_cast<const void *>(kern), total, granted, "the resident-slab gather-pass kernel")) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kRsThreads), total, stream, p, kRsSlabBytes, parts);
-    return check_launch("msda backward (resident-slab kernel, grad_loc/grad_attn)");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kRsThreads), total, stream, p, kRsSlabBytes, parts, frame_split);
+    return check_launch(frame_split ? "msda backward (resident-slab kernel, grad_loc/grad_attn, one source frame per workgroup)"
+                                    : "msda backward (resident-slab kernel, grad_loc/grad_attn)");
 }
 
 template <typename T, typename TL>
-int bwd_rs_l0(int pl0, const Params &p, int parts, unsigned grid, hipStream_t stream)
+int bwd_rs_l0(int pl0, const Params &p, int parts, unsigned grid, hipStream_t stream, int frame_split)
 {
-    return pl0 == 2 ? bwd_rs<T, TL, 2>(p, parts, grid, stream) : bwd_rs<T, TL, 1>(p, parts, grid, stream);
+    return pl0 == 2 ? bwd_rs<T, TL, 2>(p, parts, grid, stream, frame_split) : bwd_rs<T, TL, 1>(p, parts, grid, stream, frame_split);
 }
 
 }  // namespace
@@ -765,10 +792,10 @@ int launch_fwd_rs(int dtype, int nt, int first_slab_level, const Params &p, int 
     });
 }
 
-int launch_bwd_rs(int dtype, int first_slab_level, const Params &p, int parts, unsigned grid, hipStream_t stream)
+int launch_bwd_rs(int dtype, int first_slab_level, const Params &p, int parts, unsigned grid, hipStream_t stream, int frame_split)
 {
     return dispatch_types(dtype, [&](auto t, auto tl) {
-        return bwd_rs_l0<typename decltype(t)::type, typename decltype(tl)::type>(first_slab_level, p, parts, grid, stream);
+        return bwd_rs_l0<typename decltype(t)::type, typename decltype(tl)::type>(first_slab_level, p, parts, grid, stream, frame_split);
     });
 }
 

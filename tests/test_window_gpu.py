@@ -140,10 +140,10 @@ def test_window_route_is_automatic_where_the_slab_holds_the_last_level_only():
 
 @pytest.mark.parametrize("seed", range(24))
 def test_window_kernels_random_pyramids(seed, monkeypatch):
-    if seed % 3 == 0:
-        monkeypatch.setenv("MSDA_WIN_MIN_HALO", "9")        # plans with two staging phases (narrow halos otherwise fit in one)
     """Random pyramids (ragged level ratios, levels smaller than a tile, 1-5 levels), frame tables with repeated / missing
     frames, point counts, dtypes and sampling spreads, forced onto the window kernels."""
+    if seed % 3 == 0:
+        monkeypatch.setenv("MSDA_WIN_MIN_HALO", "9")        # plans with two staging phases (narrow halos otherwise fit in one)
     from devis_amd.functions import MSDeformAttnTemporalFunction
     _force(monkeypatch)
     rng = np.random.default_rng(900 + seed)
