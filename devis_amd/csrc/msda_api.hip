@@ -425,9 +425,21 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             // traffic of (clip, head, part) workgroups walking the frames.  Pays for 4-byte types from ~8 clips on (same box, fp32:
             // 8 / 16 / 32 clips 0.245 -> 0.229 / 0.48 -> 0.44 / 0.881 -> 0.874 ms; 4 clips 0.100 -> 0.122: too few workgroups per
             // frame map in one L2; bf16 0.360 -> 0.354: its workgroups already hold 4 tiles per wave).
+            // SMALL batches -- the one clip per GPU DeVIS itself issues (main.py:85) -- cannot fill the chip with (clip, head, part)
+            // workgroups at all (tpw = 0) and used to fall to the tile kernels: with the frames as a workgroup index 1 / 2 clips make
+            // 192 / 384 workgroups of <= 2 tiles per wave (same box, gather pass of 1 clip fp32 0.058 -> 0.040 ms, bf16 0.074 -> 0.037;
+            // 2 clips 0.088 -> 0.063, 0.094 -> 0.065; profiles/r04_logs/small_batch_sweep.log).
             int fparts = knobs().bwd_rs_fsplit;
-            if (fparts < 0) fparts = (esz == 4 && p.frames > 1 && clips * p.M * p.frames * 2 >= 3LL * device_cus()) ? 2 : 0;
-            if (want && fparts > 0 && p.frames > 1 && clips * p.M * p.frames * fparts <= 0x7fffffffLL) {
+            bool want_small = false;
+            if (fparts < 0) {
+                fparts = (esz == 4 && p.frames > 1 && clips * p.M * p.frames * 2 >= 3LL * device_cus()) ? 2 : 0;
+                if (!fparts && !tpw && mode == -1 && p.frames > 1 && l0_host <= p.L - 1 && clips * p.M * p.frames * 4 >= device_cus() / 2 &&
+                    rs_tiles_per_clip >= 4 * kRsWaves) {                   // (every wave of the 4 workgroups of a (clip, head, frame) gets a tile)
+                    fparts = 4;
+                    want_small = true;
+                }
+            }
+            if ((want || want_small) && fparts > 0 && p.frames > 1 && clips * p.M * p.frames * fparts <= 0x7fffffffLL) {
                 rc = launch_bwd_rs(dtype, l0_host, p, fparts, (unsigned)(clips * p.M * p.frames * fparts), stream, 1);
                 if (rc) return rc;
                 done = true;
