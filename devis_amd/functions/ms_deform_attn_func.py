@@ -259,9 +259,27 @@ class _PaddedValueProj(Function):
         g2d = grad_value.reshape(N * S, weight.shape[0])
         x2d = x.reshape(N * S, C)
         grad_x = (g2d @ weight).view(N, S, C) if ctx.needs_input_grad[0] else None
-        grad_w = g2d.t() @ x2d if ctx.needs_input_grad[1] else None
+        grad_w = _split_k_wgrad(g2d, x2d) if ctx.needs_input_grad[1] else None
         grad_b = g2d.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return grad_x, grad_w, grad_b, None, None, None, None
+
+
+def _split_k_wgrad(g2d, x2d, rows_per_split=1024):
+    """``g2d.t() @ x2d`` for a LONG reduction (rows = every pixel of a clip, 28 920 at 360x640 x 6 frames) onto a small
+    ``[out, in]`` result: the BLAS library runs that as 32 workgroups of one 32x64 tile each (0.109 ms for 256 x 256 in fp32,
+    0.104 in bf16 on MI355X -- the largest single kernel of a decoder-layer step, profiles/r04_logs/module_kernels.txt).
+    Cut into slices of ~``rows_per_split`` rows it is one batched product plus a sum over the slices: 0.067 / 0.047 ms
+    (scripts/wgrad_probe.py).  The slices' partial results are added in the tensors' own precision."""
+    R = g2d.shape[0]
+    k = R // rows_per_split
+    if k < 4 or not g2d.is_contiguous() or not x2d.is_contiguous():
+        return g2d.t() @ x2d
+    r = R // k
+    main = r * k
+    w = torch.bmm(g2d[:main].view(k, r, -1).transpose(1, 2), x2d[:main].view(k, r, -1)).sum(0)
+    if main < R:
+        w.addmm_(g2d[main:].t(), x2d[main:])
+    return w
 
 
 def project_value(x, linear, n_heads, padding_mask=None, pad_heads=1, consumer_masks_grad=False):

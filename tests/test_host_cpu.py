@@ -270,3 +270,23 @@ def test_fused_linear_parameters_are_cached_only_outside_autograd():
         mod.attention_weights.bias.add_(1.0)                     # a parameter changes in place: new version -> rebuilt
         w4, b4 = _fused_linear_params(mod, lins)
         assert b4 is not b2 and torch.equal(b4[-mod.attention_weights.bias.numel():], mod.attention_weights.bias)
+
+
+def test_split_k_weight_gradient_of_value_proj_matches_the_plain_product():
+    """`_split_k_wgrad` (the weight gradient of the padded value_proj, cut into row slices) against g.t() @ x, with a row
+    count that leaves a tail slice, in fp64; and through the autograd Function against nn.Linear's own backward."""
+    import torch
+    from devis_amd.functions import project_value
+    from devis_amd.functions.ms_deform_attn_func import _split_k_wgrad
+    gen = torch.Generator().manual_seed(5)
+    g = torch.randn(4 * 1024 + 37, 24, generator=gen, dtype=torch.float64)
+    x = torch.randn(4 * 1024 + 37, 16, generator=gen, dtype=torch.float64)
+    torch.testing.assert_close(_split_k_wgrad(g, x), g.t() @ x, rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(_split_k_wgrad(g[:100], x[:100]), g[:100].t() @ x[:100], rtol=0, atol=0)      # short: plain product
+    lin = torch.nn.Linear(16, 24).double()
+    inp = torch.randn(3, 1500, 16, generator=gen, dtype=torch.float64, requires_grad=True)
+    wgt = torch.randn(3, 1500, 4, 6, generator=gen, dtype=torch.float64)
+    got = torch.autograd.grad((project_value(inp, lin, 4, None, 1) * wgt).sum(), (inp, lin.weight, lin.bias))
+    want = torch.autograd.grad((lin(inp).view(3, 1500, 4, 6) * wgt).sum(), (inp, lin.weight, lin.bias))
+    for a, b in zip(got, want):
+        torch.testing.assert_close(a, b, rtol=1e-11, atol=1e-11)
