@@ -201,6 +201,12 @@ def shapes_hint(shapes):
     hit = _shape_hints.get(key)
     if hit is not None and hit[0] is shapes:
         return hit[1]
+    if shapes.is_cuda and torch.cuda.is_current_stream_capturing():
+        # a tensor first seen inside a HIP-graph capture (the reference's transformer rebuilds spatial_shapes on every forward,
+        # deformable_transformer.py:87) cannot be read back without breaking the capture: no hint -- the library then selects
+        # its kernels from the sizes alone (include/msda.h: the hint is optional); run the call once eagerly, or keep the
+        # tensor alive across steps, to capture the routes the hint enables
+        return None
     host = shapes.detach().to("cpu", torch.int64).reshape(-1).tolist()
     arr = (ctypes.c_int64 * len(host))(*host)
     if len(_shape_hints) > 64:

@@ -29,7 +29,11 @@ def _pyramid(spatial_shapes):
     if isinstance(spatial_shapes, torch.Tensor):
         if spatial_shapes.is_cuda:
             from . import _native
-            flat = list(_native.shapes_hint(spatial_shapes))
+            hint = _native.shapes_hint(spatial_shapes)
+            if hint is None:
+                raise RuntimeError("get_reference_points: spatial_shapes is a device tensor first seen inside a HIP-graph capture; "
+                                   "call once outside the capture (or pass the sizes as Python ints)")
+            flat = list(hint)
         else:
             flat = spatial_shapes.reshape(-1).tolist()
         return tuple((int(flat[2 * i]), int(flat[2 * i + 1])) for i in range(len(flat) // 2))

@@ -724,6 +724,39 @@ def test_graph_replay_equals_eager():
                 assert torch.equal(a, b), i
 
 
+def test_capture_with_a_spatial_shapes_tensor_never_seen_before():
+    """The reference's transformer rebuilds ``spatial_shapes`` on every forward (deformable_transformer.py:87).  A tensor the
+    library has no host copy of cannot be read back inside a HIP-graph capture: the call then goes without the hint
+    (`_native.shapes_hint` returns None) instead of breaking the capture, and the replay equals the eager call."""
+    from devis_amd import _native
+    from devis_amd.functions import MSDeformAttnTemporalFunction
+    d = make_temporal_inputs(81, T=3, W=2, M=8, D=32, Lq=50, shapes=[(20, 33), (10, 17), (5, 9), (3, 5)], Pc=4, Pt=4)
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in d.items()}
+    keys = ("value", "loc_c", "aw_c", "loc_t", "aw_t")
+    static = [t[k].clone().requires_grad_(True) for k in keys]
+
+    def step(shapes):
+        out = MSDeformAttnTemporalFunction.apply(static[0], shapes, t["lsi"], t["ftab"], *static[1:], 1)
+        return (out,) + torch.autograd.grad(out, static, t["grad_out"])
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step(t["shapes"])
+    torch.cuda.current_stream().wait_stream(side)
+    fresh = t["shapes"].clone()                     # same values, a tensor the hint cache has not seen
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        assert _native.shapes_hint(fresh) is None
+        captured = step(fresh)
+    graph.replay()
+    torch.cuda.synchronize()
+    want = step(t["shapes"])
+    for i, (a, b) in enumerate(zip(captured, want)):
+        assert _maxabs(a.detach().double().cpu().numpy(), b.detach().double().cpu().numpy()) <= 1e-5 * max(1.0, float(b.abs().max())), i
+
+
 @pytest.mark.parametrize("env", [{}, {"MSDA_FWD_RS": "1", "MSDA_BWD_RS": "1"}, {"MSDA_FORCE_GENERIC": "1"}, {"MSDA_SCATTER_OWN": "0"},
                                  {"MSDA_BWD_MODE": "atomic"}],
                          ids=["auto", "resident-slab", "generic", "lds-scatter", "atomic"])
