@@ -422,9 +422,9 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             const bool want = mode == 1 || (mode == -1 && tpw && l0_host <= p.L - 1);
             // One source frame per workgroup (round 4): the gather pass carries nothing from frame to frame, so (clip, head, frame,
             // half of the clip's tiles) workgroups stage ONE slab each and meet at no barrier afterwards -- a quarter of the staging
-            // traffic of (clip, head, part) workgroups walking the frames.  Pays for 4-byte types from ~8 clips on (same box, fp32:
+            // traffic of (clip, head, part) workgroups walking the frames.  Pays from ~8 clips on (same box, fp32:
             // 8 / 16 / 32 clips 0.245 -> 0.229 / 0.48 -> 0.44 / 0.881 -> 0.874 ms; 4 clips 0.100 -> 0.122: too few workgroups per
-            // frame map in one L2; bf16 0.360 -> 0.354: its workgroups already hold 4 tiles per wave).
+            // frame map in one L2).
             // SMALL batches -- the one clip per GPU DeVIS itself issues (main.py:85) -- cannot fill the chip with (clip, head, part)
             // workgroups at all (tpw = 0) and used to fall to the tile kernels: with the frames as a workgroup index 1 / 2 clips make
             // 192 / 384 workgroups of <= 2 tiles per wave (same box, gather pass of 1 clip fp32 0.058 -> 0.040 ms, bf16 0.074 -> 0.037;
@@ -432,7 +432,10 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             int fparts = knobs().bwd_rs_fsplit;
             bool want_small = false;
             if (fparts < 0) {
-                fparts = (esz == 4 && p.frames > 1 && clips * p.M * p.frames * 2 >= 3LL * device_cus()) ? 2 : 0;
+                // (round 4, second sweep, profiles/r04_logs/gather_fsplit_sweep.log: 2-byte types gain 5-10 % at 8 / 16 / 32 / 64 clips;
+                // fp32 gains 4-11 % up to 32 clips and loses 3 % at 64)
+                const long long wgs = clips * p.M * p.frames * 2;
+                fparts = (p.frames > 1 && wgs >= 3LL * device_cus() && (esz == 2 || wgs < 24LL * device_cus())) ? 2 : 0;
                 if (!fparts && !tpw && mode == -1 && p.frames > 1 && l0_host <= p.L - 1 && clips * p.M * p.frames * 4 >= device_cus() / 2 &&
                     rs_tiles_per_clip >= 4 * kRsWaves) {                   // (every wave of the 4 workgroups of a (clip, head, frame) gets a tile)
                     fparts = 4;
