@@ -75,6 +75,9 @@ CASES = {
     "dec16_bf16": lambda: temporal_case(16, "A", "uniform", 300, torch.bfloat16, 20),
     "dec64": lambda: temporal_case(64, "A", "uniform", 300, torch.float32, 6),
     "dec1": lambda: temporal_case(1, "A", "uniform", 300, torch.float32, 30),
+    "dec2": lambda: temporal_case(2, "A", "uniform", 300, torch.float32, 30),
+    "dec4": lambda: temporal_case(4, "A", "uniform", 300, torch.float32, 30),
+    "dec1_bf16": lambda: temporal_case(1, "A", "uniform", 300, torch.bfloat16, 30),
     "encA": lambda: temporal_case(1, "A", "local", 4820, torch.float32, 10),
     "encB": lambda: temporal_case(1, "B", "local", 22223, torch.float32, 5),
     "cfg1": lambda: plain_case(bench.PYRAMIDS["B"], 8, 22223, "local", torch.bfloat16, 8),
