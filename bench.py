@@ -323,6 +323,20 @@ def other_configs(args, device):
                              "fwd_bwd_ms": round(ms, 4), "M_queries_per_s": round(rows / ms / 1e3, 3)}
     del step, fwd
     torch.cuda.empty_cache()
+    # (ii-c) the decoder batch on the 800x1333 pyramid (BASELINE configs[1]'s image size with the decoder's query count): two levels
+    # stay outside the resident slab, so route rules tuned on the 360x640 pyramid are checked against this one too
+    if args.pyramid == "A":
+        args.pyramid = "B"
+        try:
+            for key, dt in (("decoder_800x1333_f32", torch.float32), ("decoder_800x1333_bf16", torch.bfloat16)):
+                step, fwd, rows = fused_case(8, "uniform", dt)
+                ms, fms = _event_ms(step, 10, 5), _event_ms(fwd, 10, 5)
+                res[key] = {"workload": "cfg3 decoder call on the 800x1333 pyramid (S = 22223), 8 clips, uniform locations, %s" % str(dt)[6:],
+                            "fwd_bwd_ms": round(ms, 4), "fwd_ms": round(fms, 4), "M_queries_per_s": round(rows / ms / 1e3, 3)}
+                del step, fwd
+                torch.cuda.empty_cache()
+        finally:
+            args.pyramid = "A"
     # (iii) the headline batch in the 16-bit storage types (arithmetic stays fp32)
     for key, dt, sampling in (("headline_bf16", torch.bfloat16, "storage"), ("headline_f16", torch.float16, "storage"),
                               ("headline_bf16_fp32_sampling", torch.bfloat16, "fp32")):

@@ -387,6 +387,9 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             // the slab must hold at least the last level.  (Since the whole-row loads / stores of the points and gradients
             // the kernel wins for every dtype as soon as ANY level fits -- 800x1333, levels 2-3 resident.)
             if (mode != 1 && l0_host > p.L - 1) nt = 0;
+            // slabs that start at level 2 (large pyramids): 2 tiles per wave at most -- the 4-tile instantiations of that slot body
+            // spill 10-40 VGPRs (profiles/r04_resource_usage.txt); BASELINE configs[1] forward 0.306 -> 0.290 ms, SwinL 0.088 -> 0.082
+            if (l0_host >= 2 && nt > 2) nt = 2;
             const int force_nt = knobs().fwd_rs_nt;
             if (force_nt == 1 || force_nt == 2 || force_nt == 4) nt = force_nt;
             const int parts = nt ? (rs_tiles_per_clip + kRsWaves * nt - 1) / (kRsWaves * nt) : 0;
@@ -417,6 +420,7 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             // resident-slab gather pass: same applicability rule as the forward
             const int mode = knobs().bwd_rs;
             int tpw = rs_tiles_per_wave(p, rs_tiles_per_clip, host_pixels_below(p, l0_host) * rs_row, mode == 1, l2_budget);
+            if (l0_host >= 2 && tpw > 2) tpw = 2;        // (as in the forward: configs[1] gather pass 0.407 -> 0.395 ms)
             if (knobs().bwd_rs_tpw > 0) tpw = knobs().bwd_rs_tpw;
             const int parts = tpw ? (rs_tiles_per_clip + tpw * kRsWaves - 1) / (tpw * kRsWaves) : 1;       // (L2: see the forward)
             const bool want = mode == 1 || (mode == -1 && tpw && l0_host <= p.L - 1);
@@ -434,9 +438,13 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             if (fparts < 0) {
                 // (round 4, second sweep, profiles/r04_logs/gather_fsplit_sweep.log: 2-byte types gain 5-10 % at 8 / 16 / 32 / 64 clips;
                 // fp32 gains 4-11 % up to 32 clips and loses 3 % at 64)
+                // Only while the levels outside the slab are small: the frame-split grid keeps 16 frame maps per XCD in flight instead
+                // of 4 -- fine for the 360x640 pyramid's level 0 (460 KB in fp32), 12-16 % SLOWER on the 800x1333 one (levels 0-1
+                // outside: 2.7 MB per map; 16 clips bf16 0.531 -> 0.618 ms, fp32 0.906 -> 1.012).
                 const long long wgs = clips * p.M * p.frames * 2;
-                fparts = (p.frames > 1 && wgs >= 3LL * device_cus() && (esz == 2 || wgs < 24LL * device_cus())) ? 2 : 0;
-                if (!fparts && !tpw && mode == -1 && p.frames > 1 && l0_host <= p.L - 1 && clips * p.M * p.frames * 4 >= device_cus() / 2 &&
+                const bool small_outside = host_pixels_below(p, l0_host) * rs_row <= (1ll << 20);
+                fparts = (p.frames > 1 && small_outside && wgs >= 3LL * device_cus() && (esz == 2 || wgs < 24LL * device_cus())) ? 2 : 0;
+                if (!fparts && !tpw && mode == -1 && p.frames > 1 && small_outside && l0_host <= p.L - 1 && clips * p.M * p.frames * 4 >= device_cus() / 2 &&
                     rs_tiles_per_clip >= 4 * kRsWaves) {                   // (every wave of the 4 workgroups of a (clip, head, frame) gets a tile)
                     fparts = 4;
                     want_small = true;
