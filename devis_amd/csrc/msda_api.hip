@@ -178,19 +178,29 @@ long long host_pixels_below(const Params &p, int l0)
 // 1 / 2 / 4 tiles per wave: fp32 (460 KiB per level-0 map) forward 0.337 / 0.364 / -- ms, gather pass 0.423 / 0.471 /
 // 0.560; bf16 (230 KiB, two heads per 128-byte line) forward -- / 0.246 / 0.238, gather pass 0.363 / 0.326 / 0.312.
 // Hence a budget of 2 MiB for 4-byte types and 4 MiB for 2-byte types.
-int rs_tiles_per_wave(const Params &p, int tiles_per_clip, long long outside_bytes, bool force, long long l2_budget)
+int rs_tiles_per_wave(const Params &p, int tiles_per_clip, long long outside_bytes, bool force, long long l2_budget, int max_tiles = 4)
 {
+    // Among the candidates that (nearly) fill the chip and keep the non-resident levels of the (clip, head) pairs in flight per XCD
+    // within `l2_budget` -- or the smallest one if none does -- the one with the least (rounds of workgroups over the CUs) x (tiles
+    // per wave), larger workgroups on a tie: 360 workgroups of 4 tiles are two rounds of 4, 720 of 2 are three rounds of 2 (round
+    // 4 audit, 1-clip encoder call on the SwinL pyramid in bf16: forward 0.455 -> 0.373 ms, gather pass 0.634 -> 0.534).
     const int64_t clips = p.groups / p.frames;
-    const int cus_per_xcd = device_cus() / 8 > 0 ? device_cus() / 8 : 1;
-    int pick = 0;
+    const int cus = device_cus(), cus_per_xcd = cus / 8 > 0 ? cus / 8 : 1;
+    int pick = 0, fallback = 0;
+    long long best = 0;
     for (int cand : {4, 2, 1}) {
+        if (cand > max_tiles) continue;
         const int parts = (tiles_per_clip + kRsWaves * cand - 1) / (kRsWaves * cand);
-        if (!force && clips * p.M * parts < device_cus()) continue;          // must fill the chip
-        pick = cand;
+        const long long wgs = clips * p.M * parts;
+        if (!force && 4 * wgs < 3LL * cus) continue;                 // must (nearly) fill the chip: 232 workgroups of the 1-clip
+                                                                      // encoder call do (bf16 forward 0.263 -> 0.227 ms)
+        fallback = cand;                                              // (ends as the smallest admissible candidate)
         const long long pairs = (cus_per_xcd + parts - 1) / parts;
-        if (pairs * outside_bytes <= l2_budget) break;
+        if (pairs * outside_bytes > l2_budget) continue;
+        const long long cost = ((wgs + cus - 1) / cus) * cand;
+        if (!pick || cost < best) { pick = cand; best = cost; }
     }
-    return pick;
+    return pick ? pick : fallback;
 }
 
 bool standard_value_layout(const Params &p)
@@ -373,7 +383,10 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
     // would hold the last level at most (fp32 at 800x1333: 273 of 22223 pixels) -- measured forward 2.38 -> 1.07 ms, gather pass 2.85 -> 1.60 ms there; where
     // more levels fit the slab (16-bit types, the 360x640 pyramid) the two families are on a par and the slab kernels stay.
     auto window_route = [&](int mode, WinPlan &w) {
-        if (mode == 0 || (mode != 1 && !(p.Lq == p.S && p.L > 1 && l0_host >= p.L - 1))) return false;     // (cheap tests first)
+        // (round 4 audit: also when a 4-byte slab holds only the last TWO levels -- SwinL 480x768 in fp32: forward 0.49 -> 0.37 ms,
+        // gather pass 0.66 -> 0.55; 2-byte slabs of that kind -- 800x1333 bf16 -- are on a par and stay)
+        const bool few_levels = l0_host >= p.L - 1 || (esz == 4 && p.L > 2 && l0_host >= p.L - 2);
+        if (mode == 0 || (mode != 1 && !(p.Lq == p.S && p.L > 1 && few_levels))) return false;     // (cheap tests first)
         return win_plan_cached(p, esz, mode == 1, w);
     };
     if (!bwd) {
@@ -383,13 +396,14 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             // resident-slab forward: up to NT * 16 tiles of 16 rows per workgroup, so that the per-frame slab staging is
             // amortised; tiles per wave (NT) and workgroups per (clip, head) (parts): see rs_tiles_per_wave
             const int mode = knobs().fwd_rs;                               // -1 auto, 0 off, 1 force
-            int nt = rs_tiles_per_wave(p, rs_tiles_per_clip, host_pixels_below(p, l0_host) * rs_row, mode == 1, l2_budget);
+            // at most 2 tiles per wave for slabs that start at level 2 (large pyramids) and for fp32: the 4-tile instantiations of
+            // those slot bodies spill 10-40 VGPRs (profiles/r04_resource_usage.txt); BASELINE configs[1] forward 0.306 -> 0.290 ms,
+            // SwinL 0.088 -> 0.082, 2-clip fp32 encoder call 0.52 -> 0.46
+            const int max_nt = (l0_host >= 2 || esz == 4) ? 2 : 4;
+            int nt = rs_tiles_per_wave(p, rs_tiles_per_clip, host_pixels_below(p, l0_host) * rs_row, mode == 1, l2_budget, max_nt);
             // the slab must hold at least the last level.  (Since the whole-row loads / stores of the points and gradients
             // the kernel wins for every dtype as soon as ANY level fits -- 800x1333, levels 2-3 resident.)
             if (mode != 1 && l0_host > p.L - 1) nt = 0;
-            // slabs that start at level 2 (large pyramids): 2 tiles per wave at most -- the 4-tile instantiations of that slot body
-            // spill 10-40 VGPRs (profiles/r04_resource_usage.txt); BASELINE configs[1] forward 0.306 -> 0.290 ms, SwinL 0.088 -> 0.082
-            if (l0_host >= 2 && nt > 2) nt = 2;
             const int force_nt = knobs().fwd_rs_nt;
             if (force_nt == 1 || force_nt == 2 || force_nt == 4) nt = force_nt;
             const int parts = nt ? (rs_tiles_per_clip + kRsWaves * nt - 1) / (kRsWaves * nt) : 0;
@@ -419,8 +433,8 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
         if (!done && rs_ok && (p.cull_points || !p.bbox)) {
             // resident-slab gather pass: same applicability rule as the forward
             const int mode = knobs().bwd_rs;
-            int tpw = rs_tiles_per_wave(p, rs_tiles_per_clip, host_pixels_below(p, l0_host) * rs_row, mode == 1, l2_budget);
-            if (l0_host >= 2 && tpw > 2) tpw = 2;        // (as in the forward: configs[1] gather pass 0.407 -> 0.395 ms)
+            int tpw = rs_tiles_per_wave(p, rs_tiles_per_clip, host_pixels_below(p, l0_host) * rs_row, mode == 1, l2_budget,
+                                        l0_host >= 2 ? 2 : 4);      // (as in the forward: configs[1] gather pass 0.407 -> 0.395 ms)
             if (knobs().bwd_rs_tpw > 0) tpw = knobs().bwd_rs_tpw;
             const int parts = tpw ? (rs_tiles_per_clip + tpw * kRsWaves - 1) / (tpw * kRsWaves) : 1;       // (L2: see the forward)
             const bool want = mode == 1 || (mode == -1 && tpw && l0_host <= p.L - 1);
@@ -442,11 +456,13 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
                 // of 4 -- fine for the 360x640 pyramid's level 0 (460 KB in fp32), 12-16 % SLOWER on the 800x1333 one (levels 0-1
                 // outside: 2.7 MB per map; 16 clips bf16 0.531 -> 0.618 ms, fp32 0.906 -> 1.012).
                 const long long wgs = clips * p.M * p.frames * 2;
-                const bool small_outside = host_pixels_below(p, l0_host) * rs_row <= (1ll << 20);
+                // (route audit, profiles/r04_logs/route_audit_*.log: SwinL pyramid in fp32, 737 KB outside, 8-32 clips 14-20 % slower)
+                const bool small_outside = host_pixels_below(p, l0_host) * rs_row <= (512ll << 10);
                 fparts = (p.frames > 1 && small_outside && wgs >= 3LL * device_cus() && (esz == 2 || wgs < 24LL * device_cus())) ? 2 : 0;
-                if (!fparts && !tpw && mode == -1 && p.frames > 1 && small_outside && l0_host <= p.L - 1 && clips * p.M * p.frames * 4 >= device_cus() / 2 &&
+                if (!fparts && !tpw && mode == -1 && p.frames > 1 && l0_host <= p.L - 1 && clips * p.M * p.frames * 4 >= device_cus() / 2 &&
                     rs_tiles_per_clip >= 4 * kRsWaves) {                   // (every wave of the 4 workgroups of a (clip, head, frame) gets a tile)
-                    fparts = 4;
+                    // (2-byte types with two clips: 2 workgroups per (clip, head, frame) -- 0.067 -> 0.056 ms; fp32 the other way round)
+                    fparts = (esz == 2 && clips * p.M * p.frames * 2 >= 3LL * device_cus() / 4) ? 2 : 4;
                     want_small = true;
                 }
             }
