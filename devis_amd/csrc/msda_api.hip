@@ -196,8 +196,11 @@ int rs_tiles_per_wave(const Params &p, int tiles_per_clip, long long outside_byt
                                                                       // encoder call do (bf16 forward 0.263 -> 0.227 ms)
         fallback = cand;                                              // (ends as the smallest admissible candidate)
         const long long pairs = (cus_per_xcd + parts - 1) / parts;
-        if (pairs * outside_bytes > l2_budget) continue;
-        const long long cost = ((wgs + cus - 1) / cus) * cand;
+        // (encoder-shaped calls -- one query per pixel, sampling round its own position -- find their non-resident lines in the L2
+        // whatever the pairs in flight: single-frame fp32 encoder call on the SwinL pyramid, 6 images, 0.134 -> 0.089 ms)
+        if (p.Lq != p.S && pairs * outside_bytes > l2_budget) continue;
+        // (x2, + 1: half a tile's worth of fixed cost per workgroup -- slab staging, set-up; 8-image encoder call 0.072 -> 0.064 ms)
+        const long long cost = ((wgs + cus - 1) / cus) * (2 * cand + 1);
         if (!pick || cost < best) { pick = cand; best = cost; }
     }
     return pick ? pick : fallback;
@@ -385,7 +388,8 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
     auto window_route = [&](int mode, WinPlan &w) {
         // (round 4 audit: also when a 4-byte slab holds only the last TWO levels -- SwinL 480x768 in fp32: forward 0.49 -> 0.37 ms,
         // gather pass 0.66 -> 0.55; 2-byte slabs of that kind -- 800x1333 bf16 -- are on a par and stay)
-        const bool few_levels = l0_host >= p.L - 1 || (esz == 4 && p.L > 2 && l0_host >= p.L - 2);
+        // (temporal calls only: single-frame encoder calls on that pyramid are 6-26 % faster on the slab kernels)
+        const bool few_levels = l0_host >= p.L - 1 || (esz == 4 && p.frames > 1 && p.L > 2 && l0_host >= p.L - 2);
         if (mode == 0 || (mode != 1 && !(p.Lq == p.S && p.L > 1 && few_levels))) return false;     // (cheap tests first)
         return win_plan_cached(p, esz, mode == 1, w);
     };
@@ -407,6 +411,11 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             const int force_nt = knobs().fwd_rs_nt;
             if (force_nt == 1 || force_nt == 2 || force_nt == 4) nt = force_nt;
             const int parts = nt ? (rs_tiles_per_clip + kRsWaves * nt - 1) / (kRsWaves * nt) : 0;
+            // few tiles per (clip, head) leave waves of the workgroups without one: 19 tiles (300 queries of a single-frame call)
+            // on 2 x 16 waves -- 36-image decoder-like call in fp32 on the SwinL pyramid 0.078 ms here, 0.055 on the tile kernels
+            // (only where the slab starts at level 2 in a 4-byte type, i.e. saves the least: elsewhere, and in the gather pass, the slab
+            // kernels stay ahead by 4-19 %)
+            if (mode != 1 && nt && esz == 4 && l0_host >= 2 && 10LL * rs_tiles_per_clip < 7LL * parts * kRsWaves * nt) nt = 0;
             if (mode != 0 && nt && clips * p.M * parts <= 0x7fffffffLL)
                 return launch_fwd_rs(dtype, nt, l0_host, p, parts, (unsigned)(clips * p.M * parts), stream);
         }

@@ -1,6 +1,6 @@
 """GPU probe: is the AUTOMATIC route of the forward / gather pass the fastest one the library has, shape by shape?
 
-    python scripts/route_audit.py [quick]
+    python scripts/route_audit.py [quick | plain]
 
 Temporal decoder calls (300 queries per frame) and encoder calls (every pixel a query, local sampling) on three pyramids -- 360x640,
 SwinL 480x768 and 800x1333 -- at several batch sizes and storage types; every forced alternative that applies is timed after the
@@ -70,8 +70,23 @@ def main():
                 cases.append(("dec", pyr, clips, dtype))
             for clips in ((1,) if quick else (1, 2)):
                 cases.append(("enc", pyr, clips, dtype))
+    if len(sys.argv) > 1 and sys.argv[1] == "plain":
+        # single-frame MSDeformAttn: the encoder call (every pixel a query, N images) and the decoder-like call (300 queries)
+        cases = [(kind, pyr, n, dtype) for pyr in ("A", "S", "B") for dtype in (torch.float32, torch.bfloat16)
+                 for kind, ns in (("penc", (1, 2, 6, 8)), ("pdec", (1, 6, 36))) for n in ns]
     for kind, pyr, clips, dtype in cases:
         S = sum(h * w for h, w in bench.PYRAMIDS[pyr])
+        if kind in ("penc", "pdec"):
+            fwd, bwd, gv, reps = scatter_ab.plain_case(bench.PYRAMIDS[pyr], clips, S if kind == "penc" else 300,
+                                                       "local" if kind == "penc" else "uniform", dtype, 12)
+            tag = "%s %s %2d images %-8s" % (kind, pyr, clips, str(dtype)[6:])
+            audit(tag + " fwd", fwd, [a for a in FWD], reps, {})
+            knobs()
+            bwd()
+            audit(tag + " gather", bwd, [a for a in BWD if not a[0].startswith("fs")], reps, {"MSDA_BWD_PHASES": 1})
+            del fwd, bwd, gv
+            torch.cuda.empty_cache()
+            continue
         if kind == "enc" and clips * S * 6 * 256 * 4 * 12 > 40e9:
             continue
         try:
