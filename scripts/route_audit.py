@@ -1,6 +1,6 @@
 """GPU probe: is the AUTOMATIC route of the forward / gather pass the fastest one the library has, shape by shape?
 
-    python scripts/route_audit.py [quick | plain]
+    python scripts/route_audit.py [quick | plain | scatter]
 
 Temporal decoder calls (300 queries per frame) and encoder calls (every pixel a query, local sampling) on three pyramids -- 360x640,
 SwinL 480x768 and 800x1333 -- at several batch sizes and storage types; every forced alternative that applies is timed after the
@@ -19,7 +19,7 @@ import scatter_ab
 from devis_amd import _native
 
 bench.PYRAMIDS["S"] = scatter_ab.SWIN
-KEYS = ("MSDA_FWD_RS", "MSDA_FWD_RS_NT", "MSDA_BWD_RS", "MSDA_BWD_RS_TPW", "MSDA_BWD_RS_FSPLIT", "MSDA_FWD_WIN", "MSDA_BWD_WIN")
+KEYS = ("MSDA_SCATTER_DBG", "MSDA_SCATTER_OWN", "MSDA_FWD_RS", "MSDA_FWD_RS_NT", "MSDA_BWD_RS", "MSDA_BWD_RS_TPW", "MSDA_BWD_RS_FSPLIT", "MSDA_FWD_WIN", "MSDA_BWD_WIN")
 FWD = (("tile", {"MSDA_FWD_RS": 0, "MSDA_FWD_WIN": 0}), ("rs1", {"MSDA_FWD_RS": 1, "MSDA_FWD_RS_NT": 1, "MSDA_FWD_WIN": 0}),
        ("rs2", {"MSDA_FWD_RS": 1, "MSDA_FWD_RS_NT": 2, "MSDA_FWD_WIN": 0}), ("rs4", {"MSDA_FWD_RS": 1, "MSDA_FWD_RS_NT": 4, "MSDA_FWD_WIN": 0}),
        ("win", {"MSDA_FWD_WIN": 1}))
@@ -70,6 +70,27 @@ def main():
                 cases.append(("dec", pyr, clips, dtype))
             for clips in ((1,) if quick else (1, 2)):
                 cases.append(("enc", pyr, clips, dtype))
+    if len(sys.argv) > 1 and sys.argv[1] == "scatter":
+        # grad_value scatter: automatic against the level-by-level item order and the static schedule
+        alts = (("level order", {"MSDA_SCATTER_DBG": 256}), ("static", {"MSDA_SCATTER_DBG": 16}))
+        todo = [("dec", pyr, c, dt) for pyr in ("A", "S", "B") for dt in (torch.float32, torch.bfloat16) for c in ((6, 8, 10, 12) if len(sys.argv) > 2 else (1, 4, 16, 32))]
+        todo += [("enc", pyr, 1, dt) for pyr in ("A", "S", "B") for dt in (torch.float32, torch.bfloat16)]
+        todo += [(kind, pyr, n, dt) for pyr in ("A", "S", "B") for dt in (torch.float32, torch.bfloat16)
+                 for kind, ns in (("penc", (1, 8)), ("pdec", (6, 36))) for n in ns]
+        for kind, pyr, clips, dtype in todo:
+            S = sum(h * w for h, w in bench.PYRAMIDS[pyr])
+            if kind in ("penc", "pdec"):
+                fwd, bwd, gv, reps = scatter_ab.plain_case(bench.PYRAMIDS[pyr], clips, S if kind == "penc" else 300,
+                                                           "local" if kind == "penc" else "uniform", dtype, 10)
+            else:
+                fwd, bwd, gv, reps = scatter_ab.temporal_case(clips, pyr, "local" if kind == "enc" else "uniform", S if kind == "enc" else 300, dtype, 10)
+            knobs()
+            bwd()
+            audit("%s %s %2d %-8s scatter" % (kind, pyr, clips, str(dtype)[6:]), bwd,
+                  alts, reps, {"MSDA_BWD_PHASES": 2})
+            del fwd, bwd, gv
+            torch.cuda.empty_cache()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "plain":
         # single-frame MSDeformAttn: the encoder call (every pixel a query, N images) and the decoder-like call (300 queries)
         cases = [(kind, pyr, n, dtype) for pyr in ("A", "S", "B") for dtype in (torch.float32, torch.bfloat16)
