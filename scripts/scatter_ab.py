@@ -16,6 +16,7 @@ from devis_amd import _native
 
 DEV = torch.device("cuda:0")
 SWIN = [(60, 96), (30, 48), (15, 24), (8, 12)]
+bench.PYRAMIDS["S"] = SWIN
 
 
 def knobs(**env):
@@ -77,6 +78,10 @@ CASES = {
     "dec1": lambda: temporal_case(1, "A", "uniform", 300, torch.float32, 30),
     "dec2": lambda: temporal_case(2, "A", "uniform", 300, torch.float32, 30),
     "dec4": lambda: temporal_case(4, "A", "uniform", 300, torch.float32, 30),
+    "dec8": lambda: temporal_case(8, "A", "uniform", 300, torch.float32, 20),
+    "dec6S": lambda: temporal_case(6, "S", "uniform", 300, torch.float32, 20),
+    "dec12_bf16": lambda: temporal_case(12, "A", "uniform", 300, torch.bfloat16, 20),
+    "pdec36": lambda: plain_case(bench.PYRAMIDS["A"], 36, 300, "uniform", torch.float32, 20),
     "dec1_bf16": lambda: temporal_case(1, "A", "uniform", 300, torch.bfloat16, 30),
     "encA": lambda: temporal_case(1, "A", "local", 4820, torch.float32, 10),
     "encB": lambda: temporal_case(1, "B", "local", 22223, torch.float32, 5),
