@@ -192,8 +192,9 @@ int rs_tiles_per_wave(const Params &p, int tiles_per_clip, long long outside_byt
         if (cand > max_tiles) continue;
         const int parts = (tiles_per_clip + kRsWaves * cand - 1) / (kRsWaves * cand);
         const long long wgs = clips * p.M * parts;
-        if (!force && 4 * wgs < 3LL * cus) continue;                 // must (nearly) fill the chip: 232 workgroups of the 1-clip
-                                                                      // encoder call do (bf16 forward 0.263 -> 0.227 ms)
+        // must fill the chip -- nearly, for workgroups of several tiles per wave: 232 workgroups of 4 tiles (1-clip encoder call,
+        // bf16 forward 0.263 -> 0.227 ms) do; 240 of 1 tile (1-image SwinL encoder call) are 7 % behind the tile kernels
+        if (!force && (cand > 1 ? 4 * wgs < 3LL * cus : wgs < cus)) continue;
         fallback = cand;                                              // (ends as the smallest admissible candidate)
         const long long pairs = (cus_per_xcd + parts - 1) / parts;
         // (encoder-shaped calls -- one query per pixel, sampling round its own position -- find their non-resident lines in the L2
