@@ -13,8 +13,11 @@ from devis_amd import _native as _native_mod
 ROUTES = [{}, {"MSDA_SCATTER_DBG": "16"}, {"MSDA_BWD_CULL": "2"}, {"MSDA_BWD_CULL": "0"}, {"MSDA_SCATTER_LDS_KB": "6", "MSDA_SCATTER_OWN": "0"},
           {"MSDA_SCATTER_OWN": "0"}, {"MSDA_FWD_RS": "1", "MSDA_BWD_RS": "1"}, {"MSDA_FWD_RS": "0", "MSDA_BWD_RS": "0"},
           {"MSDA_FWD_RS": "1", "MSDA_BWD_RS": "1", "MSDA_SCATTER_DBG": "16"}, {"MSDA_BWD_RS": "1", "MSDA_BWD_CULL": "0"},
-          {"MSDA_BWD_MODE": "atomic"}, {"MSDA_FWD_RS": "1", "MSDA_FWD_RS_NT": "4"}]
-KEYS = ["MSDA_SCATTER_DBG", "MSDA_BWD_CULL", "MSDA_SCATTER_LDS_KB", "MSDA_SCATTER_OWN", "MSDA_FWD_RS", "MSDA_BWD_RS", "MSDA_BWD_MODE", "MSDA_FWD_RS_NT"]
+          {"MSDA_BWD_MODE": "atomic"}, {"MSDA_FWD_RS": "1", "MSDA_FWD_RS_NT": "4"},
+          {"MSDA_BWD_RS": "1", "MSDA_BWD_RS_FSPLIT": "1"}, {"MSDA_BWD_RS": "1", "MSDA_BWD_RS_FSPLIT": "2", "MSDA_FWD_RS": "1", "MSDA_FWD_RS_NT": "2"},
+          {"MSDA_BWD_RS": "1", "MSDA_BWD_RS_FSPLIT": "4"}, {"MSDA_BWD_RS": "1", "MSDA_BWD_RS_TPW": "2", "MSDA_BWD_RS_FSPLIT": "0"}]
+KEYS = ["MSDA_SCATTER_DBG", "MSDA_BWD_CULL", "MSDA_SCATTER_LDS_KB", "MSDA_SCATTER_OWN", "MSDA_FWD_RS", "MSDA_BWD_RS", "MSDA_BWD_MODE", "MSDA_FWD_RS_NT",
+        "MSDA_BWD_RS_FSPLIT", "MSDA_BWD_RS_TPW"]
 def maxabs(a, b): return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max()) if a.size else 0.0
 def layout(v, kind):
     if kind == 1: return _native.head_major(v)
