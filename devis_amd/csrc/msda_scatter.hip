@@ -560,6 +560,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
     const int clips = p.groups / p.frames;
     const unsigned n_items = (unsigned)clips * (unsigned)p.frames * (unsigned)p.M * (unsigned)NB;      // (< 2^31: host)
     const bool dynamic = p.workspace != nullptr && (dbg & 16) == 0 && n_items < 16u * gridDim.x;
+    const bool clip_major = (long long)p.Lq * (1 + p.window) <= 4096;       // see prepare()
     const int lane8 = blockIdx.x % 8;
     const int strideA = p.M * p.LA * p.PA, strideB = p.M * p.LB * p.PB;      // loc/attn elements per query
     // owner side: quad Q owns pixels s * kOwnQuads + Q of the band.  4-byte types: lane c of the quad holds the
@@ -592,10 +593,17 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                 part = s_order[rest % (unsigned)NB];
                 clip = (int)(rest / (unsigned)NB);
                 while (l + 1 < L && s_first[l + 1] <= part) ++l;
-            } else if (dynamic) {      // heaviest first: levels from the last to the first (see msda_bwd_value_lds_kernel)
-                const unsigned ctm = (unsigned)clips * F * M;
+            } else if (dynamic) {
+                // clip by clip, and inside a clip heaviest first: levels from the last to the first (see msda_bwd_value_lds_kernel).
+                // The items in flight at one time then belong to one or two clips -- they share the clips' grad_out rows and
+                // culling records in the L2, as the static stride's order does (round 4: with the levels outermost over ALL clips
+                // the static stride was 5-9 % faster at 6-12 clips) -- and the item list still ends on light items.
+                // (light items only -- a decoder's few hundred queries per source: an encoder-shaped call's one-band levels are
+                // items of 20-40 chunks each, which must ALL start first; clip by clip BASELINE configs[1] went 0.63 -> 0.89 ms)
+                const unsigned ctm = clip_major ? F * M : (unsigned)clips * F * M, per_clip = F * M * (unsigned)NB;
+                clip = clip_major ? (int)(item / per_clip) : 0;
                 l = L - 1;
-                unsigned local = item;
+                unsigned local = item - (unsigned)clip * per_clip;
                 while (l > 0 && local >= ctm * (unsigned)(s_first[l + 1] - s_first[l])) {
                     local -= ctm * (unsigned)(s_first[l + 1] - s_first[l]);
                     --l;
@@ -605,7 +613,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                 unsigned rest = local / M;
                 part = s_first[l] + (int)(rest % nb_l); rest /= nb_l;
                 f = (int)(rest % F);
-                clip = (int)(rest / F);
+                if (!clip_major) clip = (int)(rest / F);
             } else {
                 m = (int)(item % M);
                 unsigned rest = item / M;
