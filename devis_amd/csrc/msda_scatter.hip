@@ -533,6 +533,20 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
     for (int i = tid; i < kOwnPix; i += kOwnThreads) head[i] = kOwnNil;
     __syncthreads();
     const int NB = s_first[L];
+    if (dbg & 512) {
+        // the zero-fill of msda_zero_unowned_kernel, dealt over this kernel's threads: pixels of `value` rows outside every level
+        // (spatial_shapes that do not tile [0, S)); the host only sets the bit when no level takes the float-atomic branch, so
+        // nothing else in this launch writes these pixels
+        const int64_t total = (int64_t)p.groups * p.S;
+        for (int64_t idx = (int64_t)blockIdx.x * kOwnThreads + tid; idx < total; idx += (int64_t)gridDim.x * kOwnThreads) {
+            const int sp = (int)(idx % p.S);
+            bool inside = false;
+            for (int l = 0; l < L; ++l) inside = inside || (sp >= s_lsi[l] && sp < s_lsi[l] + s_H[l] * s_W[l]);
+            if (inside) continue;
+            GV *dst = static_cast<GV *>(p.grad_value) + idx * (p.M * D);
+            for (int c = 0; c < p.M * D; ++c) dst[c] = GV(0.f);
+        }
+    }
     // Long candidate ranges (encoder shapes): the dynamic schedule deals the bands of ALL levels in the order of their
     // position in the image, frames innermost, so that the items an XCD runs at one time read the grad_out rows and the
     // points of the SAME queries (those near that part of the image) from its L2 -- with the bands of one level and frame
