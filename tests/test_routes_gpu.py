@@ -1,0 +1,79 @@
+"""Which kernel family a call takes (msda_last_route) for the shapes the route rules of round 4 were audited on
+(scripts/route_audit.py): a change of a rule that moves one of these shapes to another family shows up
+here, not only as a slower bench line.  Values do not matter (zeros): routes depend on sizes only."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+PYR = {"A": [(45, 80), (23, 40), (12, 20), (6, 10)], "S": [(60, 96), (30, 48), (15, 24), (8, 12)], "B": [(100, 167), (50, 84), (25, 42), (13, 21)]}
+DEV = "cuda:0"
+
+
+def _temporal(pyr, clips, Lq, dtype, T=6):
+    from devis_amd import _native
+    shapes = torch.tensor(PYR[pyr], dtype=torch.int64, device=DEV)
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S, M, D, L, P, W = int(shapes.prod(1).sum()), 8, 32, 4, 4, T - 1
+    if Lq is None:
+        Lq = S
+    ftab = torch.tensor([[t for t in range(T) if t != f] for f in range(T)], dtype=torch.int32, device=DEV)
+    value = torch.zeros(clips * T, S, M, D, dtype=dtype, device=DEV)
+    loc_c = torch.full((clips * T, Lq, M, L, P, 2), 0.5, dtype=dtype, device=DEV)
+    aw_c = torch.zeros(clips * T, Lq, M, L, P, dtype=dtype, device=DEV)
+    loc_t = torch.full((clips * T, Lq, M, W * L, P, 2), 0.5, dtype=dtype, device=DEV)
+    aw_t = torch.zeros(clips * T, Lq, M, W * L, P, dtype=dtype, device=DEV)
+    out = torch.empty(clips * T, Lq, M * D, dtype=dtype, device=DEV)
+    _native.temporal_forward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, clips, out)
+    fwd = _native.last_route()
+    gv = torch.empty(value.shape, dtype=_native.grad_value_dtype(value, shapes, Lq, L, P, clips=clips, window=W, Pt=P), device=DEV)
+    grads = [torch.empty_like(x) for x in (loc_c, aw_c, loc_t, aw_t)]
+    _native.temporal_backward(value, shapes, lsi, ftab, loc_c, aw_c, loc_t, aw_t, torch.zeros_like(out), clips, gv, *grads)
+    torch.cuda.synchronize()
+    return fwd, _native.last_route()
+
+
+@pytest.mark.parametrize("pyr,clips,Lq,dtype,fwd_has,bwd_has", [
+    # the call DeVIS issues: tile forward, gather pass on the slab kernel with the frames as a workgroup index
+    ("A", 1, 300, torch.float32, "tile kernel", "one source frame per workgroup"),
+    ("B", 1, 300, torch.bfloat16, "tile kernel", "one source frame per workgroup"),
+    # the bench batch
+    ("A", 16, 300, torch.float32, "resident-slab kernel, 1 tiles per wave", "one source frame per workgroup"),
+    ("A", 16, 300, torch.bfloat16, "resident-slab kernel, 4 tiles per wave", "one source frame per workgroup"),
+    # large maps outside the slab: no frame split (12-20 % slower there)
+    ("B", 16, 300, torch.float32, "resident-slab kernel, 1 tiles per wave", "resident-slab kernel, grad_loc/grad_attn)"),
+    ("S", 16, 300, torch.float32, "resident-slab kernel, 1 tiles per wave", "resident-slab kernel, grad_loc/grad_attn)"),
+    ("S", 16, 300, torch.bfloat16, "resident-slab kernel", "one source frame per workgroup"),
+    # encoder-shaped calls: slab kernels while three levels fit, window kernels when a 4-byte slab holds two or fewer
+    ("A", 1, None, torch.float32, "resident-slab kernel, 2 tiles per wave", "resident-slab kernel"),
+    ("A", 1, None, torch.bfloat16, "resident-slab kernel, 4 tiles per wave", "resident-slab kernel"),
+    ("S", 1, None, torch.float32, "resident-window kernel", "resident-window kernel"),
+    ("S", 1, None, torch.bfloat16, "resident-slab kernel, 2 tiles per wave", "resident-slab kernel"),
+], ids=lambda v: str(v).replace("torch.", "") if not isinstance(v, str) or len(v) < 3 else None)
+def test_temporal_call_routes(pyr, clips, Lq, dtype, fwd_has, bwd_has):
+    fwd, bwd = _temporal(pyr, clips, Lq, dtype)
+    assert fwd_has in fwd, fwd
+    assert bwd_has in bwd, bwd
+    assert "owner-computes scatter" in bwd, bwd
+    # the zero-fill rides in the scatter kernel when every level fits a band
+    assert "zero-fill" not in bwd, bwd
+
+
+def test_single_frame_decoder_like_call_on_a_sparse_fp32_slab_takes_the_tile_forward():
+    """36 images x 300 queries on the SwinL pyramid in fp32: the slab would start at level 2 and 19 tiles would sit on 2 x 16
+    waves -- the tile forward is 30 % faster there (the gather pass stays on the slab kernel)."""
+    from devis_amd import _native
+    shapes = torch.tensor(PYR["S"], dtype=torch.int64, device=DEV)
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S, N, Lq = int(shapes.prod(1).sum()), 36, 300
+    value = torch.zeros(N, S, 8, 32, device=DEV)
+    loc = torch.full((N, Lq, 8, 4, 4, 2), 0.5, device=DEV)
+    aw = torch.zeros(N, Lq, 8, 4, 4, device=DEV)
+    out = torch.empty(N, Lq, 256, device=DEV)
+    _native.forward(value, shapes, lsi, loc, aw, out)
+    assert "tile kernel" in _native.last_route(), _native.last_route()
+    value_a = torch.zeros(N, 4820, 8, 32, device=DEV)
+    shapes_a = torch.tensor(PYR["A"], dtype=torch.int64, device=DEV)
+    lsi_a = torch.cat((shapes_a.new_zeros(1), shapes_a.prod(1).cumsum(0)[:-1]))
+    _native.forward(value_a, shapes_a, lsi_a, loc, aw, out)
+    assert "resident-slab kernel" in _native.last_route(), _native.last_route()
