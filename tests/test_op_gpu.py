@@ -542,6 +542,33 @@ def test_grad_value_is_overwritten(route, monkeypatch):
     assert _maxabs(got[:, :S0], ref[1]) <= 2e-5 * max(1.0, np.abs(ref[1]).max())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_storage_typed_grad_value_is_overwritten_outside_the_levels(dtype):
+    """The same contract for a 16-bit grad_value written by the scatter itself (ABI v10): pixel rows of `value` that belong to
+    no level come back as zeros (round 4: from the scatter kernel's own prologue when the host knows the shapes)."""
+    from devis_amd import _native
+    rng = np.random.default_rng(6)
+    shapes = [(9, 7), (5, 4), (3, 2)]
+    d = round_to(make_inputs(6, 3, 8, 32, 41, shapes, 4), dtype)
+    pad = 7
+    value = np.concatenate([d["value"], rng.standard_normal((3, pad, 8, 32))], axis=1)
+    ref = oracle_fwd_bwd(d)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in d.items()}
+    v = torch.from_numpy(value).to(DEV, dtype)
+    loc, aw, go = t["loc"].to(dtype), t["aw"].to(dtype), t["grad_out"].to(dtype).contiguous()
+    gvt = _native.grad_value_dtype(v, t["shapes"], 41, 3, 4)
+    assert gvt == dtype
+    gv = torch.full(v.shape, float("nan"), device=DEV, dtype=gvt)
+    gl, ga = torch.empty_like(loc), torch.empty_like(aw)
+    _native.backward(v, t["shapes"], t["lsi"], loc, aw, go, gv, gl, ga)
+    assert "owner-computes" in _native.last_route() and "zero-fill" not in _native.last_route(), _native.last_route()
+    got = gv.float().cpu().numpy()
+    S0 = d["value"].shape[1]
+    assert np.isfinite(got).all()
+    assert (got[:, S0:] == 0).all()
+    assert _maxabs(got[:, :S0], ref[1]) <= 2e-2 * max(1.0, np.abs(ref[1]).max())
+
+
 @pytest.mark.parametrize("route", ["default", "tile", "atomic", "generic"])
 def test_head_major_value_layout(route, monkeypatch):
     """value stored head-major ([M, N, S, D] memory behind the same [N, S, M, D] shape; include/msda.h
