@@ -417,8 +417,13 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             // (only where the slab starts at level 2 in a 4-byte type, i.e. saves the least: elsewhere, and in the gather pass, the slab
             // kernels stay ahead by 4-19 %)
             if (mode != 1 && nt && esz == 4 && l0_host >= 2 && 10LL * rs_tiles_per_clip < 7LL * parts * kRsWaves * nt) nt = 0;
-            if (mode != 0 && nt && clips * p.M * parts <= 0x7fffffffLL)
-                return launch_fwd_rs(dtype, nt, l0_host, p, parts, (unsigned)(clips * p.M * parts), stream);
+            if (mode != 0 && nt && clips * p.M * parts <= 0x7fffffffLL) {
+                // fp32, one tile per wave, slab from level 2 on: the software-pipelined slot body of that instantiation spills 31 VGPRs
+                // and its plain loop (the kernel compiled for a level-1 slab falls back to it) is 16-27 % faster on the SwinL pyramid
+                // (decoder call, 4 / 16 / 32 clips: 0.175 -> 0.137, 0.644 -> 0.540, 1.178 -> 0.973 ms; 800x1333: the same)
+                const int body_l0 = (esz == 4 && nt == 1 && l0_host >= 2) ? 1 : l0_host;
+                return launch_fwd_rs(dtype, nt, body_l0, p, parts, (unsigned)(clips * p.M * parts), stream);
+            }
         }
         return launch_fwd_tile(dtype, G, p, (unsigned)blocks, lds, stream);
     }
