@@ -476,8 +476,9 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
                 fparts = (p.frames > 1 && small_outside && wgs >= 3LL * device_cus() && (esz == 2 || wgs < 24LL * device_cus())) ? 2 : 0;
                 // fp32 batches whose (clip, head, part) workgroups are a single round over the CUs (4 clips): four workgroups per (clip,
                 // head, frame) balance better -- 0.103 -> 0.099 / 0.177 -> 0.149 / 0.259 -> 0.242 ms on the three audited pyramids;
-                // 2-byte types lose 2-14 % there and stay
-                if (!fparts && tpw && esz == 4 && mode == -1 && p.frames > 1 && l0_host <= p.L - 1 && clips * p.M * parts <= device_cus()) fparts = 4;
+                // 2-byte types lose 2-14 % there and stay, and so do encoder-shaped calls (one clip is 232 workgroups of 4 tiles: 0.36 vs
+                // 0.47 ms on the frame-split grid)
+                if (!fparts && tpw && esz == 4 && mode == -1 && p.frames > 1 && p.Lq != p.S && l0_host <= p.L - 1 && clips * p.M * parts <= device_cus()) fparts = 4;
                 if (!fparts && !tpw && mode == -1 && p.frames > 1 && l0_host <= p.L - 1 && clips * p.M * p.frames * 4 >= device_cus() / 2 &&
                     rs_tiles_per_clip >= 4 * kRsWaves) {                   // (every wave of the 4 workgroups of a (clip, head, frame) gets a tile)
                     // (2-byte types with two clips: 2 workgroups per (clip, head, frame) -- 0.067 -> 0.056 ms; fp32 the other way round)

@@ -45,10 +45,13 @@ def _temporal(pyr, clips, Lq, dtype, T=6):
     ("S", 16, 300, torch.float32, "resident-slab kernel, 1 tiles per wave", "resident-slab kernel, grad_loc/grad_attn)"),
     ("S", 16, 300, torch.bfloat16, "resident-slab kernel", "one source frame per workgroup"),
     # encoder-shaped calls: slab kernels while three levels fit, window kernels when a 4-byte slab holds two or fewer
-    ("A", 1, None, torch.float32, "resident-slab kernel, 2 tiles per wave", "resident-slab kernel"),
-    ("A", 1, None, torch.bfloat16, "resident-slab kernel, 4 tiles per wave", "resident-slab kernel"),
+    ("A", 1, None, torch.float32, "resident-slab kernel, 2 tiles per wave", "resident-slab kernel, grad_loc/grad_attn)"),
+    ("A", 1, None, torch.bfloat16, "resident-slab kernel, 4 tiles per wave", "resident-slab kernel, grad_loc/grad_attn)"),
     ("S", 1, None, torch.float32, "resident-window kernel", "resident-window kernel"),
-    ("S", 1, None, torch.bfloat16, "resident-slab kernel, 2 tiles per wave", "resident-slab kernel"),
+    ("S", 1, None, torch.bfloat16, "resident-slab kernel, 2 tiles per wave", "resident-slab kernel, grad_loc/grad_attn)"),
+    # four clips in fp32: one round of (clip, head, part) workgroups -> the frame-split grid; not in 2-byte types
+    ("A", 4, 300, torch.float32, "resident-slab kernel, 1 tiles per wave", "one source frame per workgroup"),
+    ("A", 4, 300, torch.bfloat16, "resident-slab kernel, 1 tiles per wave", "resident-slab kernel, grad_loc/grad_attn)"),
 ], ids=lambda v: str(v).replace("torch.", "") if not isinstance(v, str) or len(v) < 3 else None)
 def test_temporal_call_routes(pyr, clips, Lq, dtype, fwd_has, bwd_has):
     fwd, bwd = _temporal(pyr, clips, Lq, dtype)
