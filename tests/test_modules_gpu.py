@@ -189,3 +189,30 @@ def test_temporal_decoder_module_is_graph_capturable():
         assert torch.allclose(out_g, out_e, rtol=1e-5, atol=1e-6)
         for x, y in zip(gg, ge):
             assert torch.allclose(x, y, rtol=1e-4, atol=1e-5 * float(y.abs().max()))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2), (torch.float16, 4e-3)], ids=["f32", "bf16", "f16"])
+def test_value_proj_gradients_at_clip_size_through_the_split_k_product(dtype, tol):
+    """`project_value` at the size of one DeVIS clip (T x S = 28 920 rows, 256 -> 256): its backward computes the weight gradient as
+    a batched product over row slices (`_split_k_wgrad`, round 4); all three gradients against the fp64 products of the same rounded
+    inputs, the slices' partial sums being added in the storage type."""
+    from devis_amd.functions import project_value
+    gen = torch.Generator().manual_seed(17)
+    T, S, C, M = 6, 4820, 256, 8
+    lin = torch.nn.Linear(C, C)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(C, C, generator=gen) * 0.05)
+        lin.bias.copy_(torch.randn(C, generator=gen) * 0.05)
+    x = torch.randn(T, S, C, generator=gen)
+    g = torch.randn(T, S, M, C // M, generator=gen)
+    lin_d = lin.to("cuda:0", dtype)
+    x_d = x.to("cuda:0", dtype).requires_grad_(True)
+    g_d = g.to("cuda:0", dtype)
+    out = project_value(x_d, lin_d, M, None, 1)
+    gx, gw, gb = torch.autograd.grad(out, (x_d, lin_d.weight, lin_d.bias), g_d)
+    x64, g64 = x_d.detach().double().cpu().reshape(-1, C), g_d.double().cpu().reshape(-1, C)
+    w64 = lin_d.weight.detach().double().cpu()
+    want = (g64 @ w64, g64.t() @ x64, g64.sum(0))
+    for got, ref in zip((gx.reshape(-1, C), gw, gb), want):
+        err = float((got.double().cpu() - ref).abs().max())
+        assert err <= tol * max(1.0, float(ref.abs().max())), (err, float(ref.abs().max()))
