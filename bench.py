@@ -638,7 +638,8 @@ def main():
 
         fwd_ms, fwd_med = time_kernel(lambda: _native.temporal_forward(
             dv[0], b["shapes"], b["lsi"], b["ftab"], dv[1], dv[2], dv[3], dv[4], args.clips, out), 20)
-        fwd_name = kernel_name(_native.last_route(), "forward")     # the kernels the library actually launched
+        routes = {"forward": _native.last_route()}
+        fwd_name = kernel_name(routes["forward"], "forward")        # the kernels the library actually launched
         # the backward entry point launches two kernels; MSDA_BWD_PHASES lets each be timed alone
         ws = _native.bwd_workspace(device, args.clips * T, q, M, L * (1 + W))
         def bwd():
@@ -652,11 +653,13 @@ def main():
         os.environ["MSDA_BWD_PHASES"] = "1"
         _native.reload_knobs()
         gat_ms, gat_med = time_kernel(bwd, 20)
-        gat_name = kernel_name(_native.last_route(), "gather")
+        routes["gather_pass"] = _native.last_route()
+        gat_name = kernel_name(routes["gather_pass"], "gather")
         os.environ["MSDA_BWD_PHASES"] = "2"
         _native.reload_knobs()
         sca_ms, sca_med = time_kernel(bwd, 20)
-        sca_name = kernel_name(_native.last_route(), "scatter")
+        routes["scatter"] = _native.last_route()
+        sca_name = kernel_name(routes["scatter"], "scatter")
         os.environ.pop("MSDA_BWD_PHASES")
         os.environ.pop("MSDA_ENABLE_HOOKS")
         _native.reload_knobs()
@@ -694,7 +697,8 @@ def main():
                                  "algorithmic_GBps": round(v[2] * args.clips / (v[0] * 1e-3) / 1e9, 1),
                                  "frac_of_hbm_peak": round(v[2] * args.clips / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                              for k, v in kernels.items()},
-                 "forward_M_queries_per_s": round(args.clips * T * q / (fwd_ms * 1e-3) / 1e6, 2)}
+                 "forward_M_queries_per_s": round(args.clips * T * q / (fwd_ms * 1e-3) / 1e6, 2),
+                 "routes": routes}       # msda_last_route() of the three launches timed above: which kernel family ran, as the library says
 
     # ---- CPU baseline: the reference's pure-PyTorch path on the host cores (bounded sample) -----
     cpu = None
