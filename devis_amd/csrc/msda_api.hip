@@ -456,8 +456,8 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             // One source frame per workgroup (round 4): the gather pass carries nothing from frame to frame, so (clip, head, frame,
             // half of the clip's tiles) workgroups stage ONE slab each and meet at no barrier afterwards -- a quarter of the staging
             // traffic of (clip, head, part) workgroups walking the frames.  Pays from ~8 clips on (same box, fp32:
-            // 8 / 16 / 32 clips 0.245 -> 0.229 / 0.48 -> 0.44 / 0.881 -> 0.874 ms; 4 clips 0.100 -> 0.122: too few workgroups per
-            // frame map in one L2).
+            // 8 / 16 / 32 clips 0.245 -> 0.229 / 0.48 -> 0.44 / 0.881 -> 0.874 ms; 4 clips with TWO workgroups per frame
+            // 0.100 -> 0.122 -- with four it pays there too, see below).
             // SMALL batches -- the one clip per GPU DeVIS itself issues (main.py:85) -- cannot fill the chip with (clip, head, part)
             // workgroups at all (tpw = 0) and used to fall to the tile kernels: with the frames as a workgroup index 1 / 2 clips make
             // 192 / 384 workgroups of <= 2 tiles per wave (same box, gather pass of 1 clip fp32 0.058 -> 0.040 ms, bf16 0.074 -> 0.037;
@@ -473,7 +473,12 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
                 const long long wgs = clips * p.M * p.frames * 2;
                 // (route audit, profiles/r04_logs/route_audit_*.log: SwinL pyramid in fp32, 737 KB outside, 8-32 clips 14-20 % slower)
                 const bool small_outside = host_pixels_below(p, l0_host) * rs_row <= (512ll << 10);
-                fparts = (p.frames > 1 && small_outside && wgs >= 3LL * device_cus() && (esz == 2 || wgs < 24LL * device_cus())) ? 2 : 0;
+                // (encoder-shaped batches: 8 clips at 360x640 in fp32 2.50 -> 2.80 ms on this grid, in bf16 2.49 -> 2.13)
+                fparts = (p.frames > 1 && small_outside && wgs >= 3LL * device_cus() &&
+                          (esz == 2 || (wgs < 24LL * device_cus() && p.Lq != p.S))) ? 2 : 0;
+                // (2-byte encoder-shaped batches one size below that: four workgroups per frame at 4 clips, 1.23 -> 1.13 ms at 360x640,
+                // 1.94 -> 1.80 on the SwinL pyramid)
+                if (!fparts && esz == 2 && p.frames > 1 && p.Lq == p.S && small_outside && 2 * wgs >= 3LL * device_cus()) fparts = 4;
                 // fp32 batches whose (clip, head, part) workgroups are a single round over the CUs (4 clips): four workgroups per (clip,
                 // head, frame) balance better -- 0.103 -> 0.099 / 0.177 -> 0.149 / 0.259 -> 0.242 ms on the three audited pyramids;
                 // 2-byte types lose 2-14 % there and stay, and so do encoder-shaped calls (one clip is 232 workgroups of 4 tiles: 0.36 vs

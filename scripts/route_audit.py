@@ -1,6 +1,6 @@
 """GPU probe: is the AUTOMATIC route of the forward / gather pass the fastest one the library has, shape by shape?
 
-    python scripts/route_audit.py [quick | plain | scatter]
+    python scripts/route_audit.py [quick | enc | plain | scatter]
 
 Temporal decoder calls (300 queries per frame) and encoder calls (every pixel a query, local sampling) on three pyramids -- 360x640,
 SwinL 480x768 and 800x1333 -- at several batch sizes and storage types; every forced alternative that applies is timed after the
@@ -68,8 +68,10 @@ def main():
         for dtype in (torch.float32, torch.bfloat16):
             for clips in ((1, 16) if quick else (1, 2, 4, 8, 16, 32)):
                 cases.append(("dec", pyr, clips, dtype))
-            for clips in ((1,) if quick else (1, 2)):
+            for clips in ((1,) if quick else ((1, 2) if pyr == "B" else (1, 2, 4, 8))):
                 cases.append(("enc", pyr, clips, dtype))
+    if len(sys.argv) > 1 and sys.argv[1] == "enc":
+        cases = [c for c in cases if c[0] == "enc"]
     if len(sys.argv) > 1 and sys.argv[1] == "scatter":
         # grad_value scatter: automatic against the level-by-level item order and the static schedule
         alts = (("level order", {"MSDA_SCATTER_DBG": 256}), ("static", {"MSDA_SCATTER_DBG": 16}))
