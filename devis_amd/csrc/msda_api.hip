@@ -484,9 +484,11 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
                 // 2-byte types lose 2-14 % there and stay, and so do encoder-shaped calls (one clip is 232 workgroups of 4 tiles: 0.36 vs
                 // 0.47 ms on the frame-split grid)
                 if (!fparts && tpw && esz == 4 && mode == -1 && p.frames > 1 && p.Lq != p.S && l0_host <= p.L - 1 && clips * p.M * parts <= device_cus()) fparts = 4;
-                if (!fparts && !tpw && mode == -1 && p.frames > 1 && l0_host <= p.L - 1 && clips * p.M * p.frames * 4 >= device_cus() / 2 &&
-                    rs_tiles_per_clip >= 4 * kRsWaves) {                   // (every wave of the 4 workgroups of a (clip, head, frame) gets a tile)
+                if (!fparts && !tpw && mode == -1 && p.frames > 1 && l0_host <= p.L - 1 && clips * p.M * p.frames * 4 >= device_cus() / 2) {
                     // (2-byte types with two clips: 2 workgroups per (clip, head, frame) -- 0.067 -> 0.056 ms; fp32 the other way round)
+                    // Whatever the query count -- DeVIS's shipped configs run 60 queries per frame (YouTube-VIS) and 180 (OVIS), 24 / 72
+                    // tiles per clip: one clip of 60 queries 0.050 -> 0.020 ms in fp32, 0.065 -> 0.020 in fp16, 10 queries 0.042 -> 0.018
+                    // (the tile kernels walk a chain of 24 dependent gather batches per wave however few rows there are)
                     fparts = (esz == 2 && clips * p.M * p.frames * 2 >= 3LL * device_cus() / 4) ? 2 : 4;
                     want_small = true;
                 }
