@@ -415,3 +415,24 @@ def test_non_finite_pixels_nobody_samples_do_not_leak(env, dtype, monkeypatch):
         if i in (2, 4) and dtype != torch.float32:
             continue                                                     # grad_loc at 16-bit: cell borders, tested elsewhere
         assert _maxabs(a, b) <= tol * max(1.0, np.abs(b).max()), i
+
+
+@pytest.mark.parametrize("dtype,tol,tol_loc", [(torch.float32, 2e-5, 2e-4), (torch.float16, 2e-3, 1e-2)], ids=["f32", "f16"])
+@pytest.mark.parametrize("Lq", [60, 180, 7], ids=["yt-vis-60", "ovis-180", "q7"])
+def test_one_clip_at_the_query_counts_of_the_shipped_configs(Lq, dtype, tol, tol_loc):
+    """DeVIS's shipped configs run 60 (YouTube-VIS) / 180 (OVIS) queries per frame, not the code's default of 300:
+    one clip, T = 6, connect-all, on the 360x640 pyramid, against the fp64 oracle on the same rounded inputs.  The gather pass of such
+    a call takes the resident-slab kernel with one source frame per workgroup (round 4) -- also with 7 queries, a fraction of a tile."""
+    T = 6
+    d = round_to(make_temporal_inputs(2100 + Lq, T=T, W=T - 1, M=8, D=32, Lq=Lq, shapes=PYR_A, Pc=4, Pt=4, dtype=np.float64), dtype)
+    routes = []
+    got = _run_temporal(d, dtype, 1, routes)
+    assert "one source frame per workgroup" in routes[0] and "owner-computes" in routes[0], routes
+    keys = ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")
+    ref = temporal_reference(*[np.asarray(d[k], dtype=np.float64) if d[k].dtype.kind == "f" else d[k] for k in keys])
+    ref32 = temporal_reference(*[np.asarray(d[k], dtype=np.float32) if d[k].dtype.kind == "f" else d[k] for k in keys]) \
+        if dtype == torch.float32 else ref
+    for i, (a, b) in enumerate(zip(got, ref)):
+        want = ref32[i] if i in (2, 4) else b              # fp32 grad_loc: same-arithmetic oracle (cell borders)
+        bound = (tol_loc if i in (2, 4) else tol) * max(1.0, np.abs(want).max())
+        assert _maxabs(a, want) <= bound, (i, _maxabs(a, want), bound)
