@@ -258,6 +258,31 @@ def other_configs(args, device):
         del graph
     except Exception as exc:       # (reported, never fatal for the headline)
         res["single_clip_graph"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    # (i-b'') the same call at the query count of DeVIS's shipped YouTube-VIS configs (60 per frame; 300 is the code's default and
+    # BASELINE's figure): forward + backward of one clip, eager and replayed from a HIP graph
+    saved_queries = args.queries
+    try:
+        args.queries = 60
+        step60, fwd60, rows60 = fused_case(1, "uniform", torch.float32)
+        entry = {"workload": "ONE clip, T=%d x 60 queries per frame (the shipped YouTube-VIS configs), fused call, f32" % args.frames,
+                 "fwd_bwd_ms": round(_event_ms(step60, 30, 10), 4), "fwd_ms": round(_event_ms(fwd60, 30, 10), 4)}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step60()
+        torch.cuda.current_stream().wait_stream(side)
+        graph60 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph60):
+            step60()
+        entry["graph_fwd_bwd_ms"] = round(_event_ms(graph60.replay, 30, 10), 4)
+        entry["M_queries_per_s_graph"] = round(rows60 / entry["graph_fwd_bwd_ms"] / 1e3, 3)
+        res["single_clip_60_queries"] = entry
+        del graph60, step60, fwd60
+    except Exception as exc:
+        res["single_clip_60_queries"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    finally:
+        args.queries = saved_queries
     # (i-b') the same at MODULE level: TemporalMSDeformAttnDecoder of one clip, forward + backward incl. its Linears -- eager with
     # the fused single launch, eager in the reference's call pattern (2*T operator calls + T value gathers per layer,
     # ms_deform_attn.py:325-364), and captured with torch.cuda.make_graphed_callables

@@ -41,7 +41,7 @@ def main():
     worse = []
     # host-side times: they follow the box's CPU, not the kernels (the small plain calls of configs[4] run 0.03-0.07 ms of kernels
     # under 0.09-0.25 ms of Python + autograd: the same build measured 0.085 and 0.18 ms on one box within a minute)
-    host_bound = ("eager", "single_clip_latency", "cpu_baseline", "cfg4_swinl_fp16_decoder_like", "cfg4_mask_head_like")
+    host_bound = ("eager", "single_clip_latency", "single_clip_60_queries.fwd", "cpu_baseline", "cfg4_swinl_fp16_decoder_like", "cfg4_mask_head_like")
     print("%-110s %10s %10s %8s" % ("time (ms)", "before", "after", "ratio"))
     for k in sorted(set(old) & set(new)):
         r = new[k] / old[k] if old[k] > 0 else float("nan")
