@@ -46,6 +46,7 @@ size_t tile_lds_bytes(int rpw, int nvl, bool bwd, bool intervals = false)
 struct Knobs {
     int fwd_rs = -1, fwd_rs_nt = 0;     // resident-slab forward: -1 auto, 0 off, 1 force; tiles per wave (0 = auto)
     int bwd_rs = -1, bwd_rs_tpw = 0;    // resident-slab gather pass: -1 auto, 0 off, 1 force; tiles per wave (0 = auto)
+    int fwd_tile_waves = -1;            // forward tile kernel: waves per tile (-1 auto)
     int bwd_rs_fsplit = -1;             // gather pass with one source frame per workgroup: parts per (clip, head, frame); -1 auto, 0 off
     int fwd_win = -1, bwd_win = -1;     // resident-window kernels (encoder-shaped calls): -1 auto, 0 off, 1 force
     int win_min_halo = 5;               // narrowest halo a window plan may have; one staging phase is preferred from here on (5 holds
@@ -76,6 +77,7 @@ void load_knobs()
         k.fwd_rs = env_int("MSDA_FWD_RS", k.fwd_rs); k.fwd_rs_nt = env_int("MSDA_FWD_RS_NT", k.fwd_rs_nt);
         k.bwd_rs = env_int("MSDA_BWD_RS", k.bwd_rs); k.bwd_rs_tpw = env_int("MSDA_BWD_RS_TPW", k.bwd_rs_tpw);
         k.bwd_rs_fsplit = env_int("MSDA_BWD_RS_FSPLIT", k.bwd_rs_fsplit);
+        k.fwd_tile_waves = env_int("MSDA_FWD_TILE_WAVES", k.fwd_tile_waves);
         k.fwd_win = env_int("MSDA_FWD_WIN", k.fwd_win); k.bwd_win = env_int("MSDA_BWD_WIN", k.bwd_win);
         k.win_min_halo = env_int("MSDA_WIN_MIN_HALO", k.win_min_halo);
         const char *mode = getenv("MSDA_BWD_MODE");
@@ -425,7 +427,20 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
                 return launch_fwd_rs(dtype, nt, body_l0, p, parts, (unsigned)(clips * p.M * parts), stream);
             }
         }
-        return launch_fwd_tile(dtype, G, p, (unsigned)blocks, lds, stream);
+        // SMALL forwards -- one clip at the 60 / 180 queries per frame of DeVIS's shipped configs is 192-1104 single-wave workgroups on
+        // 1024 SIMDs, each walking its rows' 96 points as a chain of dependent gather batches -- put THREE waves on a tile, each with
+        // a share of the tile's 16-point chunks, partial rows added through LDS in wave order (msda_fwd_tile_kernel, MW): 60 queries
+        // fp32 0.020 -> 0.013 ms, fp16 0.034 -> 0.015; 180 queries fp16 0.041 -> 0.027; 300 queries bf16 0.043 -> 0.031.  With more
+        // workgroups than SIMDs (fp32 from 180 queries on) the chip is busy anyway and the split only adds the exchange
+        // (profiles/r04_logs/small_batch_tile_waves.log: no gain at 1824 workgroups).
+        const int chunks = (p.LA * p.PA + kPch - 1) / kPch + (p.LB * p.PB + kPch - 1) / kPch;
+        int waves = knobs().fwd_tile_waves;
+        if (waves < 0) waves = blocks <= (esz == 4 ? 768 : 1024) ? 3 : 1;
+        waves = std::max(1, std::min(std::min(waves, chunks), kTileMaxWaves));
+        if (!(G == 4 || G == 8)) waves = 1;
+        auto lds_of = [&](int w) { return (size_t)w * RPW * kRowSlots * 32 + (size_t)(p.LA + p.LB) * sizeof(Level) + (size_t)w * kWave * VEC * 4; };
+        while (waves > 1 && lds_of(waves) > 48 * 1024) --waves;
+        return launch_fwd_tile(dtype, G, p, (unsigned)blocks, waves > 1 ? lds_of(waves) : lds, stream, waves);
     }
     if (!scatter_applicable(p)) {
         if (p.gv_storage) return fail(MSDA_ERR_ARG, "msda backward: this call needs grad_value in the arithmetic type (see msda_grad_value_dtype)%s");

@@ -376,6 +376,7 @@ __device__ __forceinline__ void load_xy(const f16_t *loc2, float &x, float &y)
 // launch geometry shared by kernels and dispatcher
 // ------------------------------------------------------------------------------------------------
 constexpr int kRowSlots = kPch + 1;         // tile kernels: 16-byte record slots per row (odd: LDS banks)
+constexpr int kTileMaxWaves = 8;            // forward tile kernel: waves of one workgroup that share a tile (small calls)
 // owner-computes scatter
 #ifndef MSDA_OWN_THREADS
 #define MSDA_OWN_THREADS 1024
@@ -477,7 +478,7 @@ int dispatch_types(int dtype, F &&f)
 
 // ---- per-family launchers (each translation unit owns its kernels; MSDA_OK or a negative msda_status) ----
 // msda_tile.hip: G = D / (16 / sizeof(T)) lanes per row, one wave per workgroup
-int launch_fwd_tile(int dtype, int G, const Params &p, unsigned blocks, size_t lds, hipStream_t stream);
+int launch_fwd_tile(int dtype, int G, const Params &p, unsigned blocks, size_t lds, hipStream_t stream, int waves = 1);
 int launch_bwd_tile(int dtype, int G, bool atomics, const Params &p, unsigned blocks, size_t lds, hipStream_t stream);
 // msda_rs.hip: resident-slab kernels (D = 32); nt = tiles per wave of the forward (1, 2, 4); first_slab_level = the host's
 // guess of the first pyramid level inside the slab (1 or 2: picks the kernel whose software-pipelined slot body is compiled

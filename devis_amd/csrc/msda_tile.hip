@@ -137,24 +137,37 @@ __device__ __forceinline__ void build_chunk(const Params &p, const ChunkRef<TL> 
 
 // NB = sampling points whose 4*NB corner loads are issued back to back before any FMA consumes them
 // (memory-level parallelism per wave); more points in flight cost VGPRs, i.e. waves per SIMD.
-template <typename T, typename TL, int G, int NB>       // T: value / out, TL: sampling_loc / attn_weight
-__global__ void __launch_bounds__(kWave, 4)
+// MW (round 4): SMALL calls -- one clip at the query counts of DeVIS's shipped configs (60 / 180 per frame) is a few hundred
+// single-wave workgroups on 1024 SIMDs, each walking its rows' 96 points as ~24 dependent batches of gathers: latency-bound.  With
+// MW a workgroup is blockDim.x / 64 waves on the SAME tile: wave w takes the chunks w, w + nw, ... (its own record slots in LDS,
+// no workgroup barrier inside the loop) and the partial rows are added up through LDS in wave order at the end -- the same sums
+// on every run.  The host uses it (3 waves) while the workgroups are fewer than the SIMDs (msda_api.hip): 60 queries 0.020 ->
+// 0.013 ms (fp16 0.034 -> 0.015); at 300 queries in fp32 (1824 workgroups) it changes nothing.
+template <typename T, typename TL, int G, int NB, bool MW>       // T: value / out, TL: sampling_loc / attn_weight
+__global__ void __launch_bounds__(MW ? kWave * kTileMaxWaves : kWave, 4)
 msda_fwd_tile_kernel(const Params p)
 {
     constexpr int VEC = Store<T>::VEC;
     constexpr int RPW = kWave / G;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    int4 *s_off = reinterpret_cast<int4 *>(lds_raw);
-    float4 *s_w = reinterpret_cast<float4 *>(s_off + RPW * kRowSlots);
-    Level *s_lvl = reinterpret_cast<Level *>(s_w + RPW * kRowSlots);
+    const int lane = threadIdx.x % kWave;
+    const int wave = MW ? __builtin_amdgcn_readfirstlane(threadIdx.x / kWave) : 0, nw = MW ? (int)blockDim.x / kWave : 1;
+    int4 *s_off = reinterpret_cast<int4 *>(lds_raw) + wave * (RPW * kRowSlots);
+    float4 *s_w = reinterpret_cast<float4 *>(reinterpret_cast<int4 *>(lds_raw) + nw * (RPW * kRowSlots)) + wave * (RPW * kRowSlots);
+    Level *s_lvl = reinterpret_cast<Level *>(reinterpret_cast<int4 *>(lds_raw) + 2 * nw * (RPW * kRowSlots));
 
-    const int lane = threadIdx.x;
     int m, group, q0;
     tile_coords<RPW>(p, m, group, q0);
     const int clip = group / p.frames, t = group - clip * p.frames;
     const int nvl = p.LA + p.LB;
-    for (int j = lane; j < nvl; j += kWave) s_lvl[j] = make_level(p, t, j);
+    for (int j = threadIdx.x; j < nvl; j += (int)blockDim.x) s_lvl[j] = make_level(p, t, j);
     __syncthreads();
+    // the records of a chunk are written and read by ONE wave: its LDS operations complete in order, so with MW a compiler
+    // fence + s_waitcnt replaces the workgroup barrier (the waves of a workgroup run different numbers of chunks)
+    auto chunk_sync = [&]() {
+        if constexpr (MW) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else __syncthreads();
+    };
 
     const int r = lane / G, sub = lane % G;
     const int rows_valid = min(RPW, p.Lq - q0);
@@ -174,11 +187,11 @@ msda_fwd_tile_kernel(const Params p)
     // (measured: 0.73 -> 0.82 ms); the other waves of the SIMD cover the stage phase instead.
     Staged<staged_per_lane<RPW>()> st;
 #pragma unroll 1
-    for (int ci = 0; ci < n_all; ++ci) {
+    for (int ci = wave; ci < n_all; ci += nw) {
         const ChunkRef<TL> c = get_chunk<TL>(p, ci, nA);
         load_chunk<TL, RPW>(p, c, row0, rows_valid, lane, st);
         build_chunk<T, RPW, false>(p, c, st, s_lvl, s_off, s_w, nullptr, lane);
-        __syncthreads();
+        chunk_sync();
         const int np = min(kPch, c.LP - c.p0);
         const int4 *ro = s_off + r * kRowSlots;
         const float4 *rw = s_w + r * kRowSlots;
@@ -208,7 +221,19 @@ msda_fwd_tile_kernel(const Params p)
                 }
             }
         }
+        chunk_sync();
+    }
+    if constexpr (MW) {
+        float *s_red = reinterpret_cast<float *>(s_lvl + nvl);          // [nw][64][VEC]
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) s_red[(wave * kWave + lane) * VEC + c] = acc[c];
         __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[c] = s_red[lane * VEC + c];
+        for (int w = 1; w < nw; ++w)
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) acc[c] += s_red[(w * kWave + lane) * VEC + c];
     }
     if (r < rows_valid) {
         T *out = static_cast<T *>(p.out) + (row0 + (int64_t)r * p.M) * p.D + sub * VEC;
@@ -436,12 +461,18 @@ msda_bwd_tile_kernel(const Params p)
 
 
 template <typename T, typename TL, int G>
-int fwd_tile(const Params &p, unsigned blocks, size_t lds, hipStream_t stream)
+int fwd_tile(const Params &p, unsigned blocks, size_t lds, hipStream_t stream, int waves)
 {
     // points whose 4 * NB corner loads are in flight: 4 for 4-byte types; 2 for 2-byte types, whose lanes hold 8 channels
     // (4 points x 4 corners x 8 fp32 channels would be the whole register budget)
     constexpr int NB = sizeof(T) == 4 ? 4 : 2;
-    hipLaunchKernelGGL((msda_fwd_tile_kernel<T, TL, G, NB>), dim3(blocks), dim3(kWave), lds, stream, p);
+    if constexpr (G == 4 || G == 8) {          // (D = 32: the only rows small calls were measured on)
+        if (waves > 1) {
+            hipLaunchKernelGGL((msda_fwd_tile_kernel<T, TL, G, NB, true>), dim3(blocks), dim3(kWave * waves), lds, stream, p);
+            return check_launch("msda forward (tile kernel, several waves per tile)");
+        }
+    }
+    hipLaunchKernelGGL((msda_fwd_tile_kernel<T, TL, G, NB, false>), dim3(blocks), dim3(kWave), lds, stream, p);
     return check_launch("msda forward (tile kernel)");
 }
 
@@ -474,11 +505,11 @@ int by_lanes(int G, F &&f)
 
 }  // namespace
 
-int launch_fwd_tile(int dtype, int G, const Params &p, unsigned blocks, size_t lds, hipStream_t stream)
+int launch_fwd_tile(int dtype, int G, const Params &p, unsigned blocks, size_t lds, hipStream_t stream, int waves)
 {
     return dispatch_types(dtype, [&](auto t, auto tl) {
         return by_lanes(G, [&](auto g) {
-            return fwd_tile<typename decltype(t)::type, typename decltype(tl)::type, decltype(g)::value>(p, blocks, lds, stream);
+            return fwd_tile<typename decltype(t)::type, typename decltype(tl)::type, decltype(g)::value>(p, blocks, lds, stream, waves);
         });
     });
 }

@@ -35,11 +35,11 @@ def _temporal(pyr, clips, Lq, dtype, T=6):
 
 @pytest.mark.parametrize("pyr,clips,Lq,dtype,fwd_has,bwd_has", [
     # the call DeVIS issues: tile forward, gather pass on the slab kernel with the frames as a workgroup index
-    ("A", 1, 300, torch.float32, "tile kernel", "one source frame per workgroup"),
+    ("A", 1, 300, torch.float32, "(tile kernel)", "one source frame per workgroup"),
     ("B", 1, 300, torch.bfloat16, "tile kernel", "one source frame per workgroup"),
     # ... at the query counts of DeVIS's shipped configs (60 per frame on YouTube-VIS, 180 on OVIS): 2.5-3x faster than the tile kernels
-    ("A", 1, 60, torch.float32, "tile kernel", "one source frame per workgroup"),
-    ("S", 1, 180, torch.float16, "tile kernel", "one source frame per workgroup"),
+    ("A", 1, 60, torch.float32, "tile kernel, several waves per tile", "one source frame per workgroup"),
+    ("S", 1, 180, torch.float16, "tile kernel, several waves per tile", "one source frame per workgroup"),
     # the bench batch
     ("A", 16, 300, torch.float32, "resident-slab kernel, 1 tiles per wave", "one source frame per workgroup"),
     ("A", 16, 300, torch.bfloat16, "resident-slab kernel, 4 tiles per wave", "one source frame per workgroup"),
