@@ -55,13 +55,11 @@ class _AllGatherRows(Function):
     @staticmethod
     def backward(ctx, grad):
         group = ctx.group
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        world = dist.get_world_size(group)
         grad = grad.contiguous()
         rows = grad.shape[0] // world
-        if dist.get_backend(group) == "gloo":
-            # gloo (the CPU test backend) has no reduce-scatter: all-reduce and keep the own rows
-            dist.all_reduce(grad, group=group)
-            return grad[rank * rows:(rank + 1) * rows].clone(), None
+        # the same call under RCCL (GPU) and gloo (the CPU tests: torch >= 2.x implements it there), so that the
+        # world-size 2 / 3 / 8 tests execute the branch an 8-GPU node runs
         mine = grad.new_empty((rows,) + tuple(grad.shape[1:]))
         dist.reduce_scatter_tensor(mine, grad, op=dist.ReduceOp.SUM, group=group)
         return mine, None
@@ -169,8 +167,9 @@ def sharded_temporal_attention_batch(clips, n_frames, spatial_size, spatial_shap
     before them run -- xGMI is point-to-point and a ring all-gather of one clip's ``value`` is bound by one link, so
     the next clip's shards are the cheapest thing to overlap it with.  ``clips``: a list of
     ``(value_chunk, loc_curr, aw_curr, loc_temp, aw_temp)`` as :func:`sharded_temporal_attention` takes them.
-    Returns the list of this rank's output rows, one ``[T, Lq_local, M*D]`` per clip; backward runs one reduce-scatter
-    per clip (autograd orders them)."""
+    Returns the list of this rank's output rows, one ``[T, Lq_local, M*D]`` per clip.  Only the FORWARD collectives are
+    overlapped: backward runs one reduce-scatter per clip where autograd reaches it, and the compute stream waits for each
+    (its result is the next node's input)."""
     pending, out_dtypes = [], []
     for value_chunk, *_ in clips:
         out_dtype = None

@@ -61,6 +61,17 @@ def main():
     lsi = torch.from_numpy(d["lsi"]).to(device)
     ftab = torch.from_numpy(d["ftab"]).to(device)
 
+    # the backward collective must be the reduce-scatter an 8-GPU node runs (not an all-reduce stand-in): count the calls
+    calls = {"rs": 0, "ar": 0}
+    real_rs, real_ar = dist.reduce_scatter_tensor, dist.all_reduce
+    def counting_rs(*a, **k):
+        calls["rs"] += 1
+        return real_rs(*a, **k)
+    def counting_ar(*a, **k):
+        calls["ar"] += 1
+        return real_ar(*a, **k)
+    dist.reduce_scatter_tensor, dist.all_reduce = counting_rs, counting_ar
+
     out = cp.sharded_temporal_attention(v_chunk, T, S, shapes, lsi, ftab, lc, ac, lt, at)
     go = torch.from_numpy(np.ascontiguousarray(d["grad_out"][:, q0:q1])).to(device, dt)
     gv, glc, gac, glt, gat = torch.autograd.grad(out, (v_chunk, lc, ac, lt, at), go)
@@ -110,6 +121,8 @@ def main():
                                                               d["loc_t"], 0.0 * d["aw_t"])[:, q0:q1], "batch clip 1")
     gb = torch.autograd.grad(outs, (v_chunk, lc, ac, lt, at), [go, 0.0 * go])
     assert all(same(a, b) for a, b in zip(gb, (gv, glc, gac, glt, gat))), "batched form differs"
+    dist.reduce_scatter_tensor, dist.all_reduce = real_rs, real_ar
+    assert calls["rs"] == 5 and calls["ar"] == 0, calls       # plain, overlapped, 16-bit transport, two batched clips
     # the ranges tile the query axis
     r = [cp.shard_range(Lq, world, k) for k in range(world)]
     assert r[0][0] == 0 and r[-1][1] == Lq and all(r[i][1] == r[i + 1][0] for i in range(world - 1))
