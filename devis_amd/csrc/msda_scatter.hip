@@ -683,6 +683,18 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         }
         const int H = s_H[l], W = s_W[l], R = s_R[l];
         const bool direct = (R == 0);
+        if (direct && (dbg & 512)) {
+            // The host's copy of the shapes (a selection HINT, include/msda.h) said every level fits a band, so nothing zero-filled
+            // grad_value for the float-atomic branch -- but the DEVICE shapes have a level wider than a band: the hint was stale.
+            // Adding into the unzeroed buffer would be silently wrong; the level's pixels of this (clip, frame, head) are poisoned
+            // with NaN instead, so that the caller's mistake shows in the first value it reads.
+            GV *bad = static_cast<GV *>(p.grad_value) + (((int64_t)clip * p.frames + f) * p.S + s_lsi[l]) * MD + m * D;
+            for (int64_t i = tid; i < (int64_t)H * W * D; i += kOwnThreads)
+                bad[(i / D) * MD + (i % D)] = GV(__builtin_nanf(""));
+            if (wave == 0) prepare(it + 1u, cur ^ 1);
+            __syncthreads();
+            continue;
+        }
         const int r0 = direct ? 0 : (part - s_first[l]) * R;
         const int r1 = direct ? H - 1 : min(H, r0 + R) - 1;
         const int npix = direct ? 0 : (r1 - r0 + 1) * W;

@@ -1,0 +1,118 @@
+"""HIP-graph wrapper for one attention layer (``devis_amd.graphed``).
+
+One clip per GPU -- DeVIS's own setting (main.py:85; the call that matters at inference: tracker.py:320-323) -- is HOST-bound
+when run eagerly: a ``TemporalMSDeformAttnDecoder`` layer step is ~0.5 ms of GPU time but 0.8-1.3 ms of wall clock (the BLAS
+library alone spends 35-55 us of CPU per GEMM call).  The library only enqueues work (no allocation of its own, no
+synchronisation), so a layer can be captured into a HIP graph as it is; this module does the bookkeeping:
+
+    layer = devis_amd.graphed(model.transformer.decoder.layers[0].cross_attn, example_inputs)
+    out = layer(query, reference_points, src, spatial_shapes, level_start_index, temporal_offsets)
+
+* forward AND backward are captured (``torch.cuda.make_graphed_callables``): gradients flow to the floating-point inputs that
+  required them at capture time and to the module's parameters, exactly as from the eager module;
+* one graph per SIGNATURE -- shapes / dtypes / ``requires_grad`` of the floating-point tensor arguments, and the identity (object
+  and version) of every other argument: the integer tensors (``spatial_shapes``, ``level_start_index``), the list of
+  ``temporal_offsets``, ``None`` masks.  Those are bound into the graph at capture: the library chooses kernels, grids and LDS plans
+  from a host copy of ``spatial_shapes``, so a graph is only valid for the pyramid it was captured with.  A call with another
+  signature captures (and caches) another graph; keep the integer tensors alive across steps -- the reference's transformer
+  rebuilds ``spatial_shapes`` on every forward (deformable_transformer.py:87): hoist it, or accept one capture per step, which
+  is slower than eager.
+"""
+import threading
+
+import torch
+from torch import nn
+
+
+def _is_flowing(x):
+    return isinstance(x, torch.Tensor) and x.is_floating_point()
+
+
+def _static_key(x):
+    """Identity of a bound (non-flowing) argument: tensors by object and version, containers element-wise, the rest by value."""
+    if isinstance(x, torch.Tensor):
+        return ("t", id(x), x._version)
+    if isinstance(x, (list, tuple)):
+        return ("l", type(x).__name__) + tuple(_static_key(e) for e in x)
+    return ("v", x)
+
+
+class _Bound(nn.Module):
+    """The wrapped module with its non-flowing arguments fixed: what is captured (an nn.Module, so that its parameters are
+    graph inputs and receive gradients)."""
+
+    def __init__(self, inner, template):
+        super().__init__()
+        self.inner = inner
+        self._template = template           # positional arguments; None at the places of the flowing tensors
+        self._slots = [i for i, a in enumerate(template) if a is _FLOW]
+
+    def forward(self, *flowing):
+        args = list(self._template)
+        for i, t in zip(self._slots, flowing):
+            args[i] = t
+        return self.inner(*args)
+
+
+_FLOW = object()
+
+
+class GraphedLayer:
+    """Callable with the wrapped module's positional signature; see the module docstring.  ``graphs`` = number of captured
+    signatures (tests, diagnostics)."""
+
+    def __init__(self, module, num_warmup_iters=3):
+        self.module = module
+        self.num_warmup_iters = num_warmup_iters
+        self._cache = {}
+        self._keep = {}                     # signature -> the bound arguments (kept alive: their identity is the key)
+        self._lock = threading.Lock()
+
+    @property
+    def graphs(self):
+        return len(self._cache)
+
+    def _signature(self, args):
+        sig = []
+        for a in args:
+            if _is_flowing(a):
+                sig.append(("f", tuple(a.shape), a.dtype, a.device, a.requires_grad))
+            else:
+                sig.append(_static_key(a))
+        return tuple(sig) + (self.module.training,)
+
+    def capture(self, *args):
+        """Capture (or fetch) the graph for this signature without running it: call once per shape before timing."""
+        if not any(_is_flowing(a) and a.is_cuda for a in args):
+            raise RuntimeError("devis_amd.graphed: needs CUDA (HIP) tensor arguments -- there is no CPU path to capture")
+        sig = self._signature(args)
+        with self._lock:
+            fn = self._cache.get(sig)
+            if fn is not None:
+                return fn
+            template = [_FLOW if _is_flowing(a) else a for a in args]
+            flowing = tuple(a for a in args if _is_flowing(a))
+            # one eager call first: the library reads its host copy of spatial_shapes (devis_amd._native.shapes_hint) outside the
+            # capture, so that the graph records the routes that hint enables
+            with torch.no_grad():
+                self.module(*args)
+            samples = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in flowing)
+            bound = _Bound(self.module, template)
+            fn = torch.cuda.make_graphed_callables(bound, samples, num_warmup_iters=self.num_warmup_iters)
+            self._cache[sig] = fn
+            self._keep[sig] = [a for a in args if not _is_flowing(a)]
+            return fn
+
+    def __call__(self, *args):
+        fn = self.capture(*args)
+        return fn(*(a for a in args if _is_flowing(a)))
+
+
+def graphed(module, example_inputs=None, num_warmup_iters=3):
+    """Static-shape HIP-graph wrapper around one attention layer (``MSDeformAttn``, ``TemporalMSDeformAttnEncoder`` /
+    ``Decoder``, or any module built on this package's operator): returns a :class:`GraphedLayer`.  ``example_inputs`` (the
+    positional arguments of one call) are captured right away; other shapes are captured on first use."""
+    layer = GraphedLayer(module, num_warmup_iters)
+    if example_inputs is not None:
+        layer.capture(*example_inputs)
+    return layer

@@ -11,6 +11,7 @@ reference's call pattern (``2*T`` calls of ``MSDeformAttnFunction``) -- same res
 and by the benchmark's "reference call pattern" line.
 """
 import math
+import threading
 import warnings
 
 import torch
@@ -192,7 +193,106 @@ class MSDeformAttn(_FusedParamsCache, nn.Module):
                                    _normalizer(input_spatial_shapes), P)
         output = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index, locations.contiguous(),
                                             weights.contiguous(), self.im2col_step, input_padding_mask)
-        return self.output_proj(output), None
+        output = self.output_proj(output)
+        _flush_offset_checks(output)
+        return output, None
+
+
+class _FrameTables:
+    """Frame tables of the temporal modules, cached per LIST of offset tensors, and the deferred range checks of device-side
+    offsets.  One process-wide instance (``_FRAME_TABLES``): the encoder and the decoder stack of a model pass different
+    lists (devis_transformer.py:103-121, 151-169), each keeps its own entry (a few entries, least recently used out); all
+    state is guarded by a lock, since DeVIS's data-parallel wrapper and user code may run ``forward`` from several threads.
+
+    The transformer hands the SAME offset tensors to every layer of one forward but builds NEW ones every forward, so a
+    table is reused while the very same tensor objects come back (unchanged: ``_version``) and otherwise rebuilt WITHOUT a
+    host synchronisation: a handful of tiny launches once per stack per forward.
+
+    The reference indexes value[temporal_offsets[t] + t] with torch semantics: a negative index wraps once, anything else
+    out of range trips the indexing kernel's device-side assert.  The kernels take absolute frame ids in [0, T), so the
+    table is normalised here; the range check raises IndexError at once for CPU offsets and -- ``strict`` (module attribute
+    ``STRICT_TEMPORAL_OFFSETS``, one synchronisation per NEW list of offsets) -- for device offsets; otherwise the verdict
+    of a device-side check travels to pinned memory behind the work already queued and is raised by the first call that
+    finds it arrived: the next ``_frame_table`` call of any temporal module, or the end of the module forward that used
+    the table when the device happens to be done by then (``flush``).  A bad table is never served from the cache once its
+    verdict is known, and it is wrapped into range either way: a bad offset reads a wrong frame, never memory outside the
+    clip.  (torch._assert_async would abort the process on this ROCm build: no message, nothing to catch.)"""
+
+    capacity = 8
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._entries = []          # [(offset tensors with versions, n_frames, device, table)], most recently used last
+        self._pending = []          # [(pinned verdict, event, n_frames, offsets as given)]
+
+    @staticmethod
+    def _describe(offsets):
+        try:
+            return " (temporal_offsets = %s)" % [o.detach().cpu().tolist() for o in offsets]
+        except Exception:       # pragma: no cover -- never let the description mask the error
+            return ""
+
+    def raise_on_bad_offsets(self, wait=False):
+        bad = None
+        with self._lock:
+            keep = []
+            for host, done, n_frames, offsets in self._pending:
+                if wait:
+                    done.synchronize()
+                if not done.query():
+                    keep.append((host, done, n_frames, offsets))
+                elif not bool(host) and bad is None:
+                    bad = (n_frames, offsets)
+            self._pending = keep
+            if bad is not None:
+                self._entries = [e for e in self._entries if not self._same(e[0], bad[1])]
+        if bad is not None:
+            raise IndexError("temporal_offsets point outside the clip's %d frames%s" % (bad[0], self._describe(bad[1])))
+
+    flush = raise_on_bad_offsets
+
+    @staticmethod
+    def _same(held, offsets):
+        return len(held) == len(offsets) and all(a is b and a._version == v for (a, v), b in zip(held, offsets))
+
+    def get(self, temporal_offsets, n_frames, device):
+        self.raise_on_bad_offsets()
+        with self._lock:
+            for i, (held, nf, dev, table) in enumerate(self._entries):
+                if nf == n_frames and dev == device and self._same(held, temporal_offsets):
+                    self._entries.append(self._entries.pop(i))
+                    return table
+        table = torch.stack([o.to(device) for o in temporal_offsets]) \
+            + torch.arange(n_frames, device=device)[:, None]
+        in_range = ((table >= -n_frames) & (table < n_frames)).all()
+        capturing = in_range.is_cuda and torch.cuda.is_current_stream_capturing()
+        if not in_range.is_cuda or (STRICT_TEMPORAL_OFFSETS and not capturing):
+            if not bool(in_range):
+                raise IndexError("temporal_offsets point outside the clip's %d frames%s"
+                                 % (n_frames, self._describe(temporal_offsets)))
+        elif not capturing:
+            host = torch.empty((), dtype=torch.bool, pin_memory=True)
+            host.copy_(in_range, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            with self._lock:
+                self._pending.append((host, done, n_frames, list(temporal_offsets)))
+        table = torch.remainder(table, n_frames).to(torch.int32).contiguous()
+        with self._lock:
+            self._entries.append(([(o, o._version) for o in temporal_offsets], n_frames, device, table))
+            del self._entries[:-self.capacity]
+        return table
+
+
+def _flush_offset_checks(like):
+    """End of a temporal module's forward: raise for any range check whose verdict has reached the host by now (no wait)."""
+    if like.is_cuda and torch.cuda.is_current_stream_capturing():
+        return
+    _FRAME_TABLES.flush()
+
+
+STRICT_TEMPORAL_OFFSETS = False     # True: device-side temporal offsets are range-checked with one synchronisation per new list
+_FRAME_TABLES = _FrameTables()
 
 
 class TemporalMSDeformAttnBase(_FusedParamsCache, nn.Module):
@@ -299,65 +399,17 @@ class TemporalMSDeformAttnBase(_FusedParamsCache, nn.Module):
         reference's dense layout: padding would push the backward onto the slow generic kernel."""
         return 0 if 1 + n_frames * self.t_window > 63 else self.value_pad_heads
 
-    _table_cache = None     # (offset tensors, n_frames, device, table): shared by all layers of a transformer
-    _pending_range_checks = []      # (pinned verdict, event, n_frames) of device-side offset checks not yet read
-
     @staticmethod
     def _raise_on_bad_offsets(wait=False):
-        """Deferred range checks of device-side temporal offsets (see _frame_table): raises IndexError for the first one
-        whose verdict has arrived (``wait``: synchronise on the outstanding ones first -- tests, debugging)."""
-        pending = TemporalMSDeformAttnBase._pending_range_checks
-        keep, bad = [], None
-        for host, done, n_frames in pending:
-            if wait:
-                done.synchronize()
-            if not done.query():
-                keep.append((host, done, n_frames))
-            elif not bool(host) and bad is None:
-                bad = n_frames
-        TemporalMSDeformAttnBase._pending_range_checks = keep
-        if bad is not None:
-            TemporalMSDeformAttnBase._table_cache = None
-            raise IndexError("temporal_offsets point outside the clip's %d frames" % bad)
+        """Deferred range checks of device-side temporal offsets (see :class:`_FrameTables`): raises IndexError for the
+        first one whose verdict has arrived (``wait``: synchronise on the outstanding ones first -- tests, debugging)."""
+        _FRAME_TABLES.raise_on_bad_offsets(wait)
 
     @staticmethod
     def _frame_table(temporal_offsets, n_frames, device):
-        """[T, W] absolute frame indices: frame_table[t] = temporal_offsets[t] + t (ref :339, :445).
-        The transformer hands the SAME offset tensors to every layer of one forward (devis_transformer.py:103-121,
-        151-169) but builds NEW ones every forward, so the table is cached while the very same tensor objects come
-        back and otherwise rebuilt WITHOUT a host synchronisation: a handful of tiny
-        launches once per stack per forward.
-
-        The reference indexes value[temporal_offsets[t] + t] with torch semantics: a negative index wraps once,
-        anything else out of range trips the indexing kernel's device-side assert.  The kernels take absolute frame ids
-        in [0, T), so the table is normalised here; the range check raises IndexError at once for CPU offsets and, for
-        device offsets, at the first call made after its verdict has reached the host (no synchronisation; at the latest
-        the next forward of the stack -- ``_raise_on_bad_offsets``)."""
-        TemporalMSDeformAttnBase._raise_on_bad_offsets()
-        cached = TemporalMSDeformAttnBase._table_cache
-        if cached is not None and cached[1] == n_frames and cached[2] == device and \
-                len(cached[0]) == len(temporal_offsets) and \
-                all(a is b and a._version == v for (a, v), b in zip(cached[0], temporal_offsets)):
-            return cached[3]
-        table = torch.stack([o.to(device) for o in temporal_offsets]) \
-            + torch.arange(n_frames, device=device)[:, None]
-        in_range = ((table >= -n_frames) & (table < n_frames)).all()
-        if not in_range.is_cuda:
-            if not bool(in_range):
-                raise IndexError("temporal_offsets point outside the clip's %d frames" % n_frames)
-        elif not torch.cuda.is_current_stream_capturing():
-            # no synchronisation here: the verdict travels to pinned memory behind the work already queued and is read by a
-            # LATER call (_raise_on_bad_offsets) -- the table below is wrapped into range either way, so a bad offset reads
-            # a wrong frame but never memory outside the clip.  (torch._assert_async would abort the process on this
-            # ROCm build: no message, nothing to catch.)
-            host = torch.empty((), dtype=torch.bool, pin_memory=True)
-            host.copy_(in_range, non_blocking=True)
-            done = torch.cuda.Event()
-            done.record()
-            TemporalMSDeformAttnBase._pending_range_checks.append((host, done, n_frames))
-        table = torch.remainder(table, n_frames).to(torch.int32).contiguous()
-        TemporalMSDeformAttnBase._table_cache = ([(o, o._version) for o in temporal_offsets], n_frames, device, table)
-        return table
+        """[T, W] absolute frame indices: frame_table[t] = temporal_offsets[t] + t (ref :339, :445); see
+        :meth:`_FrameTables.get`."""
+        return _FRAME_TABLES.get(temporal_offsets, n_frames, device)
 
     def _attend(self, value, shapes, level_start, temporal_offsets, loc_curr, w_curr, loc_temp, w_temp):
         """[T, Lq, C]: current-frame + temporal attention for every frame."""
@@ -420,6 +472,7 @@ class TemporalMSDeformAttnDecoder(TemporalMSDeformAttnBase):
         output = self._attend(value, input_spatial_shapes, input_level_start_index, temporal_offsets,
                               loc_curr, w_curr, loc_temp, w_temp)
         output = self.output_proj(output.flatten(0, 1)[None])
+        _flush_offset_checks(output)
         return (output, [loc_curr[t][None] for t in range(T)], [loc_temp[t][None] for t in range(T)],
                 w_curr, w_temp)
 

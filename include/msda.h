@@ -41,9 +41,13 @@
  *     always dense [N, S, M, D].
  *
  *   - `spatial_shapes_host` (HOST pointer to [L, 2] int64, or NULL; ABI v8): a host copy of `spatial_shapes`,
- *     used ONLY to choose between kernels (which pyramid levels fit the LDS slab).  Results never depend on
- *     it; NULL makes the library guess from `spatial_size`.  The device tensor stays the one the kernels read
- *     (no host synchronisation inside the library, as in the reference).
+ *     used ONLY to choose between kernels (which pyramid levels fit the LDS slab); NULL makes the library guess
+ *     from `spatial_size`.  The device tensor stays the one the kernels read (no host synchronisation inside
+ *     the library, as in the reference).  FORWARD results never depend on the hint.  For the BACKWARD entry
+ *     points the hint, when given, MUST be a true copy of the device tensor (as for msda_grad_value_dtype):
+ *     whether grad_value is zero-filled for a level wider than a scatter band (more than 1024 pixels per row;
+ *     never in DeVIS) is decided from it.  A stale hint that hides such a level does not return silently wrong
+ *     sums: the kernel sees the device shapes and fills that level's pixels of grad_value with NaN.
  *
  * Symbols:  N batch, S = sum_l H_l*W_l, M heads, D channels per head, Lq queries, L levels,
  *           P points;  spatial_shapes[l] = (H_l, W_l);  sampling_loc[..., 0] = x (width), 1 = y.

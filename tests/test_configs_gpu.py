@@ -253,6 +253,18 @@ def test_frame_table_rejects_out_of_range_offsets_on_the_device_without_a_sync()
     B._raise_on_bad_offsets(wait=True)
 
 
+def test_strict_temporal_offsets_raise_at_once_and_name_the_offsets(monkeypatch):
+    """``STRICT_TEMPORAL_OFFSETS``: one synchronisation per NEW list of device-side offsets buys the reference's behaviour
+    (its indexing assert fires in the call that made the mistake); the message carries the offending offsets."""
+    import devis_amd.modules.ms_deform_attn as mm
+    mm.TemporalMSDeformAttnBase._raise_on_bad_offsets(wait=True)
+    monkeypatch.setattr(mm, "STRICT_TEMPORAL_OFFSETS", True)
+    bad = [torch.tensor([1, 7], device=DEV) for _ in range(3)]
+    with pytest.raises(IndexError, match=r"temporal_offsets = \[\[1, 7\]"):
+        mm.TemporalMSDeformAttnBase._frame_table(bad, 3, torch.device(DEV))
+    mm.TemporalMSDeformAttnBase._raise_on_bad_offsets(wait=True)      # nothing was left pending
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 1e-4)], ids=["f64", "f32"])
 @pytest.mark.parametrize("kind", ["dec", "enc"])
 def test_config_sized_modules_vs_reference_fixture(kind, dtype, tol):

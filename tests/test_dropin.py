@@ -2,15 +2,16 @@
 
 Path A: the package reached as ``src.models.ops`` through a symlink, the way DeVIS imports it
 (/root/reference/src/models/deformable_transformer.py:17, devis_transformer.py:13).
-Path B: the ``MultiScaleDeformableAttention.py`` ctypes stub printed in INTEGRATION.md, extracted from the document
-as is, driven by an autograd.Function shaped like the reference's binding
-(/root/reference/src/models/ops/functions/ms_deform_attn_func.py:18-38).
+Path B: ``integration/MultiScaleDeformableAttention.py`` -- the module DeVIS's own functions file imports -- put on the import
+path and driven by an autograd.Function shaped like the reference's binding
+(/root/reference/src/models/ops/functions/ms_deform_attn_func.py:18-38); also as ``pip`` installs it (pyproject.toml /
+setup.py, the counterpart of the reference's src/models/ops/setup.py:36-71 + make.sh).
 
 The CPU tests check that both import and load the library (no compute); the GPU tests run golden fixtures through them.
 """
 import importlib
 import os
-import re
+import subprocess
 import sys
 
 import numpy as np
@@ -38,24 +39,14 @@ def ops_as_reference_package(tmp_path):
                 del sys.modules[name]
 
 
-def _stub_source():
-    """The MultiScaleDeformableAttention.py block of INTEGRATION.md, with the library path filled in."""
-    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
-    stub = [b for b in blocks if b.lstrip().startswith("# MultiScaleDeformableAttention.py")]
-    assert len(stub) == 1, "INTEGRATION.md must hold exactly one MultiScaleDeformableAttention.py block"
-    from devis_amd import build
-    src = stub[0].replace("/path/to/devis_amd/libmsda_hip.so", build.lib_path())
-    assert build.lib_path() in src
-    return src
-
-
 @pytest.fixture()
 def msda_stub(tmp_path):
-    """The stub written to <tmp>/MultiScaleDeformableAttention.py and imported under the name DeVIS imports."""
+    """integration/MultiScaleDeformableAttention.py copied to <tmp> (as a maintainer would drop it next to main.py) and imported
+    under the name DeVIS imports."""
+    import shutil
     from devis_amd import build
     build.ensure()
-    (tmp_path / "MultiScaleDeformableAttention.py").write_text(_stub_source())
+    shutil.copy(os.path.join(ROOT, "integration", "MultiScaleDeformableAttention.py"), tmp_path / "MultiScaleDeformableAttention.py")
     sys.path.insert(0, str(tmp_path))
     try:
         sys.modules.pop("MultiScaleDeformableAttention", None)
@@ -116,6 +107,34 @@ def test_path_b_stub_imports_and_binds_the_library(msda_stub):
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):          # ms_deform_attn.h:38
         msda_stub.ms_deform_attn_forward(v, torch.from_numpy(g["spatial_shapes"]), torch.from_numpy(g["level_start_index"]),
                                          torch.from_numpy(g["sampling_locations"]), torch.from_numpy(g["attention_weights"]), 2)
+
+
+def test_pip_install_builds_and_ships_the_library_and_the_reference_module_name(tmp_path):
+    """`pip install .` (offline: --no-build-isolation --no-deps) into a scratch target: the wheel holds the devis_amd package
+    WITH libmsda_hip.so, the kernel sources and the header, and the top-level module the reference imports; a fresh
+    interpreter that sees only the scratch target imports both and loads the installed library (no compute)."""
+    import glob
+    import shutil
+    target = tmp_path / "site"
+    litter = [q for q in [os.path.join(ROOT, "build")] + glob.glob(os.path.join(ROOT, "*.egg-info")) if not os.path.exists(q)]
+    r = subprocess.run([sys.executable, "-m", "pip", "install", "--no-build-isolation", "--no-deps", "--no-index", "--quiet",
+                        "--target", str(target), ROOT], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    for q in litter + glob.glob(os.path.join(ROOT, "*.egg-info")):       # what setuptools' in-tree build leaves behind
+        if q in litter or q.endswith(".egg-info"):
+            shutil.rmtree(q, ignore_errors=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for rel in ("MultiScaleDeformableAttention.py", "devis_amd/libmsda_hip.so", "devis_amd/include/msda.h",
+                "devis_amd/csrc/msda_api.hip", "devis_amd/modules/ms_deform_attn.py"):
+        assert (target / rel).exists(), rel
+    probe = ("import sys, os; sys.path.insert(0, %r); import devis_amd, devis_amd._native as n, devis_amd.build as b; "
+             "assert os.path.dirname(b.lib_path()) == os.path.join(%r, 'devis_amd'), b.lib_path(); "
+             "assert not b.is_stale(); lib = n.load(); assert lib.msda_version() == n.MSDA_ABI_VERSION; "
+             "import MultiScaleDeformableAttention as M; "
+             "assert M.__file__.startswith(%r) and callable(M.ms_deform_attn_forward) and callable(M.ms_deform_attn_backward); "
+             "print('installed ok')" % (str(target), str(target), str(target)))
+    env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH", "MSDA_LIB")}
+    r = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=300, cwd=str(tmp_path), env=env)
+    assert r.returncode == 0 and "installed ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 # ---- GPU: golden fixtures through both paths ------------------------------------------------------------------------

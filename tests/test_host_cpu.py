@@ -161,6 +161,46 @@ def test_frame_table_is_cached_per_offset_tensors():
     assert c is not b
 
 
+def test_frame_tables_of_two_stacks_do_not_evict_each_other_and_are_thread_safe():
+    """The encoder and the decoder stack hand different offset lists to their layers in turn (devis_transformer.py:103-121,
+    151-169): each list keeps its own entry (round 4 had ONE class-level slot that the two stacks thrashed), and concurrent
+    forwards from several threads never see a half-updated cache."""
+    import threading
+    from devis_amd.modules import TemporalMSDeformAttnDecoder as Dec, TemporalMSDeformAttnEncoder as Enc
+    enc = [torch.tensor([1, 2]), torch.tensor([-1, 1]), torch.tensor([-2, -1])]
+    dec = [torch.tensor([2, 1]), torch.tensor([1, -1]), torch.tensor([-1, -2])]
+    a, b = Enc._frame_table(enc, 3, torch.device("cpu")), Dec._frame_table(dec, 3, torch.device("cpu"))
+    for _ in range(3):                      # layer after layer, alternating stacks: always hits
+        assert Enc._frame_table(enc, 3, torch.device("cpu")) is a
+        assert Dec._frame_table(dec, 3, torch.device("cpu")) is b
+    errors = []
+
+    def worker(seed):
+        try:
+            g = torch.Generator().manual_seed(seed)
+            for _ in range(200):
+                offs = [torch.randint(-f, 3 - f, (2,), generator=g) for f in range(3)]
+                want = [[int(o[0]) + f, int(o[1]) + f] for f, o in enumerate(offs)]
+                got = Dec._frame_table(offs, 3, torch.device("cpu")).tolist()
+                assert got == [[v % 3 for v in row] for row in want]
+                assert Enc._frame_table(enc, 3, torch.device("cpu")).tolist() == a.tolist()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_bad_cpu_offsets_raise_with_the_offsets_in_the_message():
+    from devis_amd.modules import TemporalMSDeformAttnDecoder as Dec
+    with pytest.raises(IndexError, match=r"outside the clip's 3 frames \(temporal_offsets = \[\[1, 7\]"):
+        Dec._frame_table([torch.tensor([1, 7])] * 3, 3, torch.device("cpu"))
+
+
 def test_project_value_padded_equals_dense_linear(monkeypatch):
     """functions.project_value (SURVEY f-3): value_proj written with a padded pixel stride and masked by
     msda_mask_rows (here: its CPU test double) gives the same value tensor and the same gradients (input, weight,

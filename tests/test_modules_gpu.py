@@ -191,6 +191,52 @@ def test_temporal_decoder_module_is_graph_capturable():
             assert torch.allclose(x, y, rtol=1e-4, atol=1e-5 * float(y.abs().max()))
 
 
+def test_graphed_helper_reproduces_the_eager_layer_with_parameter_gradients_and_caches_per_shape():
+    """``devis_amd.graphed``: the layer with the module's own call signature, forward and backward replayed from
+    a HIP graph -- outputs, input gradients AND parameter gradients of the eager module; one graph per signature (a second
+    query count captures a second graph, a repeated one does not); the decoder's auxiliary returns come through."""
+    import devis_amd
+    from devis_amd.modules import TemporalMSDeformAttnDecoder
+    torch.manual_seed(0)
+    T, C, M, L = 6, 256, 8, 4
+    shapes = torch.tensor(module_cases.CFG["pyramid"], dtype=torch.long, device=DEV)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    t_shapes = shapes.repeat(T - 1, 1)
+    t_lsi = torch.cat((t_shapes.new_zeros((1,)), t_shapes.prod(1).cumsum(0)[:-1]))
+    offsets = [torch.tensor([t for t in range(-f, T - f) if t != 0], device=DEV) for f in range(T)]
+    mod = TemporalMSDeformAttnDecoder(T, C, L, T - 1, M, 4, 4).to(DEV)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.normal_(0, 0.05)
+
+    def inputs(seed, q):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+        return (mk(1, T * q, C).requires_grad_(True), (torch.rand(1, T * q, L, 2, generator=g) * 0.8 + 0.1).to(DEV),
+                mk(T, S, C).requires_grad_(True), (shapes, t_shapes), (lsi, t_lsi), offsets)
+
+    layer = devis_amd.graphed(mod, inputs(1, 60))
+    assert layer.graphs == 1
+    params = [p for p in mod.parameters()]
+    for seed, q in ((2, 60), (3, 180), (4, 60)):
+        a, b = inputs(seed, q), inputs(seed, q)
+        res_g = layer(*a)
+        res_e = mod(*b)
+        assert len(res_g) == 5 and len(res_g[1]) == T and res_g[3].shape == res_e[3].shape
+        w = torch.randn_like(res_e[0])
+        gg = torch.autograd.grad((res_g[0] * w).sum(), [a[0], a[2]] + params)
+        ge = torch.autograd.grad((res_e[0] * w).sum(), [b[0], b[2]] + params)
+        torch.cuda.synchronize()
+        assert torch.allclose(res_g[0], res_e[0], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(res_g[3], res_e[3], rtol=1e-5, atol=1e-7) and torch.allclose(res_g[1][2], res_e[1][2], rtol=1e-5, atol=1e-6)
+        for x, y in zip(gg, ge):
+            assert torch.allclose(x, y, rtol=1e-4, atol=2e-5 * max(1e-6, float(y.abs().max())))
+    assert layer.graphs == 2                        # 60 and 180 queries per frame; the third call replayed the first graph
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        devis_amd.graphed(mod, tuple(x.cpu() if isinstance(x, torch.Tensor) else x for x in inputs(1, 60)))
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2), (torch.float16, 4e-3)], ids=["f32", "bf16", "f16"])
 def test_value_proj_gradients_at_clip_size_through_the_split_k_product(dtype, tol):
     """`project_value` at the size of one DeVIS clip (T x S = 28 920 rows, 256 -> 256): its backward computes the weight gradient as

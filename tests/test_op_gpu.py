@@ -542,6 +542,42 @@ def test_grad_value_is_overwritten(route, monkeypatch):
     assert _maxabs(got[:, :S0], ref[1]) <= 2e-5 * max(1.0, np.abs(ref[1]).max())
 
 
+def test_a_stale_shapes_hint_poisons_grad_value_instead_of_returning_wrong_sums():
+    """include/msda.h: for a backward call the host copy of the shapes must be a true copy.  A raw C-ABI caller whose hint
+    hides a level wider than a scatter band (1024 pixels per row) gets that level's grad_value as NaN -- loud -- and not
+    sums added into a buffer nobody zeroed; with the true hint (or none) the same call is exact."""
+    import ctypes
+    from devis_amd import _native
+    shapes = [(2, 1100), (3, 5)]
+    d = make_inputs(9, 1, 2, 32, 23, shapes, 4)
+    ref = oracle_fwd_bwd(d)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in d.items()}
+    v = t["value"].float().contiguous()
+    loc, aw, go = t["loc"].float(), t["aw"].float(), t["grad_out"].float().contiguous()
+    N, S, M, D = v.shape
+    _, Lq, _, L, P, _ = loc.shape
+    ws = _native.bwd_workspace(v.device, N, Lq, M, L)
+
+    def call(hint):
+        gv = torch.full(v.shape, 123.0, device=DEV)
+        gl, ga = torch.empty_like(loc), torch.empty_like(aw)
+        rc = _native.load().msda_backward(0, v.data_ptr(), t["shapes"].data_ptr(), t["lsi"].data_ptr(), loc.data_ptr(),
+                                          aw.data_ptr(), go.data_ptr(), N, S, M, D, L, Lq, P, gv.data_ptr(), 0,
+                                          gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), ws.numel() * 4, None, hint,
+                                          torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        return gv.cpu().numpy()
+
+    true_hint = (ctypes.c_int64 * 4)(2, 1100, 3, 5)
+    for hint in (true_hint, None):
+        got = call(hint)
+        assert _maxabs(got, ref[1]) <= 2e-5 * max(1.0, np.abs(ref[1]).max())
+    stale = (ctypes.c_int64 * 4)(2, 100, 3, 5)
+    got = call(stale)
+    assert np.isnan(got[:, :2200]).all()                                         # the hidden wide level: poisoned
+    assert _maxabs(got[:, 2200:], ref[1][:, 2200:]) <= 2e-5 * max(1.0, np.abs(ref[1]).max())      # the others: exact
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 def test_storage_typed_grad_value_is_overwritten_outside_the_levels(dtype):
     """The same contract for a 16-bit grad_value written by the scatter itself (ABI v10): pixel rows of `value` that belong to
