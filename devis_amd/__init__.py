@@ -18,6 +18,7 @@ from .modules import (MSDeformAttn, TemporalMSDeformAttnDecoder,  # noqa: F401
                       TemporalMSDeformAttnEncoder)
 from .argument_builders import patch_transformer  # noqa: F401
 from .graphs import graphed, GraphedLayer  # noqa: F401
+from .tuning import tune  # noqa: F401
 
 __all__ = ["MSDeformAttnFunction", "MSDeformAttnTemporalFunction", "ms_deform_attn_core_pytorch",
-           "MSDeformAttn", "TemporalMSDeformAttnEncoder", "TemporalMSDeformAttnDecoder", "patch_transformer", "graphed", "GraphedLayer"]
+           "MSDeformAttn", "TemporalMSDeformAttnEncoder", "TemporalMSDeformAttnDecoder", "patch_transformer", "graphed", "GraphedLayer", "tune"]

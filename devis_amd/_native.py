@@ -11,7 +11,7 @@ import torch
 
 from . import build as _build
 
-MSDA_ABI_VERSION = 11
+MSDA_ABI_VERSION = 12
 BWD_WORKSPACE_BYTES = 64
 _DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.float16: 3}
 
@@ -20,6 +20,7 @@ EXPORTED_SYMBOLS = (
     "msda_version", "msda_last_error", "msda_forward", "msda_backward",
     "msda_temporal_forward", "msda_temporal_backward", "msda_backward_workspace_bytes",
     "msda_prep_forward", "msda_prep_backward", "msda_reload_knobs", "msda_last_route", "msda_mask_rows", "msda_grad_value_dtype",
+    "msda_route_key", "msda_pin_route", "msda_clear_routes", "msda_route_count",
 )
 
 _lib = None
@@ -71,12 +72,79 @@ def load():
         lib.msda_prep_backward.argtypes = [_ci] + [_vp] * 9 + [ctypes.c_longlong] + [_ci] * 6 + [ctypes.c_longlong] + [_vp] * 5
         lib.msda_mask_rows.restype = _ci
         lib.msda_mask_rows.argtypes = [_ci, _vp, _vp] + [ctypes.c_longlong] * 3 + [_vp]
+        lib.msda_route_key.restype = _ci
+        lib.msda_route_key.argtypes = [_ci] * 12 + [_vp, ctypes.c_char_p, _ci]
+        lib.msda_pin_route.restype = _ci
+        lib.msda_pin_route.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        lib.msda_clear_routes.restype = None
+        lib.msda_clear_routes.argtypes = []
+        lib.msda_route_count.restype = _ci
+        lib.msda_route_count.argtypes = []
         _lib = lib
+        _load_shipped_routes()
     return _lib
 
 
 def is_loaded():
     return _lib is not None
+
+
+# ---- measured route table (include/msda.h, ABI v12) -----------------------------------------------------------------
+ROUTES_FILE = os.path.join(os.path.dirname(os.path.realpath(__file__)), "routes.json")
+
+
+def route_key(backward, dtype_code_, clips, frames, window, S, M, D, L, Lq, Pc, Pt, shapes):
+    """Key of a call shape (msda_route_key).  ``shapes``: [[H, W], ...] host values (list / tensor)."""
+    flat = [int(v) for hw in (shapes.tolist() if hasattr(shapes, "tolist") else shapes) for v in hw]
+    arr = (ctypes.c_int64 * len(flat))(*flat)
+    buf = ctypes.create_string_buffer(512)
+    n = _lib_or_load().msda_route_key(int(bool(backward)), dtype_code_, clips, frames, window, S, M, D, L, Lq, Pc, Pt, arr, buf, 512)
+    _check(n if n < 0 else 0, "msda_route_key")
+    return buf.value.decode()
+
+
+def pin_route(key, settings):
+    """Pin ``settings`` (dict name -> int, or the "name=value ..." string; empty: unpin) for call shape ``key``."""
+    if isinstance(settings, dict):
+        settings = " ".join("%s=%d" % (k, int(v)) for k, v in sorted(settings.items()))
+    _check(_lib_or_load().msda_pin_route(key.encode(), settings.encode()), "msda_pin_route")
+
+
+def clear_routes():
+    _lib_or_load().msda_clear_routes()
+
+
+def route_count():
+    return _lib_or_load().msda_route_count()
+
+
+def _lib_or_load():
+    return _lib if _lib is not None else load()
+
+
+def load_routes(path):
+    """Pin every entry of a routes file ({"routes": {key: {name: value}}}); returns the number of entries."""
+    import json
+    with open(path) as f:
+        table = json.load(f).get("routes", {})
+    for key, settings in table.items():
+        pin_route(key, settings)
+    return len(table)
+
+
+def _load_shipped_routes():
+    """devis_amd/routes.json -- the table audited on MI355X (devis_amd.tune --audit) -- unless MSDA_ROUTES=0 (A/B runs against the
+    fallback rules) or MSDA_ROUTES=/another/file.json."""
+    which = os.environ.get("MSDA_ROUTES", "")
+    if which == "0":
+        return
+    path = which or ROUTES_FILE
+    if os.path.exists(path):
+        try:
+            load_routes(path)
+        except Exception as e:  # a broken table must not take the operator down: the rules are the fallback
+            import warnings
+            warnings.warn("devis_amd: ignoring %s (%s)" % (path, e))
 
 
 def reload_knobs():

@@ -3,6 +3,9 @@
 // knobs and the per-device caches.  The kernels live in the other translation units of this directory.
 #include "msda_common.h"
 #include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
 
 namespace msda {
 
@@ -96,11 +99,100 @@ void load_knobs()
     __atomic_store_n(&g_knobs_loaded, 1, __ATOMIC_RELEASE);
 }
 
+// While a call runs with a pinned route (msda_pin_route), this thread's knobs() answers the pinned settings laid over the
+// environment's: see RouteScope below.
+thread_local const Knobs *tl_route_knobs = nullptr;
+
 inline const Knobs &knobs()
 {
+    if (tl_route_knobs) return *tl_route_knobs;
     if (!__atomic_load_n(&g_knobs_loaded, __ATOMIC_ACQUIRE)) load_knobs();      // benign race: every thread reads the same environment
     return g_knobs;
 }
+
+// ---- measured route table (ABI v12) ---------------------------------------------------------------------------------
+// The rules in launch_fast choose a kernel family, tiles per wave, the gather pass's grid and the scatter's item order from
+// sizes alone; they were calibrated on three pyramids and a few batch sizes and are the FALLBACK.  A
+// caller that has TIMED the alternatives for a call shape (devis_amd.tune, or the audited table shipped as
+// devis_amd/routes.json) pins the winner here: key = everything the rules look at (direction, dtype code, clips, frames,
+// window, S, M, D, L, Lq, points, the host copy of the shapes), settings = the route knobs.  A knob forced through the
+// environment (tests, A/B runs) wins over a pin.  Results never depend on a pin: every route computes the same function.
+struct RoutePin {
+    std::string key;
+    int fwd_rs = -2, fwd_rs_nt = -2, fwd_win = -2, fwd_tile_waves = -2;        // -2 = not pinned
+    int bwd_rs = -2, bwd_rs_tpw = -2, bwd_rs_fsplit = -2, bwd_win = -2, scatter_order = -2;
+};
+std::mutex g_routes_mutex;
+std::vector<RoutePin> g_routes;
+int g_routes_n = 0;                     // (read without the lock on the launch path: 0 = nothing pinned, skip the key)
+
+int route_key(char *buf, int len, bool bwd, int dtype, const Params &p)
+{
+    if (!p.shapes_host || p.L > 16) return -1;
+    int n = snprintf(buf, len, "%c|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|", bwd ? 'b' : 'f', dtype, p.groups / (p.frames > 0 ? p.frames : 1),
+                     p.frames, p.window, p.S, p.M, p.D, p.L, p.Lq, p.PA, p.PB);
+    for (int l = 0; l < p.L && n > 0 && n < len; ++l)
+        n += snprintf(buf + n, len - n, "%s%lldx%lld", l ? "," : "", (long long)p.shapes_host[2 * l], (long long)p.shapes_host[2 * l + 1]);
+    return (n > 0 && n < len) ? n : -1;
+}
+
+bool parse_route_settings(const char *text, RoutePin &pin)
+{
+    std::string t(text ? text : "");
+    size_t i = 0;
+    while (i < t.size()) {
+        while (i < t.size() && (t[i] == ' ' || t[i] == ',')) ++i;
+        if (i >= t.size()) break;
+        const size_t eq = t.find('=', i);
+        if (eq == std::string::npos) return false;
+        size_t end = t.find_first_of(" ,", eq);
+        if (end == std::string::npos) end = t.size();
+        const std::string name = t.substr(i, eq - i);
+        const int v = atoi(t.substr(eq + 1, end - eq - 1).c_str());
+        if (name == "fwd_rs") pin.fwd_rs = v; else if (name == "fwd_rs_nt") pin.fwd_rs_nt = v;
+        else if (name == "fwd_win") pin.fwd_win = v; else if (name == "fwd_tile_waves") pin.fwd_tile_waves = v;
+        else if (name == "bwd_rs") pin.bwd_rs = v; else if (name == "bwd_rs_tpw") pin.bwd_rs_tpw = v;
+        else if (name == "bwd_rs_fsplit") pin.bwd_rs_fsplit = v; else if (name == "bwd_win") pin.bwd_win = v;
+        else if (name == "scatter_order") pin.scatter_order = v;
+        else return false;
+        i = end;
+    }
+    return true;
+}
+
+// For the duration of one entry-point call: the pinned settings of this call's shape (if any) laid over the knobs.
+struct RouteScope {
+    Knobs merged;
+    bool active = false;
+    RouteScope(bool bwd, int dtype, const Params &p)
+    {
+        if (__atomic_load_n(&g_routes_n, __ATOMIC_ACQUIRE) == 0 || tl_route_knobs) return;
+        char key[512];
+        if (route_key(key, (int)sizeof key, bwd, dtype, p) < 0) return;
+        RoutePin pin;
+        {
+            std::lock_guard<std::mutex> lock(g_routes_mutex);
+            bool found = false;
+            for (const RoutePin &r : g_routes)
+                if (r.key == key) { pin = r; found = true; break; }
+            if (!found) return;
+        }
+        merged = knobs();
+        const Knobs dflt;
+        auto lay = [](int &dst, int dflt_v, int pinned) { if (pinned != -2 && dst == dflt_v) dst = pinned; };
+        lay(merged.fwd_rs, dflt.fwd_rs, pin.fwd_rs); lay(merged.fwd_rs_nt, dflt.fwd_rs_nt, pin.fwd_rs_nt);
+        lay(merged.fwd_win, dflt.fwd_win, pin.fwd_win); lay(merged.fwd_tile_waves, dflt.fwd_tile_waves, pin.fwd_tile_waves);
+        lay(merged.bwd_rs, dflt.bwd_rs, pin.bwd_rs); lay(merged.bwd_rs_tpw, dflt.bwd_rs_tpw, pin.bwd_rs_tpw);
+        lay(merged.bwd_rs_fsplit, dflt.bwd_rs_fsplit, pin.bwd_rs_fsplit); lay(merged.bwd_win, dflt.bwd_win, pin.bwd_win);
+        if (pin.scatter_order == 1 && (merged.scatter_dbg & 256) == 0 && merged.scatter_dbg == dflt.scatter_dbg) merged.scatter_dbg |= 256;
+        if (pin.scatter_order == 2 && merged.scatter_dbg == dflt.scatter_dbg) merged.scatter_dbg |= 2048;
+        tl_route_knobs = &merged;
+        active = true;
+    }
+    ~RouteScope() { if (active) tl_route_knobs = nullptr; }
+    RouteScope(const RouteScope &) = delete;
+    RouteScope &operator=(const RouteScope &) = delete;
+};
 
 int current_device()
 {
@@ -541,7 +633,7 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             rc = launch_zero_unowned(p, kOwnPix * p.D, p.gv_storage ? 2 : 4, stream);
             if (rc) return rc;
         }
-        return launch_scatter_grp(dtype, p.gv_storage != 0, p, grid * (1024 / kOwnThreads), (knobs().scatter_dbg & 511) | (fused_zero ? 512 : 0), stream);
+        return launch_scatter_grp(dtype, p.gv_storage != 0, p, grid * (1024 / kOwnThreads), (knobs().scatter_dbg & (511 | 2048)) | (fused_zero ? 512 : 0), stream);
     }
     if (p.gv_storage) return fail(MSDA_ERR_ARG, "msda backward: this call needs grad_value in the arithmetic type (see msda_grad_value_dtype)%s");
     // LDS-atomic scatter: 144 KiB of 8-byte accumulators per workgroup
@@ -578,6 +670,7 @@ int run(int dtype, const Params &p_in, bool bwd, hipStream_t stream)
 {
     if (dtype < MSDA_F32 || dtype > MSDA_F16_LOC32) return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
     Params p = p_in;
+    const RouteScope pinned(bwd, dtype, p);     // (the pinned settings of this call shape, if any, are what knobs() answers below)
     p.dbg = knobs().dbg;
     // culling records per point (4 x int16) when the owner-computes scatter will read them; (min, max) intervals for the
     // LDS-atomic scatter (MSDA_BWD_CULL=2 forces them)
@@ -681,6 +774,48 @@ extern "C" {
 int msda_version(void) { return MSDA_ABI_VERSION; }
 
 void msda_reload_knobs(void) { load_knobs(); }
+
+int msda_route_key(int backward, int dtype, int clips, int frames, int window, int spatial_size, int num_heads, int channels,
+                   int num_levels, int num_query, int num_curr_point, int num_temp_point, const int64_t *spatial_shapes_host,
+                   char *buf, int buf_len)
+{
+    if (!buf || buf_len <= 0 || !spatial_shapes_host || clips <= 0 || frames <= 0) return fail(MSDA_ERR_ARG, "msda_route_key: bad arguments%s");
+    Params p;
+    memset(&p, 0, sizeof p);
+    p.groups = clips * frames; p.frames = frames; p.window = window; p.S = spatial_size; p.M = num_heads; p.D = channels;
+    p.L = num_levels; p.Lq = num_query; p.PA = num_curr_point; p.PB = window > 0 ? num_temp_point : 1;
+    p.shapes_host = spatial_shapes_host;
+    const int n = route_key(buf, buf_len, backward != 0, dtype, p);
+    return n < 0 ? fail(MSDA_ERR_ARG, "msda_route_key: the key does not fit the buffer (or more than 16 levels)%s") : n;
+}
+
+int msda_pin_route(const char *key, const char *settings)
+{
+    if (!key || !key[0]) return fail(MSDA_ERR_ARG, "msda_pin_route: empty key%s");
+    RoutePin pin;
+    pin.key = key;
+    if (!parse_route_settings(settings, pin)) return fail(MSDA_ERR_ARG, "msda_pin_route: cannot parse the settings (name=value ...)%s");
+    const bool remove = !settings || !settings[0];
+    std::lock_guard<std::mutex> lock(g_routes_mutex);
+    for (size_t i = 0; i < g_routes.size(); ++i)
+        if (g_routes[i].key == pin.key) {
+            if (remove) g_routes.erase(g_routes.begin() + (long)i); else g_routes[i] = pin;
+            __atomic_store_n(&g_routes_n, (int)g_routes.size(), __ATOMIC_RELEASE);
+            return MSDA_OK;
+        }
+    if (!remove) g_routes.push_back(pin);
+    __atomic_store_n(&g_routes_n, (int)g_routes.size(), __ATOMIC_RELEASE);
+    return MSDA_OK;
+}
+
+void msda_clear_routes(void)
+{
+    std::lock_guard<std::mutex> lock(g_routes_mutex);
+    g_routes.clear();
+    __atomic_store_n(&g_routes_n, 0, __ATOMIC_RELEASE);
+}
+
+int msda_route_count(void) { return __atomic_load_n(&g_routes_n, __ATOMIC_ACQUIRE); }
 
 const char *msda_last_route(void) { return g_route; }
 

@@ -1171,7 +1171,8 @@ int launch_scatter_grp(int dtype, bool storage_typed, const Params &p, unsigned 
         // encoder call of BASELINE configs[1] (N = 8, bf16) 0.92 / 0.63 and the SwinL one (N = 6, fp16) 0.23 / 0.17 -- with
         // `clip` outermost the batch is 8 serial tails.
         // (round 4, after the per-item fixed costs shrank: at 360x640, Lq = 4820, image order is now the slower one, 0.555 / 0.529)
-        bool sorted = p.Lq >= 8192 && p.frames > 1 && p.shapes_host != nullptr && (dbg & 256) == 0;
+        // (a pinned route, msda_pin_route scatter_order: 1 = level order (bit 256), 2 = image order wherever the bands can be sorted (bit 2048))
+        bool sorted = ((p.Lq >= 8192 && p.frames > 1) || (dbg & 2048)) && p.shapes_host != nullptr && (dbg & 256) == 0;
         int bands = 0;
         for (int l = 0; sorted && l < p.L; ++l) {
             const long long H = p.shapes_host[2 * l], W = p.shapes_host[2 * l + 1];

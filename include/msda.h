@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 11
+#define MSDA_ABI_VERSION 12
 #define MSDA_BWD_WORKSPACE_BYTES 64   /* minimum device scratch of the backward entry points (ticket counters) */
 
 enum msda_dtype {
@@ -92,6 +92,31 @@ void msda_reload_knobs(void);
 /* Thread-local, human-readable list of the kernels the last entry-point call of this thread launched
  * ("msda forward (resident-slab kernel); ...").  For tests, benchmarks and bug reports. */
 const char *msda_last_route(void);
+
+/*
+ * Measured route table (ABI v12).  Which kernel family serves a call (tile / resident-slab / resident-window), with how many
+ * tiles per wave, on which grid, and in which order the scatter deals its items is chosen from the call's sizes by rules
+ * calibrated on a few pyramids (devis_amd/csrc/msda_api.hip, launch_fast).  A caller that has TIMED the
+ * alternatives for a call shape pins the winner: from then on every call of that shape (any thread) takes it.  The reference
+ * has nothing like it (one kernel per direction, ms_deform_attn_cuda.cu:61-75, 121-153); results never depend on a pin.
+ *
+ *   msda_route_key    writes the NUL-terminated key of a call shape into buf (returns its length, or a negative msda_status):
+ *                     direction, msda_dtype code, clips, frames, window, S, M, D, L, Lq, points, and the HOST copy of the
+ *                     shapes -- calls made without spatial_shapes_host are never looked up.  Plain calls: clips = N, frames = 1,
+ *                     window = 0.
+ *   msda_pin_route    settings = "name=value name=value ..." with names fwd_rs, fwd_rs_nt, fwd_win, fwd_tile_waves, bwd_rs,
+ *                     bwd_rs_tpw, bwd_rs_fsplit, bwd_win (the MSDA_* knobs of the same names, see Conventions) and
+ *                     scatter_order (1 = level order, 2 = image order).  An empty string removes the pin.  A knob forced through
+ *                     the environment (MSDA_ENABLE_HOOKS=1) wins over a pin.
+ *   msda_clear_routes removes every pin;  msda_route_count: pins held.
+ * devis_amd.tune() measures and pins; devis_amd/routes.json is the table audited on MI355X, loaded with the library.
+ */
+int msda_route_key(int backward, int dtype, int clips, int frames, int window, int spatial_size, int num_heads, int channels,
+                   int num_levels, int num_query, int num_curr_point, int num_temp_point, const int64_t *spatial_shapes_host,
+                   char *buf, int buf_len);
+int msda_pin_route(const char *key, const char *settings);
+void msda_clear_routes(void);
+int msda_route_count(void);
 
 /*
  * Forward of one MSDeformAttnFunction call.

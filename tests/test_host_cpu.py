@@ -161,6 +161,41 @@ def test_frame_table_is_cached_per_offset_tensors():
     assert c is not b
 
 
+def test_route_table_keys_pins_and_files(tmp_path):
+    """include/msda.h ABI v12: the measured route table.  Keys come from the library (one definition), pins are added, replaced,
+    removed and counted, malformed settings are refused, and a routes file (the format of devis_amd/routes.json) loads."""
+    import json
+    from devis_amd import _native
+    _native.load()
+    before = _native.route_count()
+    pyr = [[45, 80], [23, 40], [12, 20], [6, 10]]
+    kf = _native.route_key(False, 0, 16, 6, 5, 4820, 8, 32, 4, 300, 4, 4, pyr)
+    kb = _native.route_key(True, 0, 16, 6, 5, 4820, 8, 32, 4, 300, 4, 4, torch.tensor(pyr))
+    assert kf == "f|0|16|6|5|4820|8|32|4|300|4|4|45x80,23x40,12x20,6x10" and kb == "b" + kf[1:]
+    assert _native.route_key(False, 2, 8, 1, 0, 22223, 8, 32, 4, 22223, 4, 4, [[100, 167], [50, 84], [25, 42], [13, 21]]) != kf
+    try:
+        _native.pin_route(kf, {"fwd_rs": 1, "fwd_rs_nt": 2})
+        _native.pin_route(kf, "fwd_win=1")                         # replaces
+        _native.pin_route(kb, {"bwd_rs_fsplit": 4, "scatter_order": 1})
+        assert _native.route_count() == before + 2
+        with pytest.raises(RuntimeError, match="cannot parse"):
+            _native.pin_route(kb, "tiles=3")
+        _native.pin_route(kf, "")                                  # removes
+        assert _native.route_count() == before + 1
+        path = tmp_path / "routes.json"
+        path.write_text(json.dumps({"device": "test", "routes": {kf: {"fwd_rs_nt": 1}, kb: {"bwd_win": 0}}}))
+        assert _native.load_routes(str(path)) == 2 and _native.route_count() == before + 2
+    finally:
+        _native.pin_route(kf, "")
+        _native.pin_route(kb, "")
+    assert _native.route_count() == before
+    shipped = _native.ROUTES_FILE
+    if os.path.exists(shipped):                                    # the audited table parses and every entry is accepted
+        doc = json.load(open(shipped))
+        assert set(doc) >= {"device", "routes"} and all(k[0] in "fb" for k in doc["routes"])
+        assert _native.route_count() >= min(1, len(doc["routes"]))
+
+
 def test_frame_tables_of_two_stacks_do_not_evict_each_other_and_are_thread_safe():
     """The encoder and the decoder stack hand different offset lists to their layers in turn (devis_transformer.py:103-121,
     151-169): each list keeps its own entry (round 4 had ONE class-level slot that the two stacks thrashed), and concurrent
