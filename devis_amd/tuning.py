@@ -139,7 +139,13 @@ def _case(shapes, dtype, loc_dtype, clips, Lq, kind, frames, heads, channels, po
             if rc:
                 raise RuntimeError(_native.load().msda_last_error().decode())
     dims = dict(clips=clips, frames=T, window=W, S=S, M=M, D=D, L=L, Lq=q, Pc=P, Pt=P if temporal else 1)
-    return fwd, bwd, dims, (gv, glc, out)
+
+    def scatter_only():
+        # MSDA_BWD_PHASES=2 runs the scatter alone on the records the last gather pass left; the gather pass is also what zeroes
+        # the scatter's work-ticket counters (include/msda.h), so they are zeroed here (a 64-byte fill, part of every timing alike)
+        ws[:16].zero_()
+        bwd()
+    return fwd, bwd, dims, scatter_only
 
 
 def _time(fn, reps):
@@ -209,7 +215,7 @@ def tune(spatial_shapes, dtype=torch.float32, clips=1, Lq=300, kind="decoder", f
     shapes = [tuple(int(v) for v in hw) for hw in (spatial_shapes.tolist() if hasattr(spatial_shapes, "tolist") else spatial_shapes)]
     # (16-bit modules hand the operator float32 sampling locations by default -- `sampling_fp32`, ABI v11 -- a call shape of its own)
     loc_dtype = torch.float32 if (sampling_fp32 and dtype in (torch.bfloat16, torch.float16)) else dtype
-    fwd, bwd, d, _ = _case(shapes, dtype, loc_dtype, clips, Lq, kind, frames, heads, channels, points, device)
+    fwd, bwd, d, scatter_only = _case(shapes, dtype, loc_dtype, clips, Lq, kind, frames, heads, channels, points, device)
     code = _native.type_code(dtype, loc_dtype)
     keys = {b: _native.route_key(b, code, d["clips"], d["frames"], d["window"], d["S"], d["M"], d["D"], d["L"], d["Lq"], d["Pc"], d["Pt"],
                                  shapes) for b in (False, True)}
@@ -224,7 +230,9 @@ def tune(spatial_shapes, dtype=torch.float32, clips=1, Lq=300, kind="decoder", f
         chosen = dict(dict(FWD_ROUTES)[best[0]]) if best[0] is not None and best[1] < MARGIN * auto else None
         report["forward"] = {"key": keys[False], "auto_ms": round(auto, 5), "times": times, "best": best[0], "pinned": chosen}
         g_auto, g_times, g_best = _race(knobs, bwd, GATHER_ROUTES, 1, reps, _accept)
-        s_auto, s_times, s_best = _race(knobs, bwd, SCATTER_ROUTES, 2, reps, lambda n, r: "owner-computes" in r)
+        knobs.set(None, None)
+        bwd()                                       # (a full backward first: the scatter-only calls below read its culling records)
+        s_auto, s_times, s_best = _race(knobs, scatter_only, SCATTER_ROUTES, 2, reps, lambda n, r: "owner-computes" in r)
         chosen_b = {}
         if g_best[0] is not None and g_best[1] < MARGIN * g_auto:
             chosen_b.update(dict(GATHER_ROUTES)[g_best[0]])
