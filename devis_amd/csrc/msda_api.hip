@@ -3,7 +3,6 @@
 // knobs and the per-device caches.  The kernels live in the other translation units of this directory.
 #include "msda_common.h"
 #include <algorithm>
-#include <cmath>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -61,7 +60,6 @@ struct Knobs {
     int bwd_summary = 1;                // 64-query block summaries for long candidate ranges
     int scatter_lds_kb = 144, scatter_dbg = 0;
     int scatter_own = -1;               // owner-computes scatter: -1 auto, 0 off (the LDS-atomic scatter instead)
-    int scatter_split = -1;             // heavy scatter items split by query range: -1 auto, 0 off, n: n parts wherever the partial area allows
     int force_generic = 0;
     int gv_storage = 1;                 // 0: msda_grad_value_dtype always answers the arithmetic type (A/B measurements)
     int dbg = 0;
@@ -93,7 +91,6 @@ void load_knobs()
         k.scatter_lds_kb = env_int("MSDA_SCATTER_LDS_KB", k.scatter_lds_kb);
         k.scatter_dbg = env_int("MSDA_SCATTER_DBG", k.scatter_dbg);
         k.scatter_own = env_int("MSDA_SCATTER_OWN", k.scatter_own);
-        k.scatter_split = env_int("MSDA_SCATTER_SPLIT", k.scatter_split);
         k.force_generic = env_int("MSDA_FORCE_GENERIC", 0) == 1;
         k.gv_storage = env_int("MSDA_GV_STORAGE", k.gv_storage);
         k.dbg = env_int("MSDA_DBG", 0);
@@ -465,42 +462,6 @@ bool storage_typed_grad_value_ok(int dtype, const Params &p)
     return true;
 }
 
-// Owner-computes scatter: query parts per item, level by level (Params::qsplit).  An item is a (clip, frame, head, band) whose
-// candidates are ALL (source, query) groups of its level -- culled by tap rows, but a band that spans most of its level keeps most
-// of them -- so with few, long items the kernel lasts as long as its heaviest one: on the 800x1333 encoder call the last level
-// (273 pixels, ONE band) takes the 533 k points of a (frame, head) = 260 chunks of 2048 = 2.4 ms of a 2.7 ms kernel whose work,
-// evenly spread, is 1.8 ms.  Items estimated at more than `target` points are dealt to several workgroups by query range, as far
-// as the partial area holds their maps (coarse levels first: they are the heavy ones and their maps are small).  Only an
-// estimate steers this -- band heights against tap rows are data -- and only speed depends on it.
-void plan_query_split(Params &p, unsigned grid)
-{
-    memset(p.qsplit, 1, sizeof p.qsplit);
-    const int mode = knobs().scatter_split;             // -1 auto, 0 off, n > 1: every band of a level that may be split gets n parts
-    if (!p.partial || !p.shapes_host || mode == 0 || p.L > kScatterMaxLevels) return;
-    const long long clips = p.groups / p.frames, units = clips * p.frames * p.M;
-    const double srcs = 1.0 + p.window;                 // sources of a frame: itself + on average `window` temporal slots
-    double total = 0.0;
-    double per_item[kScatterMaxLevels];
-    for (int l = 0; l < p.L; ++l) {
-        const long long H = p.shapes_host[2 * l], W = p.shapes_host[2 * l + 1];
-        if (H <= 0 || W <= 0 || W > kOwnPix) return;
-        const long long R = std::min<long long>(H, kOwnPix / W), nb = (H + R - 1) / R;
-        const double pts = srcs * p.Lq * (l < p.LA ? p.PA : p.PB);       // points a (frame, head) receives on this level
-        per_item[l] = pts / (double)nb;
-        total += pts * (double)units;
-    }
-    // a quarter of an even share per workgroup: the longest item then costs at most that much idle time at the end
-    const double target = std::max(8.0 * 2048.0, total / (4.0 * (double)grid));
-    long long rows_left = p.partial_rows;
-    for (int l = p.L - 1; l >= 0; --l) {
-        const long long hw = p.shapes_host[2 * l] * p.shapes_host[2 * l + 1];
-        int K = mode > 1 ? mode : (int)std::ceil(per_item[l] / target);
-        K = std::min(K, 16);
-        while (K > 1 && (long long)K * hw > rows_left) --K;
-        if (K > 1) { p.qsplit[l] = (unsigned char)K; rows_left -= (long long)K * hw; }
-    }
-}
-
 // Launches the forward, or the backward's gather pass + scatter, on the tile / resident-slab / scatter kernels.
 int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
 {
@@ -672,9 +633,7 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             rc = launch_zero_unowned(p, kOwnPix * p.D, p.gv_storage ? 2 : 4, stream);
             if (rc) return rc;
         }
-        Params ps = p;
-        plan_query_split(ps, grid);
-        return launch_scatter_grp(dtype, p.gv_storage != 0, ps, grid * (1024 / kOwnThreads), (knobs().scatter_dbg & (511 | 2048)) | (fused_zero ? 512 : 0), stream);
+        return launch_scatter_grp(dtype, p.gv_storage != 0, p, grid * (1024 / kOwnThreads), (knobs().scatter_dbg & (511 | 2048)) | (fused_zero ? 512 : 0), stream);
     }
     if (p.gv_storage) return fail(MSDA_ERR_ARG, "msda backward: this call needs grad_value in the arithmetic type (see msda_grad_value_dtype)%s");
     // LDS-atomic scatter: 144 KiB of 8-byte accumulators per workgroup
@@ -783,26 +742,11 @@ long long workspace_need(int batch, int num_query, int num_heads, int virtual_le
            (long long)batch * num_heads * virtual_levels * nblk * 8;
 }
 
-// ... + for long candidate ranges (encoder-shaped calls) the partial maps of split scatter items (plan_query_split): num_query
-// pixel rows of 32 float channels per (map, head) -- as many rows as an encoder-shaped call has pixels
-long long workspace_partial_bytes(int batch, int num_query, int num_heads)
-{
-    return num_query >= 2048 ? ((long long)batch * num_query * num_heads * 128 + 255) / 256 * 256 : 0;
-}
-
 void attach_workspace(Params &p, void *workspace, long long bytes, int batch, int num_query, int num_heads, int vl)
 {
     p.workspace = (workspace && bytes >= MSDA_BWD_WORKSPACE_BYTES) ? static_cast<unsigned *>(workspace) : nullptr;
     p.bbox = nullptr;
     p.bsum = nullptr;
-    p.partial = nullptr;
-    p.partial_rows = 0;
-    memset(p.qsplit, 1, sizeof p.qsplit);
-    const long long need = workspace_need(batch, num_query, num_heads, vl), part_bytes = workspace_partial_bytes(batch, num_query, num_heads);
-    if (p.workspace && part_bytes > 0 && bytes >= (need + 255) / 256 * 256 + part_bytes) {       // (sized for D = 32: the only user)
-        p.partial = reinterpret_cast<float *>(reinterpret_cast<char *>(p.workspace) + (need + 255) / 256 * 256);
-        p.partial_rows = num_query;
-    }
     if (p.workspace && bytes >= workspace_need(batch, num_query, num_heads, vl) && knobs().bwd_cull != 0) {
         p.bbox = reinterpret_cast<int *>(p.workspace) + MSDA_BWD_WORKSPACE_BYTES / 4;
         // block summaries only pay for long candidate ranges (and index (group, head, level) rows with 32 bits)
@@ -877,9 +821,7 @@ const char *msda_last_route(void) { return g_route; }
 
 long long msda_backward_workspace_bytes(int batch, int num_query, int num_heads, int virtual_levels)
 {
-    const long long part = workspace_partial_bytes(batch, num_query, num_heads);
-    const long long need = workspace_need(batch, num_query, num_heads, virtual_levels);
-    return part ? (need + 255) / 256 * 256 + part : need;
+    return workspace_need(batch, num_query, num_heads, virtual_levels);
 }
 
 const char *msda_last_error(void) { return g_err; }

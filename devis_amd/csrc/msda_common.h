@@ -252,13 +252,6 @@ struct Params {
     int wide_loads;             // loc / attn arrays are 16-byte aligned (resident-slab kernels: whole-row loads)
     int dbg;                    // measurement hooks (MSDA_DBG env), 0 in production
     int gv_storage;             // bwd: grad_value is in the STORAGE type (16-bit), not the arithmetic type (owner-computes scatter only)
-    // Owner-computes scatter, HEAVY items split by query range (round 5): the candidates of a (clip, frame, head, band) item of
-    // level l are dealt to qsplit[l] items ("query parts"), each summing its share into a float partial map in `partial`
-    // ([group][sum over split levels of qsplit[l] * H_l * W_l pixel rows][M][D]); msda_scatter_reduce_kernel adds the parts
-    // in part order and writes grad_value.  Chosen by the HOST (sizes + its copy of the shapes); all 1 / null = no split.
-    unsigned char qsplit[32];   // (kScatterMaxLevels)
-    float *partial;             // device, or null
-    int partial_rows;           // pixel rows per group the partial area holds
 };
 
 struct Level { int H, W, start, pad; };   // start = first pixel of the level inside the CLIP slab

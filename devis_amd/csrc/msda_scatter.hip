@@ -479,11 +479,7 @@ __device__ __forceinline__ int per_item(int x)
     return x;
 }
 
-// SORTED: items in image order (long candidate ranges); TL: storage type of sampling_loc / attn_weight (T, or float with a 16-bit T);
-// SPLIT: heavy items dealt to several workgroups by query range (Params::qsplit) -- an instantiation of its own, so that the
-// kernel of the calls that never split (every decoder call) keeps its register allocation (it sits 0-2 VGPRs under the budget of
-// 1024-thread workgroups; the split instantiations spill 4-5, outside the chunk loop)
-template <typename T, typename TL, typename GV, bool SORTED, bool SPLIT>
+template <typename T, typename TL, typename GV, bool SORTED>        // SORTED: items in image order (long candidate ranges); TL: storage type of sampling_loc / attn_weight (T, or float with a 16-bit T)
 __global__ void __launch_bounds__(kOwnThreads, 4)
 msda_bwd_value_grp_kernel(const Params p, int dbg)
 {
@@ -501,7 +497,6 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
     unsigned *list = head + kOwnPix;                                            // [kGrpList] (k:6 | points:4 | q:22)
     __shared__ int s_H[kScatterMaxLevels], s_W[kScatterMaxLevels], s_R[kScatterMaxLevels],
         s_first[kScatterMaxLevels + 1], s_lsi[kScatterMaxLevels];
-    __shared__ int s_K[kScatterMaxLevels], s_poff[kScatterMaxLevels];      // query parts per item of the level; its first row in the partial area
     __shared__ int s_cnt[3];             // survivor counters rotate: slot j is reset two barriers before it is used again
     // Item descriptors and source tables are double-buffered: wave 0 prepares item n + 1 (ticket, decode, tables) in the shadow
     // of item n's first culling records, so an item starts without a barrier or a division of its own.
@@ -522,19 +517,13 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
     int tr_n = 0;
 #endif
     if (tid == 0) {
-        int first = 0, poff = 0;
+        int first = 0;
         for (int l = 0; l < L; ++l) {
             const int H = (int)p.shapes[2 * l], W = (int)p.shapes[2 * l + 1];
             const int R = min(H, kOwnPix / max(1, W));          // rows per band; 0 = "direct" level (row wider than a band)
-            // query parts: only with a partial area that holds them (the host sized qsplit by ITS copy of the shapes; the device
-            // shapes decide what fits -- a level that does not fit is not split: slower, never wrong)
-            int K = (SPLIT && p.partial != nullptr && R > 0) ? max(1, (int)p.qsplit[l]) : 1;
-            if (K > 1 && (long long)poff + (long long)K * H * W > (long long)p.partial_rows) K = 1;
             s_H[l] = H; s_W[l] = W; s_R[l] = R; s_lsi[l] = (int)p.lsi[l];
-            s_K[l] = K; s_poff[l] = poff;
-            if (K > 1) poff += K * H * W;
             s_first[l] = first;
-            first += ((R > 0) ? (H + R - 1) / R : 1) * K;
+            first += (R > 0) ? (H + R - 1) / R : 1;
         }
         s_first[L] = first;
         s_cnt[0] = s_cnt[1] = s_cnt[2] = 0;
@@ -559,7 +548,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             // zero-filled grad_value for the float-atomic branch -- but the DEVICE shapes have a level wider than a band: the hint
             // was stale.  Sums added into the unzeroed buffer would be silently wrong; the level's pixels are poisoned with NaN
             // instead (the atomic adds of its items, before or after this store, leave NaN), so that the caller's mistake shows in
-            // the first value it reads.
+            // the first value it reads.  (In the prologue, not in the item loop: the kernel sits at its register budget.)
             GV *dst = static_cast<GV *>(p.grad_value) + idx * (p.M * D);
             const GV fill = wide ? GV(__builtin_nanf("")) : GV(0.f);
             for (int c = 0; c < p.M * D; ++c) dst[c] = fill;
@@ -577,7 +566,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             if (tid < NB) {
                 int l = 0;
                 while (l + 1 < L && s_first[l + 1] <= tid) ++l;
-                s_key[tid] = s_R[l] > 0 ? (float)(((tid - s_first[l]) / (SPLIT ? s_K[l] : 1)) * s_R[l]) / (float)s_H[l] : 0.f;
+                s_key[tid] = s_R[l] > 0 ? (float)((tid - s_first[l]) * s_R[l]) / (float)s_H[l] : 0.f;
             }
             __syncthreads();
             if (tid < NB) {
@@ -701,10 +690,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         }
         const int H = s_H[l], W = s_W[l], R = s_R[l];
         const bool direct = (R == 0);
-        // query part of a split item (K = 1: the whole item).  (K and the part are re-read from LDS where they are needed again --
-        // the stores at the end of the item -- instead of living in scalar registers across the chunks: SGPR spills cost VGPRs)
-        const int K = SPLIT ? s_K[l] : 1, qpart = (part - s_first[l]) % K;
-        const int r0 = direct ? 0 : ((part - s_first[l]) / K) * R;
+        const int r0 = direct ? 0 : (part - s_first[l]) * R;
         const int r1 = direct ? H - 1 : min(H, r0 + R) - 1;
         const int npix = direct ? 0 : (r1 - r0 + 1) * W;
         // Small bands (the last pyramid levels: 60 pixels at 360x640) would keep only npix of the 256 owner quads busy
@@ -929,27 +915,25 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             }
             __syncthreads();
         }
-        // a split item culls its own share of the candidate batches (contiguous: consecutive queries, i.e. one region of the image)
-        const int b_lo = (int)((long long)qpart * nbat / K), b_hi = (int)((long long)(qpart + 1) * nbat / K);
-        auto next_live = [&](int bq) {       // first batch >= bq worth culling (b_hi if none); workgroup-uniform
-            if (!skipping) return min(bq, b_hi);
-            while (bq < b_hi) {
+        auto next_live = [&](int bq) {       // first batch >= bq worth culling (nbat if none); workgroup-uniform
+            if (!skipping) return min(bq, nbat);
+            while (bq < nbat) {
                 const unsigned wv = s_live[bq >> 5] >> (bq & 31);
-                if (wv) return min(bq + (int)__builtin_ctz(wv), b_hi);
+                if (wv) return min(bq + (int)__builtin_ctz(wv), nbat);
                 bq = (bq | 31) + 1;
             }
-            return b_hi;
+            return nbat;
         };
         int2 iv;
         unsigned ent;
         bool live;
-        int bcur = next_live(b_lo);
-        if (bcur < b_hi) load_records(bcur * kOwnThreads, iv, ent, live);
+        int bcur = next_live(0);
+        if (bcur < nbat) load_records(bcur * kOwnThreads, iv, ent, live);
         // the next item's descriptor and tables, while the records fly -- with a static stride; a dynamic schedule draws its
         // ticket as late as it can (below): a workgroup that commits itself to a heavy item one item early is missing at the tail
         // (measured: 800x1333 encoder call 2.76 -> 3.58 ms with early tickets)
         if (wave == 0 && !dynamic) prepare(it + 1u, cur ^ 1);
-        while (bcur < b_hi) {
+        while (bcur < nbat) {
             const int bnext = next_live(bcur + 1);
             unsigned pm = 0u;
             if (live) {
@@ -962,7 +946,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                 }
             }
             const unsigned ent_now = ent;
-            const bool last = bnext >= b_hi;
+            const bool last = bnext >= nbat;
             if (!last) load_records(bnext * kOwnThreads, iv, ent, live);      // the next live batch's records fly meanwhile
             // wave-wide exclusive scan of the per-lane survivor flags (DPP), one LDS atomic per wave
             const int cnt = pm != 0u;
@@ -1011,61 +995,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                 SlabStore<GV>::store(dst, v);
             }
         };
-        int l_end = l;
-        asm volatile("" : "+v"(l_end));             // (an opaque copy: the loads below are not merged with the ones at the item's start)
-        l_end = __builtin_amdgcn_readfirstlane(l_end);
-        const int K_end = SPLIT ? s_K[l_end] : 1;
-        // The band as FLOATS at `band` (pixel stride MD): grad_value itself when it is fp32, or -- a query part of a split item --
-        // the part's own map of the level in the partial area ([group][level's first row + part * H * W + pixel][M][D];
-        // msda_scatter_reduce_kernel adds the parts up and writes grad_value in its type).
-        auto store_float_band = [&](float *band) {
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            if (SF == 1) {
-                float *pquad = band + (int64_t)per_item(Q) * MD;
-#pragma unroll
-                for (int s = 0; s < kOwnSlots; ++s)
-                    if (s * kOwnQuads + Q < npix) {
-                        float *o = pquad + (int64_t)s * kOwnQuads * MD;
-                        __builtin_nontemporal_store((f32x4){acc[s][0], acc[s][1], acc[s][2], acc[s][3]}, reinterpret_cast<f32x4 *>(o + off1 / 4));
-                        __builtin_nontemporal_store((f32x4){acc[s][4], acc[s][5], acc[s][6], acc[s][7]}, reinterpret_cast<f32x4 *>(o + (off1 ^ 64) / 4));
-                    }
-            } else {
-                // split lists: the partial sums of virtual pixel v = pix * SF + sub (slot 0 of quad v) go through the (now
-                // free) row area as [v][32 channels] floats; one thread per (pixel, 4 channels) adds the SF partials
-                float *part = reinterpret_cast<float *>(rows);
-                if (Q < nvpix) {
-                    float *mine = part + per_item(Q) * D;
-                    *reinterpret_cast<float4 *>(mine + per_item(off1) / 4) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
-                    *reinterpret_cast<float4 *>(mine + (per_item(off1) ^ 64) / 4) = make_float4(acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
-                }
-                __syncthreads();
-                for (int i = tid; i < npix * (D / 4); i += kOwnThreads) {
-                    const int pix = i / (D / 4), c4 = (i - pix * (D / 4)) * 4;
-                    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int u = 0; u < SF; ++u) {
-                        const float4 t4 = *reinterpret_cast<const float4 *>(part + ((pix << sfs) + u) * D + c4);
-                        sum.x += t4.x; sum.y += t4.y; sum.z += t4.z; sum.w += t4.w;
-                    }
-                    __builtin_nontemporal_store((f32x4){sum.x, sum.y, sum.z, sum.w}, reinterpret_cast<f32x4 *>(band + (int64_t)pix * MD + c4));
-                }
-            }
-        };
-        float *pband = nullptr;
-        if (K_end > 1) {
-            const int qpart_end = (s_desc2[cur][2] - s_first[l_end]) % K_end;
-            pband = p.partial + ((((int64_t)clip * p.frames + f) * p.partial_rows + s_poff[l_end] + (int64_t)qpart_end * H * W +
-                                  (int64_t)r0 * W) * MD + m * D);
-        }
-        bool stored = direct;
-        if constexpr (std::is_same<GV, float>::value) {
-            if (!direct) store_float_band(pband ? pband : reinterpret_cast<float *>(gmap + (int64_t)r0 * W * MD));
-            stored = true;
-        } else {
-            if (!direct && pband) { store_float_band(pband); stored = true; }
-        }
-        if (stored) {
-            // (done above, or a level on the float-atomic branch)
-        } else if (SF == 1) {
+        if (!direct && SF == 1) {
             GV *gband = gmap + (int64_t)r0 * W * MD;
             GV *gquad = gband + (int64_t)per_item(Q) * MD;          // pixel Q of the band; slot s is kOwnQuads pixels further
 #pragma unroll
@@ -1107,7 +1037,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                     }
                 }
             }
-        } else {
+        } else if (!direct) {
             // split lists: the partial sums of virtual pixel v = pix * SF + sub (slot 0 of quad v) go through the (now
             // free) row area as [v][32 channels] floats; one thread per (pixel, 4 channels) adds the SF partials
             float *part = reinterpret_cast<float *>(rows);
@@ -1159,57 +1089,6 @@ msda_zero_unowned_kernel(const Params p, int cap_slots, int gv_bytes)
     }
 }
 
-// Split items (Params::qsplit): grad_value[pixel] = sum over the level's query parts, in part order, of their partial maps --
-// one thread per (group, pixel row of a split level, head, 4 channels).  Levels are re-derived from the device shapes exactly
-// as msda_bwd_value_grp_kernel derives them.
-template <typename GV>
-__global__ void __launch_bounds__(256)
-msda_scatter_reduce_kernel(const Params p)
-{
-    __shared__ int s_n[kScatterMaxLevels], s_k[kScatterMaxLevels], s_po[kScatterMaxLevels], s_ls[kScatterMaxLevels], s_rows;
-    const int D = 32, MD = p.M * D;
-    if (threadIdx.x == 0) {
-        int poff = 0, rows = 0;
-        for (int l = 0; l < p.L; ++l) {
-            const int H = (int)p.shapes[2 * l], W = (int)p.shapes[2 * l + 1];
-            const int R = min(H, kOwnPix / max(1, W));
-            int K = (p.partial != nullptr && R > 0) ? max(1, (int)p.qsplit[l]) : 1;
-            if (K > 1 && (long long)poff + (long long)K * H * W > (long long)p.partial_rows) K = 1;
-            s_k[l] = K; s_po[l] = poff; s_ls[l] = (int)p.lsi[l];
-            s_n[l] = K > 1 ? H * W : 0;
-            if (K > 1) { poff += K * H * W; rows += H * W; }
-        }
-        s_rows = rows;
-    }
-    __syncthreads();
-    const int rows = s_rows;
-    if (rows == 0) return;
-    const int64_t total = (int64_t)p.groups * rows * p.M * (D / 4);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % (D / 4)) * 4;
-        int64_t rest = i / (D / 4);
-        const int m = (int)(rest % p.M); rest /= p.M;
-        int r = (int)(rest % rows);
-        const int64_t g = rest / rows;
-        int l = 0;
-        while (r >= s_n[l]) { r -= s_n[l]; ++l; }           // (levels that are not split hold 0 rows)
-        const int n = s_n[l], K = s_k[l];
-        const float *src = p.partial + ((g * p.partial_rows + s_po[l] + r) * MD + m * D + c4);
-        float4 sum = *reinterpret_cast<const float4 *>(src);
-        for (int k = 1; k < K; ++k) {
-            const float4 t = *reinterpret_cast<const float4 *>(src + (int64_t)k * n * MD);
-            sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
-        }
-        GV *dst = static_cast<GV *>(p.grad_value) + ((g * p.S + s_ls[l] + r) * MD + m * D + c4);
-        if constexpr (std::is_same<GV, float>::value) {
-            *reinterpret_cast<float4 *>(dst) = sum;
-        } else {
-            const float v[4] = {sum.x, sum.y, sum.z, sum.w};
-            SlabStore<GV>::store(dst, v);
-        }
-    }
-}
-
 template <typename T, typename TL, int G>
 int scatter_lds(const Params &p, unsigned grid, int cap_bytes, int dbg, hipStream_t stream)
 {
@@ -1235,33 +1114,14 @@ int scatter_lds_g(int G, const Params &p, unsigned grid, int cap_bytes, int dbg,
     }
 }
 
-template <typename T, typename TL, typename GV, bool SORTED, bool SPLIT>
-int scatter_grp_launch(const Params &p, unsigned grid, int dbg, hipStream_t stream)
-{
-    static LdsGrant granted;
-    const auto kern = &msda_bwd_value_grp_kernel<T, TL, GV, SORTED, SPLIT>;
-    if (const int rc = grant_lds(reinterpret_cast<const void *>(kern), (size_t)grp_lds_bytes<T>(), granted,
-                                 "the group-granular owner-computes scatter kernel")) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kOwnThreads), (size_t)grp_lds_bytes<T>(), stream, p, dbg);
-    return MSDA_OK;
-}
-
 template <typename T, typename TL, typename GV, bool SORTED>
 int scatter_grp(const Params &p, unsigned grid, int dbg, hipStream_t stream)
 {
-    bool split = false;
-    for (int l = 0; p.partial && l < p.L && l < kScatterMaxLevels; ++l) split = split || p.qsplit[l] > 1;
-    if (const int rc = split ? scatter_grp_launch<T, TL, GV, SORTED, true>(p, grid, dbg, stream)
-                             : scatter_grp_launch<T, TL, GV, SORTED, false>(p, grid, dbg, stream)) return rc;
-    if (split) {
-        if (const int rc = check_launch(SORTED ? "msda backward (owner-computes scatter kernel, group-granular, items in image order, heavy items split by query range)"
-                                               : "msda backward (owner-computes scatter kernel, group-granular, heavy items split by query range)")) return rc;
-        const int64_t work = (int64_t)p.groups * p.partial_rows * p.M * 8;
-        const unsigned rb = (unsigned)std::min<int64_t>((work + 255) / 256, 8192);
-        hipLaunchKernelGGL(msda_scatter_reduce_kernel<GV>, dim3(rb ? rb : 1), dim3(256), 0, stream, p);
-        return check_launch(std::is_same<GV, float>::value ? "msda backward (sum of the query parts)"
-                                                           : "msda backward (sum of the query parts, grad_value in the storage type)");
-    }
+    static LdsGrant granted;
+    const auto kern = &msda_bwd_value_grp_kernel<T, TL, GV, SORTED>;
+    if (const int rc = grant_lds(reinterpret_cast<const void *>(kern), (size_t)grp_lds_bytes<T>(), granted,
+                                 "the group-granular owner-computes scatter kernel")) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kOwnThreads), (size_t)grp_lds_bytes<T>(), stream, p, dbg);
     if (SORTED)
         return check_launch(std::is_same<GV, float>::value ? "msda backward (owner-computes scatter kernel, group-granular, items in image order)"
                                                            : "msda backward (owner-computes scatter kernel, group-granular, items in image order, grad_value in the storage type)");
@@ -1313,7 +1173,7 @@ int launch_scatter_grp(int dtype, bool storage_typed, const Params &p, unsigned 
             const long long H = p.shapes_host[2 * l], W = p.shapes_host[2 * l + 1];
             if (H <= 0 || W <= 0) { sorted = false; break; }         // (degenerate level: the device counts its bands differently)
             const long long R = W > 0 ? std::min<long long>(H, kOwnPix / W) : 0;
-            bands += (R > 0 ? (int)((H + R - 1) / R) : 1) * (p.partial && R > 0 && p.qsplit[l] > 1 ? (int)p.qsplit[l] : 1);
+            bands += R > 0 ? (int)((H + R - 1) / R) : 1;
         }
         sorted = sorted && bands <= kOwnMaxSorted;
         if constexpr (sizeof(T) == 2) {

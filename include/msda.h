@@ -183,10 +183,7 @@ int msda_grad_value_dtype(int dtype, int clips, int frames, int window, int spat
  * 64 (ticket counters) + rows * virtual_levels * 8 (per-point culling records) + their summaries over blocks of 64
  * queries (batch * num_heads * virtual_levels * ceil(num_query / 64) * 8), with rows = batch * num_query *
  * num_heads and virtual_levels = num_levels (msda_backward) or num_levels * (1 + window)
- * (msda_temporal_backward; batch = clips * frames); since ABI v12, for num_query >= 2048 (encoder-shaped calls), also
- * batch * num_query * num_heads * 128 bytes of float partial maps: the scatter splits its heaviest work items -- the
- * coarse levels, where one (frame, head) item would otherwise last as long as the whole kernel -- by query range and
- * sums the parts in a fixed order afterwards.  A shorter workspace is valid (no split). */
+ * (msda_temporal_backward; batch = clips * frames). */
 long long msda_backward_workspace_bytes(int batch, int num_query, int num_heads, int virtual_levels);
 
 /*

@@ -462,54 +462,6 @@ def test_image_order_scatter_on_a_batch_of_clips(dtype, tol):
             assert err <= 3 * tol * scale(refs[c][1 + i]), (c, i, err)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3), (torch.float32, 2e-5)], ids=["bf16", "f16", "f32"])
-@pytest.mark.parametrize("parts", [2, 5])
-def test_scatter_items_split_by_query_range(dtype, tol, parts, monkeypatch):
-    """Round 5: heavy scatter items -- a (clip, frame, head, band) of a coarse level of an encoder-shaped call keeps every query as a
-    candidate -- are dealt to several workgroups by query range, their float partial maps summed in part order by a second
-    kernel that writes grad_value in its type (fp32, or the 16-bit storage type).  Forced here (MSDA_SCATTER_SPLIT) on a batch of
-    two clips whose partial area holds 5 parts of the last two levels (small bands: several owner quads per pixel) but only 3 of
-    level 1 and none of level 0 -- local sampling in one clip, range-wide in the other; grad_value DIRECTLY against the oracle."""
-    from devis_amd.functions import MSDeformAttnTemporalFunction
-    monkeypatch.setenv("MSDA_SCATTER_SPLIT", str(parts))
-    shapes = [(40, 48), (20, 24), (10, 12), (5, 6)]            # S = 2550 >= 2048: the workspace carries a partial area
-    S = int(sum(hh * ww for hh, ww in shapes))
-    clips, T, M = 2, 2, 2
-    keys = ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")
-    ds, refs = [], []
-    for c in range(clips):
-        d = make_temporal_inputs(300 + c, T=T, W=T - 1, M=M, D=32, Lq=S, shapes=shapes, Pc=4, Pt=4)
-        if c == 0:
-            d["loc_c"] = localise(d["loc_c"], shapes, 2.0, 7)
-            d["loc_t"] = localise(d["loc_t"], shapes, 2.0, 8)
-        d = round_to({k: (np.asarray(v, dtype=np.float64) if v.dtype.kind == "f" else v) for k, v in d.items()}, dtype)
-        ds.append(d)
-        refs.append(temporal_reference(*(d[k] for k in keys)))
-    cat = lambda k: torch.from_numpy(np.concatenate([d[k] for d in ds], 0)).to(DEV, dtype).requires_grad_(True)
-    leaves = [cat(k) for k in ("value", "loc_c", "aw_c", "loc_t", "aw_t")]
-    d0 = ds[0]
-    dev = lambda k: torch.from_numpy(d0[k]).to(DEV)
-    out = MSDeformAttnTemporalFunction.apply(leaves[0], dev("shapes"), dev("lsi"), dev("ftab"), *leaves[1:], clips)
-    grads = torch.autograd.grad(out, leaves, cat("grad_out").detach())
-    route = _direct_temporal_backward_route(leaves[0], dev("shapes"), dev("lsi"), dev("ftab"), *leaves[1:], cat("grad_out").detach(), clips)
-    assert "split by query range" in route and "sum of the query parts" in route, route
-    assert ("storage type" in route) == (dtype != torch.float32), route
-    scale = lambda x: max(1.0, float(np.abs(x).max()))
-    for c in range(clips):
-        sl = slice(c * T, (c + 1) * T)
-        err = _maxabs(grads[0][sl].double().cpu().numpy(), refs[c][1])
-        assert err <= 2 * tol * scale(refs[c][1]), (c, err)
-    # the same call without the split: identical up to the order of a pixel's fp32 terms
-    monkeypatch.setenv("MSDA_SCATTER_SPLIT", "0")
-    from devis_amd import _native
-    _native.reload_knobs()
-    plain = torch.autograd.grad(MSDeformAttnTemporalFunction.apply(leaves[0], dev("shapes"), dev("lsi"), dev("ftab"), *leaves[1:], clips),
-                                leaves, cat("grad_out").detach())
-    assert "split by query range" not in _direct_temporal_backward_route(leaves[0], dev("shapes"), dev("lsi"), dev("ftab"), *leaves[1:],
-                                                                         cat("grad_out").detach(), clips)
-    assert _maxabs(plain[0].double().cpu().numpy(), grads[0].double().cpu().numpy()) <= 2 * tol * scale(refs[0][1])
-
-
 def test_forward_resident_slab_kernel_forced(monkeypatch):
     """MSDA_FWD_RS=1 forces the resident-slab forward (levels 1.. of a source frame in a workgroup-shared LDS slab) on
     shapes the host heuristic would leave to the tile kernel (fixtures with D != 32 stay there)."""
