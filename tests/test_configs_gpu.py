@@ -55,11 +55,23 @@ def test_cfg4_plain_op_swinl_shapes(shapes, Lq, step, dtype, tol_out, tol_grad):
 
 
 def test_cfg4_im2col_step_values_agree_bitwise():
-    """The chunk loop only moves pointers (cu:61-75): step 1 and step 64 give identical forward results."""
+    """The chunk loop only moves pointers (cu:61-75): step 1 and step 64 give identical forward results -- bit for bit while the
+    same kernel family serves both batch sizes (the route RULES do here); with the measured route table (devis_amd/routes.json,
+    round 5) a batch of 6 may be pinned to another family than a batch of 1, and the two then agree to rounding (another order
+    of the same fp32 terms), like the reference's own atomicAdd order."""
+    from devis_amd import _native
     d = round_to(make_inputs(7, 6, 8, 32, 300, SWIN_PYRAMID, 4, "unit", np.float32, value_scale=1.0), torch.float16)
-    a, b = _run_op(d, torch.float16, 1), _run_op(d, torch.float16, 64)
+    _native.load()
+    _native.clear_routes()
+    try:
+        a, b = _run_op(d, torch.float16, 1), _run_op(d, torch.float16, 64)
+    finally:
+        _native._load_shipped_routes()
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
     assert _maxabs(a[1], b[1]) <= 1e-3 * max(1.0, np.abs(b[1]).max())      # grad_value: summation order may differ
+    a, b = _run_op(d, torch.float16, 1), _run_op(d, torch.float16, 64)      # ... and on whatever routes the table pins
+    for x, y, tol in ((a[0], b[0], 2e-3), (a[1], b[1], 1e-2), (a[3], b[3], 1e-2)):
+        assert _maxabs(x, y) <= tol * max(1.0, np.abs(y).max())
 
 
 BENCH_SCALE = [
