@@ -73,3 +73,17 @@ def oracle():
     from oracle import msda_oracle
     msda_oracle.build()
     return msda_oracle
+
+
+@pytest.fixture()
+def route_rules_only():
+    """For tests that assert which kernel the route RULES (csrc/msda_api.hip) pick: the measured route table
+    (devis_amd/routes.json) is taken out for the test and put back afterwards."""
+    from devis_amd import _native
+    _native.load()
+    _native.clear_routes()
+    try:
+        yield
+    finally:
+        _native.clear_routes()
+        _native._load_shipped_routes()

@@ -120,7 +120,7 @@ def test_window_kernels_take_the_other_value_layouts(layout, dtype, tol, monkeyp
         assert _maxabs(grads[i].double().cpu().numpy(), ref[1 + i]) <= (2e-5 if dtype == torch.float32 else 3 * tol) * scale(ref[1 + i]), i
 
 
-def test_window_route_is_automatic_where_the_slab_holds_the_last_level_only():
+def test_window_route_is_automatic_where_the_slab_holds_the_last_level_only(route_rules_only):
     """Automatic route: one query per pixel AND a pyramid of which the resident-slab kernels could keep the last level at most
     (fp32 at 800x1333).  (The gather pass follows the same rule; the backward runs on an autograd thread, whose route string
     this thread cannot read -- bench.py names the kernels of both directions.)"""
