@@ -527,7 +527,8 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
         // (profiles/r04_logs/small_batch_tile_waves.log: no gain at 1824 workgroups).
         const int chunks = (p.LA * p.PA + kPch - 1) / kPch + (p.LB * p.PB + kPch - 1) / kPch;
         int waves = knobs().fwd_tile_waves;
-        if (waves < 0) waves = blocks <= (esz == 4 ? 768 : 1024) ? 3 : 1;
+        // (fewer single-wave workgroups than SIMDs -- 4 per CU; 4-byte types: than three quarters of them)
+        if (waves < 0) waves = blocks <= (long long)device_cus() * (esz == 4 ? 3 : 4) ? 3 : 1;
         waves = std::max(1, std::min(std::min(waves, chunks), kTileMaxWaves));
         if (!(G == 4 || G == 8)) waves = 1;
         auto lds_of = [&](int w) { return (size_t)w * RPW * kRowSlots * 32 + (size_t)(p.LA + p.LB) * sizeof(Level) + (size_t)w * kWave * VEC * 4; };

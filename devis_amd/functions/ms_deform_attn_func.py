@@ -269,14 +269,22 @@ def _split_k_wgrad(g2d, x2d, rows_per_split=1024):
     ``[out, in]`` result: the BLAS library runs that as 32 workgroups of one 32x64 tile each (0.109 ms for 256 x 256 in fp32,
     0.104 in bf16 on MI355X -- the largest single kernel of a decoder-layer step, profiles/r04_logs/module_kernels.txt).
     Cut into slices of ~``rows_per_split`` rows it is one batched product plus a sum over the slices: 0.067 / 0.047 ms
-    (scripts/wgrad_probe.py).  The slices' partial results are added in the tensors' own precision."""
+    (scripts/wgrad_probe.py).  For 16-bit tensors the slices' partial results are summed in float32 and rounded ONCE -- a single
+    GEMM accumulates all rows in fp32, and rounding each of the ~28 partials to 16 bits first cost the weight gradient a
+    digit."""
     R = g2d.shape[0]
     k = R // rows_per_split
     if k < 4 or not g2d.is_contiguous() or not x2d.is_contiguous():
         return g2d.t() @ x2d
     r = R // k
     main = r * k
-    w = torch.bmm(g2d[:main].view(k, r, -1).transpose(1, 2), x2d[:main].view(k, r, -1)).sum(0)
+    parts = torch.bmm(g2d[:main].view(k, r, -1).transpose(1, 2), x2d[:main].view(k, r, -1))
+    if parts.dtype in (torch.bfloat16, torch.float16):
+        w = parts.sum(0, dtype=torch.float32)
+        if main < R:
+            w = w + (g2d[main:].t() @ x2d[main:]).float()
+        return w.to(g2d.dtype)
+    w = parts.sum(0)
     if main < R:
         w.addmm_(g2d[main:].t(), x2d[main:])
     return w

@@ -15,9 +15,12 @@ ROUTES = [{}, {"MSDA_SCATTER_DBG": "16"}, {"MSDA_BWD_CULL": "2"}, {"MSDA_BWD_CUL
           {"MSDA_FWD_RS": "1", "MSDA_BWD_RS": "1", "MSDA_SCATTER_DBG": "16"}, {"MSDA_BWD_RS": "1", "MSDA_BWD_CULL": "0"},
           {"MSDA_BWD_MODE": "atomic"}, {"MSDA_FWD_RS": "1", "MSDA_FWD_RS_NT": "4"},
           {"MSDA_BWD_RS": "1", "MSDA_BWD_RS_FSPLIT": "1"}, {"MSDA_BWD_RS": "1", "MSDA_BWD_RS_FSPLIT": "2", "MSDA_FWD_RS": "1", "MSDA_FWD_RS_NT": "2"},
-          {"MSDA_BWD_RS": "1", "MSDA_BWD_RS_FSPLIT": "4"}, {"MSDA_BWD_RS": "1", "MSDA_BWD_RS_TPW": "2", "MSDA_BWD_RS_FSPLIT": "0"}]
+          {"MSDA_BWD_RS": "1", "MSDA_BWD_RS_FSPLIT": "4"}, {"MSDA_BWD_RS": "1", "MSDA_BWD_RS_TPW": "2", "MSDA_BWD_RS_FSPLIT": "0"},
+          # the tile forward with 1 / 2 / 5 / 8 waves per tile (auto picks 3 or 1: the LDS clamp loop and the other counts ran nowhere)
+          {"MSDA_FWD_RS": "0", "MSDA_FWD_TILE_WAVES": "1"}, {"MSDA_FWD_RS": "0", "MSDA_FWD_TILE_WAVES": "2"},
+          {"MSDA_FWD_RS": "0", "MSDA_FWD_TILE_WAVES": "5"}, {"MSDA_FWD_RS": "0", "MSDA_FWD_TILE_WAVES": "8"}]
 KEYS = ["MSDA_SCATTER_DBG", "MSDA_BWD_CULL", "MSDA_SCATTER_LDS_KB", "MSDA_SCATTER_OWN", "MSDA_FWD_RS", "MSDA_BWD_RS", "MSDA_BWD_MODE", "MSDA_FWD_RS_NT",
-        "MSDA_BWD_RS_FSPLIT", "MSDA_BWD_RS_TPW"]
+        "MSDA_BWD_RS_FSPLIT", "MSDA_BWD_RS_TPW", "MSDA_FWD_TILE_WAVES"]
 def maxabs(a, b): return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max()) if a.size else 0.0
 def layout(v, kind):
     if kind == 1: return _native.head_major(v)

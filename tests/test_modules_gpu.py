@@ -237,11 +237,11 @@ def test_graphed_helper_reproduces_the_eager_layer_with_parameter_gradients_and_
         devis_amd.graphed(mod, tuple(x.cpu() if isinstance(x, torch.Tensor) else x for x in inputs(1, 60)))
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2), (torch.float16, 4e-3)], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 8e-3), (torch.float16, 2e-3)], ids=["f32", "bf16", "f16"])
 def test_value_proj_gradients_at_clip_size_through_the_split_k_product(dtype, tol):
     """`project_value` at the size of one DeVIS clip (T x S = 28 920 rows, 256 -> 256): its backward computes the weight gradient as
     a batched product over row slices (`_split_k_wgrad`, round 4); all three gradients against the fp64 products of the same rounded
-    inputs, the slices' partial sums being added in the storage type."""
+    inputs; the slices' partial sums are added in float32 and rounded once (round 5: one storage-type rounding, not ~28)."""
     from devis_amd.functions import project_value
     gen = torch.Generator().manual_seed(17)
     T, S, C, M = 6, 4820, 256, 8
