@@ -50,6 +50,7 @@ struct Knobs {
     int fwd_rs = -1, fwd_rs_nt = 0;     // resident-slab forward: -1 auto, 0 off, 1 force; tiles per wave (0 = auto)
     int bwd_rs = -1, bwd_rs_tpw = 0;    // resident-slab gather pass: -1 auto, 0 off, 1 force; tiles per wave (0 = auto)
     int fwd_tile_waves = -1;            // forward tile kernel: waves per tile (-1 auto)
+    int fwd_rs_body = -1;               // resident-slab forward: slot body compiled for a slab from level 1 / 2 (-1: the rule in launch_fast)
     int bwd_rs_fsplit = -1;             // gather pass with one source frame per workgroup: parts per (clip, head, frame); -1 auto, 0 off
     int fwd_win = -1, bwd_win = -1;     // resident-window kernels (encoder-shaped calls): -1 auto, 0 off, 1 force
     int win_min_halo = 5;               // narrowest halo a window plan may have; one staging phase is preferred from here on (5 holds
@@ -81,6 +82,7 @@ void load_knobs()
         k.bwd_rs = env_int("MSDA_BWD_RS", k.bwd_rs); k.bwd_rs_tpw = env_int("MSDA_BWD_RS_TPW", k.bwd_rs_tpw);
         k.bwd_rs_fsplit = env_int("MSDA_BWD_RS_FSPLIT", k.bwd_rs_fsplit);
         k.fwd_tile_waves = env_int("MSDA_FWD_TILE_WAVES", k.fwd_tile_waves);
+        k.fwd_rs_body = env_int("MSDA_FWD_RS_BODY", k.fwd_rs_body);
         k.fwd_win = env_int("MSDA_FWD_WIN", k.fwd_win); k.bwd_win = env_int("MSDA_BWD_WIN", k.bwd_win);
         k.win_min_halo = env_int("MSDA_WIN_MIN_HALO", k.win_min_halo);
         const char *mode = getenv("MSDA_BWD_MODE");
@@ -515,7 +517,8 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
                 // fp32, one tile per wave, slab from level 2 on: the software-pipelined slot body of that instantiation spills 31 VGPRs
                 // and its plain loop (the kernel compiled for a level-1 slab falls back to it) is 16-27 % faster on the SwinL pyramid
                 // (decoder call, 4 / 16 / 32 clips: 0.175 -> 0.137, 0.644 -> 0.540, 1.178 -> 0.973 ms; 800x1333: the same)
-                const int body_l0 = (esz == 4 && nt == 1 && l0_host >= 2) ? 1 : l0_host;
+                int body_l0 = (esz == 4 && nt == 1 && l0_host >= 2) ? 1 : l0_host;
+                if (knobs().fwd_rs_body == 1 || knobs().fwd_rs_body == 2) body_l0 = knobs().fwd_rs_body;     // (A/B measurements)
                 return launch_fwd_rs(dtype, nt, body_l0, p, parts, (unsigned)(clips * p.M * parts), stream);
             }
         }
