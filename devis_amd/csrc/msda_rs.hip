@@ -30,6 +30,12 @@ namespace {
                              // Same speed on every shape (round 4, same box: 0.375 / 0.376 ms fp32, 0.282 / 0.282 bf16), but the
                              // production 16-bit kernel (4 tiles per wave) no longer spills VGPRs (6 -> 0; profiles/r04_resource_usage.txt)
 #endif
+#ifndef MSDA_RS_PREFETCH
+#define MSDA_RS_PREFETCH 0   // forward, one tile per wave: the first slot's points of a frame loaded into registers early -- 1: behind the
+                             // slab's LDS-DMA (round 4: slower, loads return in order and the slab wait inherits their HBM latency),
+                             // 2: BEFORE the barrier that frees the previous slab, so that they fly while the wave waits for the slowest
+                             // wave of the frame before and land ahead of the DMA pieces (round 5)
+#endif
 #ifndef MSDA_RS_PIPE
 #define MSDA_RS_PIPE 1       // software-pipelined level-0 corners (0: the plain group loop only; A/B builds)
 #endif
@@ -68,7 +74,7 @@ __device__ __forceinline__ void rs_wave_priority(int wave)
 // levels >= l0 of source frame f (head m) -> LDS slab, 16 bytes per lane by LDS-DMA (8 lanes per pixel)
 template <typename T>
 __device__ __forceinline__ void rs_stage_slab(const Params &p, T *slab, int clip, int m, int f, int px0, int npx,
-                                              int wave, int lane)
+                                              int wave, int lane, bool wait = true)
 {
     constexpr int GL = rs_row_bytes<T>() / 16, D = 32;
     constexpr int PXW = kWave / GL;                 // pixels per LDS-DMA wave instruction
@@ -82,7 +88,7 @@ __device__ __forceinline__ void rs_stage_slab(const Params &p, T *slab, int clip
         (void)gp;
 #endif
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // The shared front of the resident-slab kernels: LDS carve, level tables, slot masks, tile geometry.
@@ -203,6 +209,7 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
 {
     constexpr int RPW = kRsRows, D = 32, ROWB = rs_row_bytes<T>(), ROWSH = ROWB == 128 ? 7 : 6;
     constexpr bool kHalf = sizeof(T) == 2;
+    constexpr bool kPrefetch = MSDA_RS_PREFETCH != 0 && NT == 1;      // (more accumulator sets: the carried points spill)
     extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];       // (no static LDS: the slab starts at 0)
     const int tid = threadIdx.x, lane = tid % kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -255,14 +262,71 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
     MSDA_RTR(9);                    // prologue done
 
     for (int f = 0; f < p.frames; ++f) {
+#if MSDA_RS_PREFETCH != 2
         __syncthreads();                                   // every wave is done with the previous slab
         MSDA_RTR(1);                // barrier: previous slab free
+#endif
+#if MSDA_RS_PREFETCH
+        // The points of this wave's FIRST (tile, slot) of the frame are requested behind the slab's LDS-DMA and land while it does
+        // (the timeline of round 4: 2.6 k of a frame's 24.8 k clocks were these loads, exposed in every wave at once after the
+        // barrier).  Everything that reads LDS -- the slot mask -- comes before the DMA is issued: hipcc puts an s_waitcnt vmcnt(0)
+        // in front of any LDS access it sees while an LDS-DMA is in flight.
+        RawPoints<TL> pre;
+        int pre_sl = -2;                                   // the slot the prefetched points belong to (-2: none)
+        int64_t pre_idx0 = 0;
+        if (kPrefetch && my_tiles > 0 && p.wide_loads) {
+            int t0, q00;
+            tile_of(0, t0, q00);
+            const unsigned todo0 = __builtin_amdgcn_readfirstlane(sh.mask[t0 * p.frames + f]);
+            if (todo0) {
+                const int sl0 = (int)__builtin_ctz(todo0) - 1, P0 = sl0 < 0 ? p.PA : p.PB;
+                if (P0 == 4 && (sl0 < 0 ? p.LA : L) * P0 == 16) {
+                    const int64_t row0 = (((int64_t)clip * p.frames + t0) * p.Lq + q00 + j) * p.M + m;
+                    pre_idx0 = row0 * ((sl0 < 0 ? p.LA : p.LB) * P0) + (sl0 < 0 ? 0 : sl0 * L * P0);
+                    pre_sl = sl0;
+                }
+            }
+        }
+#endif
+#if MSDA_RS_PREFETCH == 2
+        if (pre_sl != -2) {
+            int t0, q00;
+            tile_of(0, t0, q00);
+            pre = issue_slot_points<TL>(static_cast<const TL *>(pre_sl < 0 ? p.locA : p.locB), static_cast<const TL *>(pre_sl < 0 ? p.awA : p.awB),
+                                        pre_idx0, cor, j < min(RPW, p.Lq - q00));
+        }
+        __syncthreads();                                   // every wave is done with the previous slab (the points fly meanwhile)
+        MSDA_RTR(1);                // barrier: previous slab free
+#endif
 #if !defined(MSDA_RS_EXP) || MSDA_RS_EXP != 3
-        if (l0 < L) rs_stage_slab<T>(p, slab, clip, m, f, sh.px0, sh.npx, wave, lane);
+        if (l0 < L) rs_stage_slab<T>(p, slab, clip, m, f, sh.px0, sh.npx, wave, lane, !kPrefetch);
+#endif
+#if MSDA_RS_PREFETCH == 1
+        if (pre_sl != -2) {
+            int t0, q00;
+            tile_of(0, t0, q00);
+            pre = issue_slot_points<TL>(static_cast<const TL *>(pre_sl < 0 ? p.locA : p.locB), static_cast<const TL *>(pre_sl < 0 ? p.awA : p.awB),
+                                        pre_idx0, cor, j < min(RPW, p.Lq - q00));
+        }
+#endif
+#if MSDA_RS_PREFETCH
+        if (kPrefetch) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         MSDA_RTR(2);                // slab pieces issued and landed
         __syncthreads();
         MSDA_RTR(3);                // barrier: slab complete
+#if MSDA_RS_PREFETCH
+        // (xs / ys / as are carried into the tile loop: the first (tile, slot) it runs is the one the points were requested for --
+        // tile 0 has work in this frame, or nothing was requested -- and every later slot loads its own at its head)
+        float xs[4], ys[4], as[4];
+        bool have_points = false;
+        if (pre_sl != -2) {
+            int t0, q00;
+            tile_of(0, t0, q00);
+            finish_slot_points<TL>(pre, cor, j < min(RPW, p.Lq - q00), xs, ys, as);
+            have_points = true;
+        }
+#endif
         const int fS = f * p.S;
 #pragma unroll 1
         for (int k = 0; k < my_tiles; ++k) {
@@ -283,10 +347,10 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
             // one corner: the lane's 8 channels of the row at byte address A, times W
             auto corner = [&](auto Sc, int A, float W) {      // (A by value: the experiments below may change it)
                 constexpr bool SLAB = decltype(Sc)::value;
-#if defined(MSDA_RS_EXP)          // timing experiments (wrong results): 2 = no LDS reads, 1 = no memory corners,
+#if defined(MSDA_RS_EXP)          // timing experiments (wrong results): 2 = no LDS reads, 1 = no memory corners, 6 = neither,
                                   // 4 = memory corners read one 16-byte slice instead of two, 5 = ... from one 32 KiB window
-                if constexpr (SLAB && MSDA_RS_EXP == 2) { wacc[0] += W * (float)A; return; }
-                if constexpr (!SLAB && MSDA_RS_EXP == 1) { wacc[0] += W * (float)A; return; }
+                if constexpr (SLAB && (MSDA_RS_EXP == 2 || MSDA_RS_EXP == 6)) { wacc[0] += W * (float)A; return; }     // (6 = 1 + 2: the skeleton)
+                if constexpr (!SLAB && (MSDA_RS_EXP == 1 || MSDA_RS_EXP == 6)) { wacc[0] += W * (float)A; return; }
 #if defined(__HIP_DEVICE_COMPILE__)
                 if constexpr (!SLAB && MSDA_RS_EXP == 4) {
                     const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, A, 0, 0);
@@ -324,8 +388,13 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                 const unsigned invP = (65536u + (unsigned)P - 1u) / (unsigned)P;      // kk / P for kk * P < 2^16
                 const int first_slab_pt = l0 * P;              // points of levels >= l0 read the slab
                 const bool wide = p.wide_loads && P == 4 && npts == 16;           // (uniform) see load_slot_points
+#if MSDA_RS_PREFETCH
+                if (wide && !have_points) load_slot_points<TL>(loc, aw, idx0, cor, live, xs, ys, as);
+                have_points = false;
+#else
                 float xs[4], ys[4], as[4];
                 if (wide) load_slot_points<TL>(loc, aw, idx0, cor, live, xs, ys, as);
+#endif
                 MSDA_RTR(4);        // slot: points loaded (first use waits)
 #if MSDA_RS_PIPE
                 if (wide && l0 == PL0) {
@@ -347,7 +416,10 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                             }
                             int a0 = quad_bcast<R>(rm[G].a[S0]) + off1, a1 = quad_bcast<R>(rm[G].a[S0 + 1]) + off1;
                             asm volatile("" : "+v"(a0), "+v"(a1) : "v"(wacc[7]));
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(MSDA_RS_EXP) && (MSDA_RS_EXP == 1 || MSDA_RS_EXP == 6)      // timing only: the memory pair is not read (its FMAs stay)
+                            mv[0].q[0] = u32x4{(unsigned)a0, 1u, 2u, 3u}; mv[1].q[0] = u32x4{(unsigned)a1, 1u, 2u, 3u};
+                            if constexpr (sizeof(T) == 4) { mv[0].q[1] = mv[0].q[0]; mv[1].q[1] = mv[1].q[0]; }
+#elif defined(__HIP_DEVICE_COMPILE__)
                             mv[0] = rs_issue_row<T, false>(rsrc, a0, delta2);
                             mv[1] = rs_issue_row<T, false>(rsrc, a1, delta2);
 #endif
@@ -370,7 +442,13 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                                 {   // both corners of the pair requested before either is consumed
                                     const int A0 = quad_bcast<R>(rl.a[S0]) + off1, A1 = quad_bcast<R>(rl.a[S0 + 1]) + off1;
                                     const float W0 = quad_bcast<R>(rl.w[S0]), W1 = quad_bcast<R>(rl.w[S0 + 1]);
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(MSDA_RS_EXP) && (MSDA_RS_EXP == 2 || MSDA_RS_EXP == 6)      // timing only: the LDS pair is not read (its FMAs stay)
+                                    RsRaw<T> r0, r1;
+                                    r0.q[0] = u32x4{(unsigned)A0, 1u, 2u, 3u}; r1.q[0] = u32x4{(unsigned)A1, 1u, 2u, 3u};
+                                    if constexpr (sizeof(T) == 4) { r0.q[1] = r0.q[0]; r1.q[1] = r1.q[0]; }
+                                    rs_fma_row<T>(r0, W0, wacc);
+                                    rs_fma_row<T>(r1, W1, wacc);
+#elif defined(__HIP_DEVICE_COMPILE__)
                                     const RsRaw<T> r0 = rs_issue_row<T, true>(rsrc, A0, delta2);
                                     const RsRaw<T> r1 = rs_issue_row<T, true>(rsrc, A1, delta2);
                                     rs_fma_row<T>(r0, W0, wacc);

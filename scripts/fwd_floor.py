@@ -1,0 +1,20 @@
+"""GPU probe (round 5): the headline forward and gather pass of whatever build MSDA_LIB names -- for the timing-only builds
+-DMSDA_RS_EXP=1 (no memory corners), 2 (no LDS corners), 6 (neither: the skeleton = staging, barriers, point loads, geometry,
+broadcasts, stores), 3 (no slab staging).  Results of those builds are wrong by construction."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from devis_amd import _native, tuning
+
+if __name__ == "__main__":
+    dev = torch.device("cuda:0")
+    out = []
+    for dt in (torch.float32, torch.bfloat16):
+        fwd, bwd, d, so = tuning._case(tuning.PYRAMIDS["A"], dt, dt, 16, 300, "decoder", 6, 8, 32, 4, dev)
+        out.append("%s fwd %.4f ms [%s]" % (str(dt).split(".")[1], tuning._time(fwd, 21), _native.last_route()[14:58]))
+        del fwd, bwd, so
+        torch.cuda.empty_cache()
+    print("%-40s %s" % (os.path.basename(os.environ.get("MSDA_LIB", "libmsda_hip.so")), "   ".join(out)), flush=True)
