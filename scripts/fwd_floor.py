@@ -14,7 +14,13 @@ if __name__ == "__main__":
     out = []
     for dt in (torch.float32, torch.bfloat16):
         fwd, bwd, d, so = tuning._case(tuning.PYRAMIDS["A"], dt, dt, 16, 300, "decoder", 6, 8, 32, 4, dev)
-        out.append("%s fwd %.4f ms [%s]" % (str(dt).split(".")[1], tuning._time(fwd, 21), _native.last_route()[14:58]))
+        t_f = tuning._time(fwd, 21)
+        r_f = _native.last_route()[14:58]
+        os.environ["MSDA_ENABLE_HOOKS"] = "1"; os.environ["MSDA_BWD_PHASES"] = "1"
+        _native.reload_knobs()
+        t_g = tuning._time(bwd, 21)
+        os.environ.pop("MSDA_BWD_PHASES"); _native.reload_knobs()
+        out.append("%s fwd %.4f gather %.4f ms [%s]" % (str(dt).split(".")[1], t_f, t_g, r_f))
         del fwd, bwd, so
         torch.cuda.empty_cache()
     print("%-40s %s" % (os.path.basename(os.environ.get("MSDA_LIB", "libmsda_hip.so")), "   ".join(out)), flush=True)
