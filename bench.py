@@ -315,10 +315,12 @@ def other_configs(args, device):
             mod.fused = False
             entry["eager_reference_call_pattern_ms"] = round(_event_ms(mstep, 10, 3), 4)
             mod.fused = True
-            graphed = torch.cuda.make_graphed_callables(call, (qry, refp, srcm))
+            import devis_amd
+            layer = devis_amd.graphed(mod, (qry, refp, srcm, (shp, tsh), (lsi_, tlsi), offs))      # forward + backward from a HIP graph
+            graphed = lambda a, b, c: layer(a, b, c, (shp, tsh), (lsi_, tlsi), offs)[0]
             entry["graphed_ms"] = round(_event_ms(lambda: mstep(graphed), 20, 5), 4)
             res["decoder_layer_module"] = entry
-            del graphed, mod
+            del graphed, layer, mod
         except Exception as exc:
             res["decoder_layer_module"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         torch.cuda.empty_cache()

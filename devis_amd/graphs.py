@@ -98,7 +98,10 @@ class GraphedLayer:
                 self.module(*args)
             samples = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in flowing)
             bound = _Bound(self.module, template)
-            fn = torch.cuda.make_graphed_callables(bound, samples, num_warmup_iters=self.num_warmup_iters)
+            # (the capture runs the backward too: grad mode on, even when the first call comes from inside torch.no_grad() --
+            # inference, tracker.py:320-323 -- where the graphed callable then replays its forward graph only)
+            with torch.enable_grad():
+                fn = torch.cuda.make_graphed_callables(bound, samples, num_warmup_iters=self.num_warmup_iters)
             self._cache[sig] = fn
             self._keep[sig] = [a for a in args if not _is_flowing(a)]
             return fn

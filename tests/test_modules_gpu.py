@@ -233,6 +233,13 @@ def test_graphed_helper_reproduces_the_eager_layer_with_parameter_gradients_and_
         for x, y in zip(gg, ge):
             assert torch.allclose(x, y, rtol=1e-4, atol=2e-5 * max(1e-6, float(y.abs().max())))
     assert layer.graphs == 2                        # 60 and 180 queries per frame; the third call replayed the first graph
+    # inference: first use from inside torch.no_grad() (tracker.py:320-323) -- its own signature (nothing requires grad)
+    with torch.no_grad():
+        a = inputs(5, 60)
+        a = tuple(x.detach() if isinstance(x, torch.Tensor) else x for x in a)
+        res_g, res_e = layer(*a), mod(*a)
+        assert torch.allclose(res_g[0], res_e[0], rtol=1e-5, atol=1e-6) and not res_g[0].requires_grad
+    assert layer.graphs == 3
     with pytest.raises(RuntimeError, match="no CPU path"):
         devis_amd.graphed(mod, tuple(x.cpu() if isinstance(x, torch.Tensor) else x for x in inputs(1, 60)))
 
