@@ -168,6 +168,10 @@ def build(force=False, verbose=False, defines=(), out=None, jobs=None):
         os.replace(tmp, target)
         if official:
             _write_atomic(HASH, _source_hash() + "\n")
+        if defines:
+            # the objects of an experimental build are never reused (every unit is recompiled): removed once linked -- round 4
+            # left 128 MB of them in the tree, and the tree is what travels to the GPU box
+            shutil.rmtree(objdir, ignore_errors=True)
     return target
 
 
