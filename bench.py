@@ -315,12 +315,19 @@ def other_configs(args, device):
             mod.fused = False
             entry["eager_reference_call_pattern_ms"] = round(_event_ms(mstep, 10, 3), 4)
             mod.fused = True
-            import devis_amd
-            layer = devis_amd.graphed(mod, (qry, refp, srcm, (shp, tsh), (lsi_, tlsi), offs))      # forward + backward from a HIP graph
-            graphed = lambda a, b, c: layer(a, b, c, (shp, tsh), (lsi_, tlsi), offs)[0]
+            graphed = torch.cuda.make_graphed_callables(call, (qry, refp, srcm))       # gradients of the two inputs, as the eager lines
             entry["graphed_ms"] = round(_event_ms(lambda: mstep(graphed), 20, 5), 4)
+            # ... and through devis_amd.graphed (round 5): the module's own signature, PARAMETER gradients included (a training step)
+            import devis_amd
+            layer = devis_amd.graphed(mod, (qry, refp, srcm, (shp, tsh), (lsi_, tlsi), offs))
+            helper = lambda a, b, c: layer(a, b, c, (shp, tsh), (lsi_, tlsi), offs)[0]
+            entry["graphed_with_parameter_gradients_ms"] = round(_event_ms(lambda: mstep(helper), 20, 5), 4)
+
+            def mstep_params():
+                torch.autograd.grad((call(qry, refp, srcm) * wgt).sum(), [qry, srcm] + list(mod.parameters()))
+            entry["eager_with_parameter_gradients_ms"] = round(_event_ms(mstep_params, 20, 5), 4)
             res["decoder_layer_module"] = entry
-            del graphed, layer, mod
+            del graphed, layer, helper, mod
         except Exception as exc:
             res["decoder_layer_module"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         torch.cuda.empty_cache()

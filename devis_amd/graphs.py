@@ -41,17 +41,32 @@ class _Bound(nn.Module):
     """The wrapped module with its non-flowing arguments fixed: what is captured (an nn.Module, so that its parameters are
     graph inputs and receive gradients)."""
 
-    def __init__(self, inner, template):
+    def __init__(self, inner, template, aux_grad):
         super().__init__()
         self.inner = inner
         self._template = template           # positional arguments; None at the places of the flowing tensors
         self._slots = [i for i, a in enumerate(template) if a is _FLOW]
+        self._aux_grad = aux_grad
 
     def forward(self, *flowing):
         args = list(self._template)
         for i, t in zip(self._slots, flowing):
             args[i] = t
-        return self.inner(*args)
+        out = self.inner(*args)
+        if self._aux_grad or not isinstance(out, tuple):
+            return out
+        # Only the FIRST output carries gradients through the graph: the temporal decoder's other four (sampling locations and
+        # attention weights, returned for visualize_att_maps.py:158-169) are handed out detached -- as graph outputs that
+        # require grad each of them would cost a zero-filled cotangent and a copy per backward replay.
+        return (out[0],) + tuple(_detach(o) for o in out[1:])
+
+
+def _detach(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach()
+    if isinstance(x, (list, tuple)):
+        return type(x)(_detach(e) for e in x)
+    return x
 
 
 _FLOW = object()
@@ -61,9 +76,10 @@ class GraphedLayer:
     """Callable with the wrapped module's positional signature; see the module docstring.  ``graphs`` = number of captured
     signatures (tests, diagnostics)."""
 
-    def __init__(self, module, num_warmup_iters=3):
+    def __init__(self, module, num_warmup_iters=3, aux_grad=False):
         self.module = module
         self.num_warmup_iters = num_warmup_iters
+        self.aux_grad = aux_grad
         self._cache = {}
         self._keep = {}                     # signature -> the bound arguments (kept alive: their identity is the key)
         self._lock = threading.Lock()
@@ -97,7 +113,7 @@ class GraphedLayer:
             with torch.no_grad():
                 self.module(*args)
             samples = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in flowing)
-            bound = _Bound(self.module, template)
+            bound = _Bound(self.module, template, self.aux_grad)
             # (the capture runs the backward too: grad mode on, even when the first call comes from inside torch.no_grad() --
             # inference, tracker.py:320-323 -- where the graphed callable then replays its forward graph only)
             with torch.enable_grad():
@@ -111,11 +127,12 @@ class GraphedLayer:
         return fn(*(a for a in args if _is_flowing(a)))
 
 
-def graphed(module, example_inputs=None, num_warmup_iters=3):
+def graphed(module, example_inputs=None, num_warmup_iters=3, aux_grad=False):
     """Static-shape HIP-graph wrapper around one attention layer (``MSDeformAttn``, ``TemporalMSDeformAttnEncoder`` /
     ``Decoder``, or any module built on this package's operator): returns a :class:`GraphedLayer`.  ``example_inputs`` (the
-    positional arguments of one call) are captured right away; other shapes are captured on first use."""
-    layer = GraphedLayer(module, num_warmup_iters)
+    positional arguments of one call) are captured right away; other shapes are captured on first use.  Of a tuple of outputs
+    only the first is differentiable through the graph unless ``aux_grad=True`` (the others are returned detached)."""
+    layer = GraphedLayer(module, num_warmup_iters, aux_grad)
     if example_inputs is not None:
         layer.capture(*example_inputs)
     return layer

@@ -224,6 +224,7 @@ def test_graphed_helper_reproduces_the_eager_layer_with_parameter_gradients_and_
         res_g = layer(*a)
         res_e = mod(*b)
         assert len(res_g) == 5 and len(res_g[1]) == T and res_g[3].shape == res_e[3].shape
+        assert res_g[0].requires_grad and not res_g[3].requires_grad and not res_g[1][0].requires_grad      # aux outputs: detached
         w = torch.randn_like(res_e[0])
         gg = torch.autograd.grad((res_g[0] * w).sum(), [a[0], a[2]] + params)
         ge = torch.autograd.grad((res_e[0] * w).sum(), [b[0], b[2]] + params)
