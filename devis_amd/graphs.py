@@ -124,7 +124,12 @@ class GraphedLayer:
 
     def __call__(self, *args):
         fn = self.capture(*args)
-        return fn(*(a for a in args if _is_flowing(a)))
+        out = fn(*(a for a in args if _is_flowing(a)))
+        if self.aux_grad or not isinstance(out, tuple):
+            return out
+        # (the graphed autograd function marks every output as differentiable; the auxiliary ones carry no gradient inside the
+        # graph -- _Bound.forward -- and say so here)
+        return (out[0],) + tuple(_detach(o) for o in out[1:])
 
 
 def graphed(module, example_inputs=None, num_warmup_iters=3, aux_grad=False):
