@@ -150,12 +150,18 @@ def test_shipped_routes_are_within_five_percent_of_the_best_alternative(case):
         pytest.skip("no shipped route table")
     shapes = [s for s in tuning.audit_shapes(quick=True)]
     picks = shapes[case::8][:2]
-    for pyr, kind, clips, q, dt, l32 in picks:
-        r = tuning.tune(tuning.PYRAMIDS[pyr], dt, clips=clips, Lq=q, kind=kind, reps=11, pin=False, keep_pins=True, sampling_fp32=l32)
+    def behind(r):
+        out = []
         for side, auto_key, times_key in (("forward", "auto_ms", "times"), ("backward", "gather_auto_ms", "gather_times"),
                                           ("backward", "scatter_auto_ms", "scatter_times")):
             auto, times = r[side][auto_key], r[side][times_key]
-            if not times:
-                continue
-            best = min(times.values())
-            assert auto <= 1.05 * best + 0.003, (pyr, kind, clips, q, dt, side, auto_key, auto, times)
+            if times and auto > 1.05 * min(times.values()) + 0.003:
+                out.append((auto_key, auto, times))
+        return out
+
+    for pyr, kind, clips, q, dt, l32 in picks:
+        args = dict(clips=clips, Lq=q, kind=kind, pin=False, keep_pins=True, sampling_fp32=l32)
+        bad = behind(tuning.tune(tuning.PYRAMIDS[pyr], dt, reps=11, **args))
+        if bad:         # a clock ramp or a neighbour on the box can cost one measurement 5 %: what must hold is the second look
+            bad = [b for b in behind(tuning.tune(tuning.PYRAMIDS[pyr], dt, reps=25, **args)) if b[0] in {x[0] for x in bad}]
+        assert not bad, (pyr, kind, clips, q, dt, bad)
