@@ -76,6 +76,9 @@ class GraphedLayer:
     """Callable with the wrapped module's positional signature; see the module docstring.  ``graphs`` = number of captured
     signatures (tests, diagnostics)."""
 
+    max_graphs = 16         # captured signatures kept (least recently captured out): a graph owns its static buffers, and a caller
+                            # that hands over a NEW spatial_shapes tensor every step (see the module docstring) would pile them up
+
     def __init__(self, module, num_warmup_iters=3, aux_grad=False):
         self.module = module
         self.num_warmup_iters = num_warmup_iters
@@ -120,6 +123,9 @@ class GraphedLayer:
                 fn = torch.cuda.make_graphed_callables(bound, samples, num_warmup_iters=self.num_warmup_iters)
             self._cache[sig] = fn
             self._keep[sig] = [a for a in args if not _is_flowing(a)]
+            while len(self._cache) > self.max_graphs:
+                oldest = next(iter(self._cache))
+                del self._cache[oldest], self._keep[oldest]
             return fn
 
     def __call__(self, *args):
