@@ -12,15 +12,19 @@ from devis_amd import _native, tuning
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
     out = []
-    for dt in (torch.float32, torch.bfloat16):
-        fwd, bwd, d, so = tuning._case(tuning.PYRAMIDS["A"], dt, dt, 16, 300, "decoder", 6, 8, 32, 4, dev)
+    cases = [(torch.float32, "A", "decoder", 16), (torch.bfloat16, "A", "decoder", 16)]
+    if os.environ.get("F16_CASES"):     # the f16 kernels (v_fma_mix_f32 rows, round 5): decoder batch, temporal and single-frame encoder calls
+        cases = [(torch.float16, "A", "decoder", 16), (torch.float16, "S", "encoder", 1), (torch.float16, "B", "plain_encoder", 8),
+                 (torch.float16, "S", "plain_decoder", 6)]
+    for dt, pyr, kind, clips in cases:
+        fwd, bwd, d, so = tuning._case(tuning.PYRAMIDS[pyr], dt, dt, clips, 300, kind, 6, 8, 32, 4, dev)
         t_f = tuning._time(fwd, 21)
         r_f = _native.last_route()[14:58]
         os.environ["MSDA_ENABLE_HOOKS"] = "1"; os.environ["MSDA_BWD_PHASES"] = "1"
         _native.reload_knobs()
         t_g = tuning._time(bwd, 21)
         os.environ.pop("MSDA_BWD_PHASES"); _native.reload_knobs()
-        out.append("%s fwd %.4f gather %.4f ms [%s]" % (str(dt).split(".")[1], t_f, t_g, r_f))
+        out.append("%s %s %s fwd %.4f gather %.4f ms [%s]" % (str(dt).split(".")[1], pyr, kind, t_f, t_g, r_f[:28]))
         del fwd, bwd, so
         torch.cuda.empty_cache()
     print("%-40s %s" % (os.path.basename(os.environ.get("MSDA_LIB", "libmsda_hip.so")), "   ".join(out)), flush=True)
