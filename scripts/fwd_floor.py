@@ -16,6 +16,8 @@ if __name__ == "__main__":
     if os.environ.get("F16_CASES"):     # the f16 kernels (v_fma_mix_f32 rows, round 5): decoder batch, temporal and single-frame encoder calls
         cases = [(torch.float16, "A", "decoder", 16), (torch.float16, "S", "encoder", 1), (torch.float16, "B", "plain_encoder", 8),
                  (torch.float16, "S", "plain_decoder", 6)]
+    if os.environ.get("ENC_CASES"):     # encoder-shaped calls (resident-window kernels on the 800x1333 pyramid)
+        cases = [(torch.float32, "B", "encoder", 1), (torch.bfloat16, "B", "encoder", 1), (torch.float32, "A", "encoder", 1)]
     for dt, pyr, kind, clips in cases:
         fwd, bwd, d, so = tuning._case(tuning.PYRAMIDS[pyr], dt, dt, clips, 300, kind, 6, 8, 32, 4, dev)
         t_f = tuning._time(fwd, 21)
