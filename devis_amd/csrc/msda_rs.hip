@@ -347,10 +347,8 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
             // one corner: the lane's 8 channels of the row at byte address A, times W
             auto corner = [&](auto Sc, int A, float W) {      // (A by value: the experiments below may change it)
                 constexpr bool SLAB = decltype(Sc)::value;
-#if defined(MSDA_RS_EXP)          // timing experiments (wrong results): 2 = no LDS reads, 1 = no memory corners, 6 = neither,
+#if defined(MSDA_RS_EXP)          // timing experiments (wrong results; 1 / 2 / 6 live in rs_issue_row: no memory / LDS / any corner reads),
                                   // 4 = memory corners read one 16-byte slice instead of two, 5 = ... from one 32 KiB window
-                if constexpr (SLAB && (MSDA_RS_EXP == 2 || MSDA_RS_EXP == 6)) { wacc[0] += W * (float)A; return; }     // (6 = 1 + 2: the skeleton)
-                if constexpr (!SLAB && (MSDA_RS_EXP == 1 || MSDA_RS_EXP == 6)) { wacc[0] += W * (float)A; return; }
 #if defined(__HIP_DEVICE_COMPILE__)
                 if constexpr (!SLAB && MSDA_RS_EXP == 4) {
                     const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, A, 0, 0);
@@ -416,10 +414,7 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                             }
                             int a0 = quad_bcast<R>(rm[G].a[S0]) + off1, a1 = quad_bcast<R>(rm[G].a[S0 + 1]) + off1;
                             asm volatile("" : "+v"(a0), "+v"(a1) : "v"(wacc[7]));
-#if defined(MSDA_RS_EXP) && (MSDA_RS_EXP == 1 || MSDA_RS_EXP == 6)      // timing only: the memory pair is not read (its FMAs stay)
-                            mv[0].q[0] = u32x4{(unsigned)a0, 1u, 2u, 3u}; mv[1].q[0] = u32x4{(unsigned)a1, 1u, 2u, 3u};
-                            if constexpr (sizeof(T) == 4) { mv[0].q[1] = mv[0].q[0]; mv[1].q[1] = mv[1].q[0]; }
-#elif defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
                             mv[0] = rs_issue_row<T, false>(rsrc, a0, delta2);
                             mv[1] = rs_issue_row<T, false>(rsrc, a1, delta2);
 #endif
@@ -442,13 +437,7 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
                                 {   // both corners of the pair requested before either is consumed
                                     const int A0 = quad_bcast<R>(rl.a[S0]) + off1, A1 = quad_bcast<R>(rl.a[S0 + 1]) + off1;
                                     const float W0 = quad_bcast<R>(rl.w[S0]), W1 = quad_bcast<R>(rl.w[S0 + 1]);
-#if defined(MSDA_RS_EXP) && (MSDA_RS_EXP == 2 || MSDA_RS_EXP == 6)      // timing only: the LDS pair is not read (its FMAs stay)
-                                    RsRaw<T> r0, r1;
-                                    r0.q[0] = u32x4{(unsigned)A0, 1u, 2u, 3u}; r1.q[0] = u32x4{(unsigned)A1, 1u, 2u, 3u};
-                                    if constexpr (sizeof(T) == 4) { r0.q[1] = r0.q[0]; r1.q[1] = r1.q[0]; }
-                                    rs_fma_row<T>(r0, W0, wacc);
-                                    rs_fma_row<T>(r1, W1, wacc);
-#elif defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
                                     const RsRaw<T> r0 = rs_issue_row<T, true>(rsrc, A0, delta2);
                                     const RsRaw<T> r1 = rs_issue_row<T, true>(rsrc, A1, delta2);
                                     rs_fma_row<T>(r0, W0, wacc);
