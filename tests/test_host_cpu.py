@@ -196,6 +196,28 @@ def test_route_table_keys_pins_and_files(tmp_path):
         assert _native.route_count() >= min(1, len(doc["routes"]))
 
 
+def test_graphed_layer_signatures_and_cpu_refusal():
+    """devis_amd.graphed keys its captured graphs by the shapes / dtypes / requires_grad of the floating-point arguments and by the
+    IDENTITY (object + version) of everything else -- the integer tensors whose host copy chooses the kernels; CPU tensors are
+    refused (there is no CPU path to capture)."""
+    import devis_amd
+    from devis_amd.graphs import GraphedLayer
+    layer = GraphedLayer(torch.nn.Identity())
+    shapes, offs = torch.tensor([[4, 5], [2, 3]]), [torch.tensor([1]), torch.tensor([-1])]
+    q = torch.zeros(1, 12, 8)
+    sig = layer._signature((q, shapes, (shapes, shapes), offs, None, 64))
+    assert sig == layer._signature((torch.ones(1, 12, 8), shapes, (shapes, shapes), list(offs), None, 64))      # values of flowing tensors: no
+    assert sig != layer._signature((torch.zeros(1, 13, 8), shapes, (shapes, shapes), offs, None, 64))          # shape: yes
+    assert sig != layer._signature((q.double(), shapes, (shapes, shapes), offs, None, 64))                     # dtype: yes
+    assert sig != layer._signature((q.clone().requires_grad_(True), shapes, (shapes, shapes), offs, None, 64))
+    assert sig != layer._signature((q, shapes.clone(), (shapes, shapes), offs, None, 64))                      # another shapes OBJECT: yes
+    assert sig != layer._signature((q, shapes, (shapes, shapes), offs, None, 2))                               # plain values: by value
+    shapes.add_(0)
+    assert sig != layer._signature((q, shapes, (shapes, shapes), offs, None, 64))                              # in-place change: version
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        devis_amd.graphed(torch.nn.Identity(), (q,))
+
+
 def test_frame_tables_of_two_stacks_do_not_evict_each_other_and_are_thread_safe():
     """The encoder and the decoder stack hand different offset lists to their layers in turn (devis_transformer.py:103-121,
     151-169): each list keeps its own entry (round 4 had ONE class-level slot that the two stacks thrashed), and concurrent
