@@ -248,10 +248,13 @@ def tune(spatial_shapes, dtype=torch.float32, clips=1, Lq=300, kind="decoder", f
             _native.pin_route(keys[True], report["backward"]["pinned"])
     if verbose:
         f, b = report["forward"], report["backward"]
+        gather_pinned = bool(b["pinned"]) and any(k.startswith("bwd_") for k in b["pinned"])
+        scatter_pinned = bool(b["pinned"]) and "scatter_order" in b["pinned"]
         print("%-14s %-5s%s clips %-3d Lq %-6d %s | fwd %.4f %s -> %s | gather %.4f %s -> %s | scatter %.4f %s -> %s" % (
-            kind, str(dtype).split(".")[1], "+loc32" if loc_dtype != dtype else "", clips, d["Lq"], "x".join(str(v) for v in shapes[0]), f["auto_ms"], f["times"], f["best"] if f["pinned"] else "-",
-            b["gather_auto_ms"], b["gather_times"], b["gather_best"] if b["pinned"] and b["gather_best"] and set(dict(GATHER_ROUTES)[b["gather_best"]]) <= set(b["pinned"]) else "-",
-            b["scatter_auto_ms"], b["scatter_times"], b["scatter_best"] if b["pinned"] and "scatter_order" in b["pinned"] else "-"), flush=True)
+            kind, str(dtype).split(".")[1], "+loc32" if loc_dtype != dtype else "", clips, d["Lq"], "x".join(str(v) for v in shapes[0]),
+            f["auto_ms"], f["times"], f["best"] if f["pinned"] else "-",
+            b["gather_auto_ms"], b["gather_times"], b["gather_best"] if gather_pinned else "-",
+            b["scatter_auto_ms"], b["scatter_times"], b["scatter_best"] if scatter_pinned else "-"), flush=True)
     return report
 
 
