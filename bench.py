@@ -765,6 +765,26 @@ def main():
                "sample": "%d frame passes (each: current + temporal call, fwd+bwd, %d queries, pyramid %s, fp32) of "
                          "oracle.grid_sample_forward in the reference's call pattern, %.1f s, %d torch threads"
                          % (n, q, args.pyramid, dt, cores)}
+        # The same frame passes with the tensors on THIS GPU: what the reference's pure-PyTorch formulation (F.grid_sample, the
+        # only form of the reference's path that runs without its CUDA extension) does on an MI355X.  A second baseline beside
+        # the host-core one, never `value`; a failure here must not cost the bench line.
+        try:
+            cb = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in cb.items()}
+            c_shapes_t = c_shapes_t.to(device)
+            for t in range(T):
+                cpu_frame(t)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(4 * T):
+                cpu_frame(i % T)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            cpu["same_formulation_on_this_gpu"] = {
+                "value": round(4 * T * q / dt / 1e6, 4), "unit": "M-queries/s",
+                "sample": "%d frame passes of the same torch program (F.grid_sample + autograd, reference call pattern, fp32) on the "
+                          "GPU, %.1f ms per clip" % (4 * T, dt / 4 * 1e3)}
+        except Exception as e:      # noqa: BLE001 -- a baseline, not the product
+            cpu["same_formulation_on_this_gpu"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
 
     # every rank contributes a one: the SCALE record can check that RCCL really saw N ranks
     ranks_seen = 1
