@@ -395,10 +395,19 @@ constexpr int kOwnPix = kOwnQuads * kOwnSlots;      // pixels per band
 constexpr int kRsThreads = MSDA_RS_THREADS, kRsWaves = kRsThreads / kWave;
 constexpr int kRsRows = kWave / 4;       // rows per wave tile: one quad per row
 constexpr int kRsSlack = 1024;          // bytes: the last LDS-DMA piece may overrun the slab's pixels
-constexpr int kRsMaxFrames = 32;        // frames x frames slot masks live in LDS
+#ifndef MSDA_RS_MAXFRAMES
+#define MSDA_RS_MAXFRAMES 32
+#endif
+#ifndef MSDA_RS_LDS_BYTES
+#define MSDA_RS_LDS_BYTES (160 * 1024)  // (experiments: 80 KiB with MSDA_RS_THREADS=512, MSDA_RS_MIN_WAVES=4, MSDA_RS_MAXFRAMES=8 = two workgroups per CU on 16-bit slabs)
+#endif
+#ifndef MSDA_RS_MIN_WAVES
+#define MSDA_RS_MIN_WAVES 1
+#endif
+constexpr int kRsMaxFrames = MSDA_RS_MAXFRAMES;        // frames x frames slot masks live in LDS
 constexpr int kRsRowB = 128;            // bytes of one pixel of one head in a 4-byte type (D = 32); 64 in a 2-byte type
 constexpr int kRsTailBytes = kRsRowB + kRsMaxFrames * kRsMaxFrames * 4 + 4 * kSlabMaxLevels * 4 + 16;   // after the slab
-constexpr int kRsSlabBytes = ((160 * 1024 - 256 - kRsTailBytes) / 128) * 128;
+constexpr int kRsSlabBytes = ((MSDA_RS_LDS_BYTES - 256 - kRsTailBytes) / 128) * 128;
 
 // ---- resident-window kernels (msda_win.hip): encoder-shaped calls, where query i IS pixel i of the pyramid and samples round
 // its own position.  A workgroup owns the queries of one spatial TILE (By x Bx level-0 pixels and the pixels of the other

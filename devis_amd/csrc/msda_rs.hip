@@ -204,7 +204,7 @@ __device__ __forceinline__ RsRec rs_records(float x, float y, float a, int lvl, 
 
 // T = storage type of value / out, TL = of sampling_loc / attn_weight (T, or float with a 16-bit T)
 template <typename T, typename TL, int NT, int PL0>       // PL0: the first slab level the software-pipelined slot body is compiled for (1 or 2)
-__global__ void __launch_bounds__(kRsThreads)
+__global__ void __launch_bounds__(kRsThreads, MSDA_RS_MIN_WAVES)
 msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
 {
     constexpr int RPW = kRsRows, D = 32, ROWB = rs_row_bytes<T>(), ROWSH = ROWB == 128 ? 7 : 6;
@@ -528,7 +528,7 @@ msda_fwd_rs_kernel(const Params p, int slab_bytes, int parts)
 // stores its (grad_x, grad_y, grad_attn) directly: the 4 points of a group are 32 + 16 contiguous bytes per row.
 // Also leaves the per-point culling records (top tap row as int16) the scatter pass reads.
 template <typename T, typename TL, int PL0>      // T: value / grad_out, TL: sampling_loc / attn_weight and their gradients
-__global__ void __launch_bounds__(kRsThreads)
+__global__ void __launch_bounds__(kRsThreads, MSDA_RS_MIN_WAVES)
 msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts, int frame_split)
 {
     constexpr int RPW = kRsRows, D = 32, ROWB = rs_row_bytes<T>(), ROWSH = ROWB == 128 ? 7 : 6;
