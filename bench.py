@@ -317,11 +317,15 @@ def other_configs(args, device):
             mod.fused = True
             graphed = torch.cuda.make_graphed_callables(call, (qry, refp, srcm))       # gradients of the two inputs, as the eager lines
             entry["graphed_ms"] = round(_event_ms(lambda: mstep(graphed), 20, 5), 4)
-            # ... and through devis_amd.graphed (round 5): the module's own signature, PARAMETER gradients included (a training step)
+            # ... and through devis_amd.graphed (round 5): the module's own signature, PARAMETER gradients included (a training step),
+            # on a non-default stream as training steps through the helper must be (devis_amd/graphs.py: on the default stream the
+            # helper runs the module eagerly)
             import devis_amd
             layer = devis_amd.graphed(mod, (qry, refp, srcm, (shp, tsh), (lsi_, tlsi), offs))
             helper = lambda a, b, c: layer(a, b, c, (shp, tsh), (lsi_, tlsi), offs)[0]
-            entry["graphed_with_parameter_gradients_ms"] = round(_event_ms(lambda: mstep(helper), 20, 5), 4)
+            with devis_amd.graph_stream(device):
+                entry["graphed_with_parameter_gradients_ms"] = round(_event_ms(lambda: mstep(helper), 20, 5), 4)
+            assert layer.eager_calls == 0
 
             def mstep_params():
                 torch.autograd.grad((call(qry, refp, srcm) * wgt).sum(), [qry, srcm] + list(mod.parameters()))

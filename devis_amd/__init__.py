@@ -17,8 +17,8 @@ from .functions import (MSDeformAttnFunction, MSDeformAttnTemporalFunction,  # n
 from .modules import (MSDeformAttn, TemporalMSDeformAttnDecoder,  # noqa: F401
                       TemporalMSDeformAttnEncoder)
 from .argument_builders import patch_transformer  # noqa: F401
-from .graphs import graphed, GraphedLayer  # noqa: F401
+from .graphs import graphed, graph_stream, GraphedLayer  # noqa: F401
 from .tuning import tune  # noqa: F401
 
 __all__ = ["MSDeformAttnFunction", "MSDeformAttnTemporalFunction", "ms_deform_attn_core_pytorch",
-           "MSDeformAttn", "TemporalMSDeformAttnEncoder", "TemporalMSDeformAttnDecoder", "patch_transformer", "graphed", "GraphedLayer", "tune"]
+           "MSDeformAttn", "TemporalMSDeformAttnEncoder", "TemporalMSDeformAttnDecoder", "patch_transformer", "graphed", "graph_stream", "GraphedLayer", "tune"]

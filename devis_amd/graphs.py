@@ -10,6 +10,12 @@ synchronisation), so a layer can be captured into a HIP graph as it is; this mod
 
 * forward AND backward are captured (``torch.cuda.make_graphed_callables``): gradients flow to the floating-point inputs that
   required them at capture time and to the module's parameters, exactly as from the eager module;
+* TRAINING calls (gradients wanted) must come from a NON-DEFAULT stream -- wrap the step in ``with devis_amd.graph_stream():``.
+  On this PyTorch-ROCm build a backward graph replayed next to eager work on the legacy default stream stops writing its small
+  outputs (bias and weight gradients) from the second replay on: they come back holding whatever the forward graph last left
+  in that part of the pool, silently (``scripts/repro_graph_default_stream.py``: forty lines of pure torch, no code of this
+  package; outputs and input gradients are right, any non-default stream is right).  A training call made on the default
+  stream therefore runs the module EAGERLY (one warning; ``layer.eager_calls`` counts them); inference calls replay anywhere;
 * one graph per SIGNATURE -- shapes / dtypes / ``requires_grad`` of the floating-point tensor arguments, and the identity (object
   and version) of every other argument: the integer tensors (``spatial_shapes``, ``level_start_index``), the list of
   ``temporal_offsets``, ``None`` masks.  Those are bound into the graph at capture: the library chooses kernels, grids and LDS plans
@@ -18,10 +24,34 @@ synchronisation), so a layer can be captured into a HIP graph as it is; this mod
   rebuilds ``spatial_shapes`` on every forward (deformable_transformer.py:87): hoist it, or accept one capture per step, which
   is slower than eager.
 """
+import contextlib
 import threading
+import warnings
 
 import torch
 from torch import nn
+
+_graph_streams = {}
+
+
+@contextlib.contextmanager
+def graph_stream(device=None):
+    """Run the enclosed code on a non-default stream of ``device`` (one per device, kept), fenced against the caller's current
+    stream on entry and exit: what graphed TRAINING steps need on this PyTorch-ROCm build (see the module docstring)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    side = _graph_streams.get(device)
+    if side is None:
+        side = _graph_streams[device] = torch.cuda.Stream(device)
+    cur = torch.cuda.current_stream(device)
+    if cur == side:
+        yield side
+        return
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        yield side
+    cur.wait_stream(side)
 
 
 def _is_flowing(x):
@@ -86,6 +116,7 @@ class GraphedLayer:
         self._cache = {}
         self._keep = {}                     # signature -> the bound arguments (kept alive: their identity is the key)
         self._lock = threading.Lock()
+        self.eager_calls = 0                # training calls made on the default stream (run eagerly: see the module docstring)
 
     @property
     def graphs(self):
@@ -119,7 +150,7 @@ class GraphedLayer:
             bound = _Bound(self.module, template, self.aux_grad)
             # (the capture runs the backward too: grad mode on, even when the first call comes from inside torch.no_grad() --
             # inference, tracker.py:320-323 -- where the graphed callable then replays its forward graph only)
-            with torch.enable_grad():
+            with graph_stream(next(t.device for t in flowing if t.is_cuda)), torch.enable_grad():
                 fn = torch.cuda.make_graphed_callables(bound, samples, num_warmup_iters=self.num_warmup_iters)
             self._cache[sig] = fn
             self._keep[sig] = [a for a in args if not _is_flowing(a)]
@@ -128,9 +159,30 @@ class GraphedLayer:
                 del self._cache[oldest], self._keep[oldest]
             return fn
 
+    def _wants_gradients(self, args):
+        return torch.is_grad_enabled() and (any(_is_flowing(a) and a.requires_grad for a in args) or
+                                            any(p.requires_grad for p in self.module.parameters()))
+
     def __call__(self, *args):
+        dev = next((a.device for a in args if _is_flowing(a) and a.is_cuda), None)
+        if dev is not None and self._wants_gradients(args) and torch.cuda.current_stream(dev) == torch.cuda.default_stream(dev):
+            if not self.eager_calls:
+                warnings.warn("devis_amd.graphed: a call that needs gradients was made on the default stream and runs eagerly -- "
+                              "on this PyTorch-ROCm build a backward graph replayed next to default-stream work returns stale "
+                              "parameter gradients (scripts/repro_graph_default_stream.py); wrap the training step in "
+                              "`with devis_amd.graph_stream():`", stacklevel=2)
+            self.eager_calls += 1
+            out = self.module(*args)
+            if self.aux_grad or not isinstance(out, tuple):
+                return out
+            return (out[0],) + tuple(_detach(o) for o in out[1:])
         fn = self.capture(*args)
-        out = fn(*(a for a in args if _is_flowing(a)))
+        with graph_stream(dev):             # (no-op inside a caller's own graph_stream; inference calls from the default stream replay here too)
+            flowing = [a for a in args if _is_flowing(a)]
+            for a in flowing:
+                if a.is_cuda:
+                    a.record_stream(torch.cuda.current_stream(dev))
+            out = fn(*flowing)
         if self.aux_grad or not isinstance(out, tuple):
             return out
         # (the graphed autograd function marks every output as differentiable; the auxiliary ones carry no gradient inside the

@@ -219,28 +219,53 @@ def test_graphed_helper_reproduces_the_eager_layer_with_parameter_gradients_and_
     layer = devis_amd.graphed(mod, inputs(1, 60))
     assert layer.graphs == 1
     params = [p for p in mod.parameters()]
-    for seed, q in ((2, 60), (3, 180), (4, 60)):
+
+    def check(seed, q, eager_first):
         a, b = inputs(seed, q), inputs(seed, q)
         res_g = layer(*a)
         res_e = mod(*b)
         assert len(res_g) == 5 and len(res_g[1]) == T and res_g[3].shape == res_e[3].shape
         assert res_g[0].requires_grad and not res_g[3].requires_grad and not res_g[1][0].requires_grad      # aux outputs: detached
         w = torch.randn_like(res_e[0])
+        if eager_first:
+            ge = torch.autograd.grad((res_e[0] * w).sum(), [b[0], b[2]] + params)
         gg = torch.autograd.grad((res_g[0] * w).sum(), [a[0], a[2]] + params)
-        ge = torch.autograd.grad((res_e[0] * w).sum(), [b[0], b[2]] + params)
+        if not eager_first:
+            ge = torch.autograd.grad((res_e[0] * w).sum(), [b[0], b[2]] + params)
         torch.cuda.synchronize()
         assert torch.allclose(res_g[0], res_e[0], rtol=1e-5, atol=1e-6)
         assert torch.allclose(res_g[3], res_e[3], rtol=1e-5, atol=1e-7) and torch.allclose(res_g[1][2], res_e[1][2], rtol=1e-5, atol=1e-6)
-        for x, y in zip(gg, ge):
-            assert torch.allclose(x, y, rtol=1e-4, atol=2e-5 * max(1e-6, float(y.abs().max())))
-    assert layer.graphs == 2                        # 60 and 180 queries per frame; the third call replayed the first graph
-    # inference: first use from inside torch.no_grad() (tracker.py:320-323) -- its own signature (nothing requires grad)
+        for (name, _), x, y in zip([("query", 0), ("src", 0)] + list(mod.named_parameters()), gg, ge):
+            assert torch.allclose(x, y, rtol=1e-4, atol=2e-5 * max(1e-6, float(y.abs().max()))), (seed, q, name)
+
+    # Training steps belong on a non-default stream (devis_amd.graph_stream): on this PyTorch-ROCm build a backward graph replayed
+    # next to default-stream work hands back unwritten bias / weight gradients from the second replay on
+    # (scripts/repro_graph_default_stream.py, pure torch).  Each graph is replayed three times, the eager twin's backward now
+    # before and now after the graphed one (the orders that exposed it).
+    with devis_amd.graph_stream():
+        assert torch.cuda.current_stream() != torch.cuda.default_stream()
+        for seed, q in ((2, 60), (3, 180), (4, 60), (5, 180), (6, 60), (7, 180)):
+            check(seed, q, eager_first=bool(seed % 2))
+    assert layer.graphs == 2 and layer.eager_calls == 0     # 60 and 180 queries per frame; the later calls replayed them
+    # ... and a training call made ON the default stream runs the module eagerly (one warning), right all the same
+    assert torch.cuda.current_stream() == torch.cuda.default_stream()
+    with pytest.warns(UserWarning, match="graph_stream"):
+        check(8, 60, eager_first=False)
+    check(9, 180, eager_first=True)
+    assert layer.graphs == 2 and layer.eager_calls == 2
+    # inference: first use from inside torch.no_grad() (tracker.py:320-323) -- its own signature (nothing requires grad); replays
+    # from the default stream too, several times over, with eager work in between
     with torch.no_grad():
-        a = inputs(5, 60)
-        a = tuple(x.detach() if isinstance(x, torch.Tensor) else x for x in a)
-        res_g, res_e = layer(*a), mod(*a)
-        assert torch.allclose(res_g[0], res_e[0], rtol=1e-5, atol=1e-6) and not res_g[0].requires_grad
-    assert layer.graphs == 3
+        for seed in (10, 11, 12, 13):
+            a = inputs(seed, 60)
+            a = tuple(x.detach() if isinstance(x, torch.Tensor) else x for x in a)
+            res_g = layer(*a)
+            noise = (torch.randn_like(res_g[0]) * res_g[0]).sum()
+            res_e = mod(*a)
+            torch.cuda.synchronize()
+            assert torch.allclose(res_g[0], res_e[0], rtol=1e-5, atol=1e-6) and not res_g[0].requires_grad
+            assert torch.allclose(res_g[3], res_e[3], rtol=1e-5, atol=1e-7) and torch.allclose(res_g[1][2], res_e[1][2], rtol=1e-5, atol=1e-6)
+    assert layer.graphs == 3 and layer.eager_calls == 2
     with pytest.raises(RuntimeError, match="no CPU path"):
         devis_amd.graphed(mod, tuple(x.cpu() if isinstance(x, torch.Tensor) else x for x in inputs(1, 60)))
 
