@@ -77,12 +77,18 @@ class _Bound(nn.Module):
         self._template = template           # positional arguments; None at the places of the flowing tensors
         self._slots = [i for i, a in enumerate(template) if a is _FLOW]
         self._aux_grad = aux_grad
+        self.none_slots = []
 
     def forward(self, *flowing):
         args = list(self._template)
         for i, t in zip(self._slots, flowing):
             args[i] = t
         out = self.inner(*args)
+        if isinstance(out, tuple):
+            # (a ``None`` among the outputs -- the temporal encoder's second one -- is not something a graph can return: left out
+            # here, put back by GraphedLayer.__call__)
+            self.none_slots = [i for i, o in enumerate(out) if o is None]
+            out = tuple(o for o in out if o is not None)
         if self._aux_grad or not isinstance(out, tuple):
             return out
         # Only the FIRST output carries gradients through the graph: the temporal decoder's other four (sampling locations and
@@ -183,11 +189,15 @@ class GraphedLayer:
                 if a.is_cuda:
                     a.record_stream(torch.cuda.current_stream(dev))
             out = fn(*flowing)
-        if self.aux_grad or not isinstance(out, tuple):
+        if not isinstance(out, tuple):
             return out
-        # (the graphed autograd function marks every output as differentiable; the auxiliary ones carry no gradient inside the
-        # graph -- _Bound.forward -- and say so here)
-        return (out[0],) + tuple(_detach(o) for o in out[1:])
+        if not self.aux_grad:
+            # (the graphed autograd function marks every output as differentiable; the auxiliary ones carry no gradient inside
+            # the graph -- _Bound.forward -- and say so here)
+            out = (out[0],) + tuple(_detach(o) for o in out[1:])
+        for i in getattr(fn, "none_slots", ()):
+            out = out[:i] + (None,) + out[i:]
+        return out
 
 
 def graphed(module, example_inputs=None, num_warmup_iters=3, aux_grad=False):

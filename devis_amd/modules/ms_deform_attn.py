@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
+from .. import _native
 from ..functions import (MSDeformAttnFunction, MSDeformAttnTemporalFunction, MSDeformPrepFunction,
                          MSDeformPrepFusedFunction, project_value)
 
@@ -167,7 +168,11 @@ class MSDeformAttn(_FusedParamsCache, nn.Module):
         """
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
-        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        # ref :96 (``assert (shapes[:, 0] * shapes[:, 1]).sum() == Len_in``: a device read per call there); here against the cached
+        # host copy of the tensor -- one read per distinct ``spatial_shapes`` tensor, none inside a HIP-graph capture
+        hint = _native.shapes_hint(input_spatial_shapes) if input_spatial_shapes.is_cuda else input_spatial_shapes.reshape(-1).tolist()
+        if hint is not None:
+            assert sum(int(hint[2 * l]) * int(hint[2 * l + 1]) for l in range(len(hint) // 2)) == Len_in
         M, L, P = self.n_heads, self.n_levels, self.n_points
 
         # value_proj writes value[N, S, M, D] with one spare head slot per pixel row (SURVEY f-3): same

@@ -145,6 +145,9 @@ def test_constructor_contract():
         m_plain = MSDeformAttn(32, 2, 4, 3)
         m_plain(torch.zeros(1, 2, 32), torch.zeros(1, 2, 2, 3), torch.zeros(1, 30, 32),
                 torch.tensor([[6, 4], [3, 2]]), torch.tensor([0, 24]), None)
+    with pytest.raises(AssertionError):                          # :96: sum of H*W against the length of input_flatten
+        m_plain(torch.zeros(1, 2, 32), torch.zeros(1, 2, 2, 2), torch.zeros(1, 29, 32),
+                torch.tensor([[6, 4], [3, 2]]), torch.tensor([0, 24]), None)
 
 
 def test_frame_table_is_cached_per_offset_tensors():

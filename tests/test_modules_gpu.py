@@ -270,6 +270,64 @@ def test_graphed_helper_reproduces_the_eager_layer_with_parameter_gradients_and_
         devis_amd.graphed(mod, tuple(x.cpu() if isinstance(x, torch.Tensor) else x for x in inputs(1, 60)))
 
 
+@pytest.mark.parametrize("kind", ["plain", "temporal_encoder"])
+def test_graphed_helper_on_the_other_layer_types(kind):
+    """``devis_amd.graphed`` around ``MSDeformAttn`` (with a padding mask: a bound, non-floating argument) and around
+    ``TemporalMSDeformAttnEncoder`` (single-tensor output): four replays under ``graph_stream``, outputs, input and parameter
+    gradients against the eager module."""
+    import devis_amd
+    from devis_amd.modules import MSDeformAttn, TemporalMSDeformAttnEncoder
+    torch.manual_seed(3)
+    C, M, L = 256, 8, 4
+    pyr = [(20, 30), (10, 15), (5, 8), (3, 4)]
+    shapes = torch.tensor(pyr, dtype=torch.long, device=DEV)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    gen = torch.Generator(device="cpu")
+    mk = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    if kind == "plain":
+        N, Lq = 3, 77
+        mod = MSDeformAttn(C, L, M, 4).to(DEV)
+        mask = (torch.rand(N, S, generator=gen) < 0.1).to(DEV)
+
+        def inputs(seed):
+            gen.manual_seed(seed)
+            return (mk(N, Lq, C).requires_grad_(True), (torch.rand(N, Lq, L, 2, generator=gen) * 0.8 + 0.1).to(DEV),
+                    mk(N, S, C).requires_grad_(True), shapes, lsi, mask)
+    else:
+        T = 4
+        mod = TemporalMSDeformAttnEncoder(T, C, L, T - 1, M, 4, 2).to(DEV)
+        t_shapes = shapes.repeat(T - 1, 1)
+        t_lsi = torch.cat((t_shapes.new_zeros((1,)), t_shapes.prod(1).cumsum(0)[:-1]))
+        offsets = [torch.tensor([t for t in range(-f, T - f) if t != 0], device=DEV) for f in range(T)]
+
+        def inputs(seed):
+            gen.manual_seed(seed)
+            return (mk(T, S, C).requires_grad_(True), (torch.rand(T, S, L, 2, generator=gen) * 0.8 + 0.1).to(DEV),
+                    mk(T, S, C).requires_grad_(True), (shapes, t_shapes), (lsi, t_lsi), offsets)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.normal_(0, 0.05)
+    params = list(mod.parameters())
+    first = lambda o: o[0] if isinstance(o, tuple) else o
+    with devis_amd.graph_stream():
+        layer = devis_amd.graphed(mod, inputs(1))
+        for seed in (2, 3, 4, 5):
+            a, b = inputs(seed), inputs(seed)
+            out_g, out_e = first(layer(*a)), first(mod(*b))
+            w = torch.randn_like(out_e)
+            if seed % 2:
+                ge = torch.autograd.grad((out_e * w).sum(), [b[0], b[2]] + params)
+            gg = torch.autograd.grad((out_g * w).sum(), [a[0], a[2]] + params)
+            if not seed % 2:
+                ge = torch.autograd.grad((out_e * w).sum(), [b[0], b[2]] + params)
+            torch.cuda.synchronize()
+            assert torch.allclose(out_g, out_e, rtol=1e-5, atol=1e-6)
+            for (name, _), x, y in zip([("query", 0), ("src", 0)] + list(mod.named_parameters()), gg, ge):
+                assert torch.allclose(x, y, rtol=1e-4, atol=2e-5 * max(1e-6, float(y.abs().max()))), (kind, seed, name)
+    assert layer.graphs == 1 and layer.eager_calls == 0
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 8e-3), (torch.float16, 2e-3)], ids=["f32", "bf16", "f16"])
 def test_value_proj_gradients_at_clip_size_through_the_split_k_product(dtype, tol):
     """`project_value` at the size of one DeVIS clip (T x S = 28 920 rows, 256 -> 256): its backward computes the weight gradient as
