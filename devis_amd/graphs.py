@@ -36,18 +36,19 @@ _graph_streams = {}
 
 @contextlib.contextmanager
 def graph_stream(device=None):
-    """Run the enclosed code on a non-default stream of ``device`` (one per device, kept), fenced against the caller's current
-    stream on entry and exit: what graphed TRAINING steps need on this PyTorch-ROCm build (see the module docstring)."""
+    """Run the enclosed code on a non-default stream of ``device`` (one per device, kept), fenced against the default stream on
+    entry and exit -- what graphed TRAINING steps need on this PyTorch-ROCm build (see the module docstring); nothing to do when
+    the caller is on a non-default stream already."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
+    cur = torch.cuda.current_stream(device)
+    if cur != torch.cuda.default_stream(device):        # already on a stream of the caller's own (or inside an outer graph_stream)
+        yield cur
+        return
     side = _graph_streams.get(device)
     if side is None:
         side = _graph_streams[device] = torch.cuda.Stream(device)
-    cur = torch.cuda.current_stream(device)
-    if cur == side:
-        yield side
-        return
     side.wait_stream(cur)
     with torch.cuda.stream(side):
         yield side
