@@ -731,6 +731,18 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": d_bytes * args.clips, "avg_launch_ms": round(d_ms, 4),
                     "traffic_source": traffic_src}
+        # the fraction of the NOMINAL peak above, and of what a plain device-to-device copy reaches on this very box
+        # (1 GiB read + 1 GiB written per copy, HIP events, median of 10)
+        try:
+            src_buf = torch.empty(256 << 20, dtype=torch.float32, device=device).fill_(1.0)
+            dst_buf = torch.empty_like(src_buf)
+            copy_ms = _event_ms(lambda: dst_buf.copy_(src_buf), 10, 3)
+            copy_gbs = 2 * src_buf.numel() * 4 / (copy_ms * 1e-3) / 1e9
+            roofline["measured_copy_GBps"] = round(copy_gbs, 1)
+            roofline["frac_of_measured_copy"] = round(ach / copy_gbs, 4)
+            del src_buf, dst_buf
+        except RuntimeError:
+            pass
         extra = {"kernels": {k: {"avg_ms": round(v[0], 4), "median_ms": round(v[1], 4),
                                  "algorithmic_GBps": round(v[2] * args.clips / (v[0] * 1e-3) / 1e9, 1),
                                  "frac_of_hbm_peak": round(v[2] * args.clips / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
