@@ -80,6 +80,7 @@ CASES = {
     "dec4": lambda: temporal_case(4, "A", "uniform", 300, torch.float32, 30),
     "dec8": lambda: temporal_case(8, "A", "uniform", 300, torch.float32, 20),
     "dec6S": lambda: temporal_case(6, "S", "uniform", 300, torch.float32, 20),
+    "dec8B": lambda: temporal_case(8, "B", "uniform", 300, torch.float32, 10),
     "dec12_bf16": lambda: temporal_case(12, "A", "uniform", 300, torch.bfloat16, 20),
     "pdec36": lambda: plain_case(bench.PYRAMIDS["A"], 36, 300, "uniform", torch.float32, 20),
     "dec1_bf16": lambda: temporal_case(1, "A", "uniform", 300, torch.bfloat16, 30),
