@@ -298,7 +298,13 @@ def project_value(x, linear, n_heads, padding_mask=None, pad_heads=1, consumer_m
     rows where the mask is set (``MSDeformAttnFunction`` given the same ``padding_mask``), so the backward skips it."""
     if pad_heads <= 0 and padding_mask is None:
         return linear(x).view(x.shape[0], x.shape[1], n_heads, linear.out_features // n_heads)
-    return _PaddedValueProj.apply(x, linear.weight, linear.bias, n_heads, max(pad_heads, 0), padding_mask,
+    weight, bias = linear.weight, linear.bias
+    if x.is_cuda and torch.is_autocast_enabled("cuda"):
+        # under torch.autocast an nn.Linear computes and returns the autocast dtype; the padded product (an out= GEMM autocast
+        # does not see) does the same, so that `value` -- and with it the operator's storage type -- is 16-bit as the user asked
+        dt = torch.get_autocast_dtype("cuda")
+        x, weight, bias = x.to(dt), weight.to(dt), (bias.to(dt) if bias is not None else None)
+    return _PaddedValueProj.apply(x, weight, bias, n_heads, max(pad_heads, 0), padding_mask,
                                   bool(consumer_masks_grad) and padding_mask is not None)
 
 

@@ -270,6 +270,52 @@ def test_graphed_helper_reproduces_the_eager_layer_with_parameter_gradients_and_
         devis_amd.graphed(mod, tuple(x.cpu() if isinstance(x, torch.Tensor) else x for x in inputs(1, 60)))
 
 
+@pytest.mark.parametrize("ac", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_modules_run_under_autocast_in_16_bit_storage(ac):
+    """fp32 modules under ``torch.autocast`` (something the reference's extension cannot do: its kernels take ONE scalar type
+    for value and locations): ``value_proj`` hands the operator a 16-bit ``value`` like any autocast Linear would, the sampling
+    locations stay float32, outputs come back in the autocast dtype and parameters get float32 gradients.  Checked against the
+    fp32 run: outputs and every gradient that does not go through a sampling POSITION (those of the offset Linears and of the
+    query jump when a 16-bit offset lands in the neighbouring pixel cell of a random feature map: not compared)."""
+    from devis_amd.functions import project_value
+    from devis_amd.modules import MSDeformAttn, TemporalMSDeformAttnDecoder
+    T, C, M, L, q = 6, 256, 8, 4, 60
+    shapes = torch.tensor(module_cases.CFG["pyramid"], dtype=torch.long, device=DEV)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    t_shapes = shapes.repeat(T - 1, 1)
+    t_lsi = torch.cat((t_shapes.new_zeros((1,)), t_shapes.prod(1).cumsum(0)[:-1]))
+    offsets = [torch.tensor([t for t in range(-f, T - f) if t != 0], device=DEV) for f in range(T)]
+    gen = torch.Generator().manual_seed(5)
+    mk = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    torch.manual_seed(0)
+    dec, plain = TemporalMSDeformAttnDecoder(T, C, L, T - 1, M, 4, 4).to(DEV), MSDeformAttn(C, L, M, 4).to(DEV)
+    with torch.no_grad():
+        for p in list(dec.parameters()) + list(plain.parameters()):
+            p.normal_(0, 0.05)
+    ref = (torch.rand(1, T * q, L, 2, generator=gen) * 0.8 + 0.1).to(DEV)
+    mask = (torch.rand(T, S, generator=gen) < 0.05).to(DEV)
+    cases = [(dec, (mk(1, T * q, C).requires_grad_(True), ref, mk(T, S, C).requires_grad_(True), (shapes, t_shapes), (lsi, t_lsi), offsets)),
+             (plain, (mk(T, q, C).requires_grad_(True), ref.view(T, q, L, 2), mk(T, S, C).requires_grad_(True), shapes, lsi, mask))]
+    for mod, args in cases:
+        w = mk(*mod(*args)[0].shape)
+        wanted = [(n, p) for n, p in mod.named_parameters() if "sampling_offsets" not in n]
+        leaves = [args[2]] + [p for _, p in wanted]
+
+        def run(enabled):
+            with torch.autocast("cuda", dtype=ac, enabled=enabled):
+                out = mod(*args)[0]
+                value = project_value(args[2], mod.value_proj, M, None, 1)
+            return out, value.dtype, torch.autograd.grad((out.float() * w).sum(), leaves)
+        o32, vdt32, g32 = run(False)
+        o16, vdt16, g16 = run(True)
+        assert (vdt32, vdt16) == (torch.float32, ac) and o16.dtype == ac and all(g.dtype == torch.float32 for g in g16)
+        tol = 1e-2 if ac == torch.bfloat16 else 2e-3
+        assert float((o16.detach().float() - o32.detach()).abs().max()) <= tol * float(o32.detach().abs().max())
+        for (name, _), a, b in zip([("src", None)] + wanted, g16, g32):
+            assert float((a - b).abs().max()) <= 4 * tol * float(b.abs().max()), (type(mod).__name__, name)
+
+
 @pytest.mark.parametrize("kind", ["plain", "temporal_encoder"])
 def test_graphed_helper_on_the_other_layer_types(kind):
     """``devis_amd.graphed`` around ``MSDeformAttn`` (with a padding mask: a bound, non-floating argument) and around
