@@ -136,7 +136,10 @@ class GraphedLayer:
                 sig.append(("f", tuple(a.shape), a.dtype, a.device, a.requires_grad))
             else:
                 sig.append(_static_key(a))
-        return tuple(sig) + (self.module.training,)
+        # (+ what else changes the captured kernels: train / eval, and the ambient autocast state -- under torch.autocast use
+        # ``cache_enabled=False``, as torch.cuda.make_graphed_callables asks)
+        autocast = (torch.get_autocast_dtype("cuda"),) if torch.is_autocast_enabled("cuda") else ()
+        return tuple(sig) + (self.module.training,) + autocast
 
     def capture(self, *args):
         """Capture (or fetch) the graph for this signature without running it: call once per shape before timing."""
