@@ -229,6 +229,8 @@ class _FrameTables:
         self._lock = threading.Lock()
         self._entries = []          # [(offset tensors with versions, n_frames, device, table)], most recently used last
         self._pending = []          # [(pinned verdict, event, n_frames, offsets as given)]
+        self._captured = {}         # id -> table served inside a HIP-graph capture: the graph holds its ADDRESS, so it is never
+                                    # freed (a few hundred bytes per captured (layer stack, offsets list))
 
     @staticmethod
     def _describe(offsets):
@@ -266,6 +268,8 @@ class _FrameTables:
             for i, (held, nf, dev, table) in enumerate(self._entries):
                 if nf == n_frames and dev == device and self._same(held, temporal_offsets):
                     self._entries.append(self._entries.pop(i))
+                    if _capturing(table):
+                        self._captured[id(table)] = table
                     return table
         table = torch.stack([o.to(device) for o in temporal_offsets]) \
             + torch.arange(n_frames, device=device)[:, None]
@@ -286,7 +290,13 @@ class _FrameTables:
         with self._lock:
             self._entries.append(([(o, o._version) for o in temporal_offsets], n_frames, device, table))
             del self._entries[:-self.capacity]
+            if _capturing(table):
+                self._captured[id(table)] = table
         return table
+
+
+def _capturing(t):
+    return t.is_cuda and torch.cuda.is_current_stream_capturing()
 
 
 def _flush_offset_checks(like):

@@ -255,6 +255,22 @@ def test_frame_tables_of_two_stacks_do_not_evict_each_other_and_are_thread_safe(
     assert not errors, errors
 
 
+def test_frame_tables_served_inside_a_graph_capture_are_never_freed(monkeypatch):
+    """A HIP graph holds the ADDRESS of the frame table it was captured with; the cache is a small LRU, so a table served
+    while the stream is capturing is kept for good (here the capture is simulated: no GPU)."""
+    import weakref
+    from devis_amd.modules import ms_deform_attn as mm
+    cache = mm._FrameTables()
+    monkeypatch.setattr(mm, "_capturing", lambda t: True)
+    first = [torch.tensor([1, 2]), torch.tensor([-1, 1]), torch.tensor([-2, -1])]
+    ref = weakref.ref(cache.get(first, 3, torch.device("cpu")))
+    monkeypatch.setattr(mm, "_capturing", lambda t: False)
+    for i in range(cache.capacity + 3):                 # push the first entry out of the LRU
+        cache.get([torch.tensor([1, 2]), torch.tensor([-1, 1]), torch.tensor([-2, -1])], 3, torch.device("cpu"))
+    assert not any(cache._same(e[0], first) for e in cache._entries)
+    assert ref() is not None and ref().tolist() == [[1, 2], [0, 2], [0, 1]]
+
+
 def test_bad_cpu_offsets_raise_with_the_offsets_in_the_message():
     from devis_amd.modules import TemporalMSDeformAttnDecoder as Dec
     with pytest.raises(IndexError, match=r"outside the clip's 3 frames \(temporal_offsets = \[\[1, 7\]"):
