@@ -70,6 +70,10 @@ def _fused_linear_params(module, linears):
         return torch.cat([l.weight for l in linears]), torch.cat([l.bias for l in linears])
     if torch.is_inference_mode_enabled():
         return torch.cat([l.weight for l in linears]), torch.cat([l.bias for l in linears])
+    if params[0].is_cuda and torch.cuda.is_current_stream_capturing():
+        # inside a HIP-graph capture the concatenation is part of the graph: a cached copy would be baked in by address and go
+        # stale (or be freed) at the next optimizer step
+        return torch.cat([l.weight for l in linears]), torch.cat([l.bias for l in linears])
     key = tuple((q.data_ptr(), q._version, q.dtype) for q in params)
     cached = module.__dict__.get("_fused_params")
     if cached is None or cached[0] != key:

@@ -266,8 +266,47 @@ def test_graphed_helper_reproduces_the_eager_layer_with_parameter_gradients_and_
             assert torch.allclose(res_g[0], res_e[0], rtol=1e-5, atol=1e-6) and not res_g[0].requires_grad
             assert torch.allclose(res_g[3], res_e[3], rtol=1e-5, atol=1e-7) and torch.allclose(res_g[1][2], res_e[1][2], rtol=1e-5, atol=1e-6)
     assert layer.graphs == 3 and layer.eager_calls == 2
+    # ... and an inference graph follows the parameters: an in-place update (an optimizer step) between two replays
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.mul_(1.25)
+        a = tuple(x.detach() if isinstance(x, torch.Tensor) else x for x in inputs(14, 60))
+        res_g, res_e = layer(*a), mod(*a)
+        torch.cuda.synchronize()
+        assert layer.graphs == 3 and torch.allclose(res_g[0], res_e[0], rtol=1e-5, atol=1e-6)
     with pytest.raises(RuntimeError, match="no CPU path"):
         devis_amd.graphed(mod, tuple(x.cpu() if isinstance(x, torch.Tensor) else x for x in inputs(1, 60)))
+
+
+def test_inference_graph_follows_in_place_parameter_updates():
+    """A forward captured under ``torch.no_grad()`` (where the modules cache the concatenated query-side Linear parameters between
+    calls) must not bake that cached copy in by address: after an in-place parameter update the replay equals the eager call."""
+    from devis_amd.modules import MSDeformAttn
+    torch.manual_seed(1)
+    C, M, L, N, Lq = 256, 8, 4, 2, 50
+    shapes = torch.tensor(module_cases.CFG["pyramid"], dtype=torch.long, device=DEV)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    mod = MSDeformAttn(C, L, M, 4).to(DEV)
+    q, ref, src = torch.randn(N, Lq, C, device=DEV), torch.rand(N, Lq, L, 2, device=DEV), torch.randn(N, S, C, device=DEV)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.normal_(0, 0.05)
+        for _ in range(2):
+            mod(q, ref, src, shapes, lsi, None)                 # warm-up: fills the parameter cache, the shapes hint
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side), torch.cuda.graph(graph):
+            out = mod(q, ref, src, shapes, lsi, None)[0]
+        torch.cuda.current_stream().wait_stream(side)
+        for scale in (1.0, 1.5, 0.5):
+            for p in mod.parameters():
+                p.mul_(scale)
+            q.normal_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.allclose(out, mod(q, ref, src, shapes, lsi, None)[0], rtol=1e-5, atol=1e-6), scale
 
 
 @pytest.mark.parametrize("ac", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
