@@ -20,6 +20,7 @@ inline in the reference's ``forward`` s; the attention modules consume them as t
 import torch
 
 _grid_cache = {}
+_captured = {}
 _MAX_ENTRIES = 32
 
 
@@ -45,7 +46,10 @@ def get_reference_points(spatial_shapes, valid_ratios, device):
     every level, normalised by the valid part of the (padded) frame."""
     shapes = _pyramid(spatial_shapes)
     key = (shapes, str(device))
+    capturing = torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()
     grids = _grid_cache.get(key)
+    if grids is not None and capturing:
+        _captured.setdefault(key, grids)        # a HIP graph now holds these addresses: out of the cache's reach for good
     if grids is None:
         grids = []
         for H_, W_ in shapes:
@@ -53,9 +57,10 @@ def get_reference_points(spatial_shapes, valid_ratios, device):
                                           torch.linspace(0.5, W_ - 0.5, W_, dtype=torch.float32, device=device),
                                           indexing='ij')
             grids.append((ref_y.reshape(-1)[None], ref_x.reshape(-1)[None]))
-        if len(_grid_cache) >= _MAX_ENTRIES:
-            _grid_cache.clear()
-        _grid_cache[key] = grids
+        if not capturing:                       # (grids built INSIDE a capture live in the graph's memory pool: never shared)
+            if len(_grid_cache) >= _MAX_ENTRIES:
+                _grid_cache.clear()
+            _grid_cache[key] = grids
     per_level = []
     for lvl, ((H_, W_), (gy, gx)) in enumerate(zip(shapes, grids)):
         ref_y = gy / (valid_ratios[:, None, lvl, 1] * H_)
