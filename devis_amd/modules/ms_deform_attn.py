@@ -291,11 +291,11 @@ class _FrameTables:
             with self._lock:
                 self._pending.append((host, done, n_frames, list(temporal_offsets)))
         table = torch.remainder(table, n_frames).to(torch.int32).contiguous()
+        if _capturing(table):
+            return table                # built INSIDE a capture: a temporary of that graph (its contents exist only after a replay)
         with self._lock:
             self._entries.append(([(o, o._version) for o in temporal_offsets], n_frames, device, table))
             del self._entries[:-self.capacity]
-            if _capturing(table):
-                self._captured[id(table)] = table
         return table
 
 
