@@ -261,9 +261,15 @@ def test_frame_tables_served_inside_a_graph_capture_are_never_freed(monkeypatch)
     import weakref
     from devis_amd.modules import ms_deform_attn as mm
     cache = mm._FrameTables()
-    monkeypatch.setattr(mm, "_capturing", lambda t: True)
     first = [torch.tensor([1, 2]), torch.tensor([-1, 1]), torch.tensor([-2, -1])]
-    ref = weakref.ref(cache.get(first, 3, torch.device("cpu")))
+    eager = cache.get(first, 3, torch.device("cpu"))            # built and cached outside a capture ...
+    monkeypatch.setattr(mm, "_capturing", lambda t: True)
+    ref = weakref.ref(cache.get(first, 3, torch.device("cpu")))  # ... and served inside one
+    assert ref() is eager
+    del eager
+    other = [torch.tensor([2, 1]), torch.tensor([1, -1]), torch.tensor([-1, -2])]
+    built_inside = cache.get(other, 3, torch.device("cpu"))      # a table BUILT inside a capture is that graph's temporary: not cached
+    assert not any(cache._same(e[0], other) for e in cache._entries) and built_inside.tolist() == [[2, 1], [2, 0], [1, 0]]
     monkeypatch.setattr(mm, "_capturing", lambda t: False)
     for i in range(cache.capacity + 3):                 # push the first entry out of the LRU
         cache.get([torch.tensor([1, 2]), torch.tensor([-1, 1]), torch.tensor([-2, -1])], 3, torch.device("cpu"))

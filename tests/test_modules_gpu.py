@@ -292,14 +292,15 @@ def test_inference_graph_follows_in_place_parameter_updates():
     with torch.no_grad():
         for p in mod.parameters():
             p.normal_(0, 0.05)
-        for _ in range(2):
-            mod(q, ref, src, shapes, lsi, None)                 # warm-up: fills the parameter cache, the shapes hint
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side), torch.cuda.graph(graph):
-            out = mod(q, ref, src, shapes, lsi, None)[0]
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                mod(q, ref, src, shapes, lsi, None)             # warm-up: fills the parameter cache, the shapes hint, the BLAS handles
         torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            out = mod(q, ref, src, shapes, lsi, None)[0]
         for scale in (1.0, 1.5, 0.5):
             for p in mod.parameters():
                 p.mul_(scale)
