@@ -1,3 +1,5 @@
+"""GPU probe (round 5): gather pass of the headline batch (fp32, bf16) at the frame-split grids named in FSPLITS, for the build MSDA_LIB
+names -- the timing-only gate of the level-0-band idea (profiles/NEGATIVE_RESULTS.md R5-16)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
