@@ -10,6 +10,8 @@ A query row = one (frame, query) producing C=256 outputs; M-queries/s = clips*T*
     python bench.py                       # 1 GPU, default K/W, prints ONE JSON line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          # no launcher: bench.py starts that very torchrun as a child (launch_ranks),
+                                          # relays its line and exits with its status; < N devices visible = an error
 
 Multi-GPU (`--gpus N`): clip-parallel -- every rank runs the same per-GPU batch of clips (weak
 scaling), no collective on the data path; timing = barrier + synchronize on both sides, max over ranks.
@@ -496,13 +498,80 @@ def other_configs(args, device):
     return res
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, script=None, check_devices=True, timeout=None):
+    """`python bench.py --gpus N` started WITHOUT a launcher: run the N ranks as a CHILD `python -m torch.distributed.run`
+    (one process per GPU over RCCL, the reference's own launch: main.py:129-143, src/util/misc.py:437-460), relay rank 0's one
+    JSON line and return the child's exit status.  Called before anything in this process has initialised the GPU
+    (`torch.cuda.device_count()` does not, on this image) and never through `os.exec*`.  Fewer than N visible devices is an
+    error, never a silent `n_gpus: 1` line.  `script` / `check_devices`: the CPU test drives a stub worker through the same code."""
+    import subprocess
+    if check_devices:
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d asked for, %d device(s) visible -- refusing to run fewer ranks\n" % (n, have))
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
+    env["BENCH_LAUNCHED_RANKS"] = str(n)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        out, _ = proc.communicate()
+        sys.stderr.write("bench.py: the %d-rank child did not finish in %s s\n" % (n, timeout))
+        return 124
+    line = None
+    for text in out.splitlines():
+        text = text.strip()
+        if text.startswith("{") and text.endswith("}"):
+            try:
+                json.loads(text)
+                line = text
+            except ValueError:
+                pass
+    rc = proc.returncode
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the %d-rank child exited 0 without a JSON line\n" % n)
+        rc = 1
+    if rc == 0:
+        got = json.loads(line)
+        if got.get("n_gpus") != n or got.get("ranks_seen", n) != n:
+            sys.stderr.write("bench.py: asked for %d ranks, the line reports n_gpus=%s ranks_seen=%s\n"
+                             % (n, got.get("n_gpus"), got.get("ranks_seen")))
+            rc = 1
+    if rc != 0:
+        sys.stderr.write("bench.py: %d-rank run failed (status %d)\n" % (n, rc))
+        return rc
+    print(line, flush=True)
+    return 0
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: be the launcher (a child process; this one has not touched the GPU)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # a launcher started another number of ranks than --gpus names: the line would lie about N either way
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or drop the launcher and let "
+                 "`python bench.py --gpus %d` start its own ranks)" % (args.gpus, world, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit("bench.py: rank %d has no device (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
