@@ -11,13 +11,13 @@ import torch
 
 from . import build as _build
 
-MSDA_ABI_VERSION = 12
+MSDA_ABI_VERSION = 13
 BWD_WORKSPACE_BYTES = 64
 _DTYPE_CODE = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.float16: 3}
 
 # every symbol include/msda.h declares (tests check the library exports each of them)
 EXPORTED_SYMBOLS = (
-    "msda_version", "msda_last_error", "msda_forward", "msda_backward",
+    "msda_version", "msda_build_info", "msda_last_error", "msda_forward", "msda_backward",
     "msda_temporal_forward", "msda_temporal_backward", "msda_backward_workspace_bytes",
     "msda_prep_forward", "msda_prep_backward", "msda_reload_knobs", "msda_last_route", "msda_mask_rows", "msda_grad_value_dtype",
     "msda_route_key", "msda_pin_route", "msda_clear_routes", "msda_route_count",
@@ -51,6 +51,10 @@ def load():
         if lib.msda_version() != MSDA_ABI_VERSION:
             raise RuntimeError("devis_amd: ABI version mismatch (library %d, binding %d); rebuild with "
                                "python -m devis_amd.build --force" % (lib.msda_version(), MSDA_ABI_VERSION))
+        lib.msda_build_info.restype = ctypes.c_char_p
+        if b"timing_only=1" in lib.msda_build_info() and os.environ.get("MSDA_ENABLE_HOOKS") != "1":
+            raise RuntimeError("devis_amd: %s is a TIMING-ONLY build (kernels that skip work, wrong results); it loads only "
+                               "with MSDA_ENABLE_HOOKS=1" % path)
         lib.msda_forward.restype = _ci
         lib.msda_forward.argtypes = [_ci] + [_vp] * 5 + [_ci] * 7 + [_vp, _vp, _vp, _vp]
         lib.msda_backward.restype = _ci
@@ -122,11 +126,39 @@ def _lib_or_load():
     return _lib if _lib is not None else load()
 
 
-def load_routes(path):
-    """Pin every entry of a routes file ({"routes": {key: {name: value}}}); returns the number of entries."""
+def _file_arch(doc):
+    """gfx name a routes file was measured on: its "arch" field, else the gfxNNN inside its "device" string."""
+    import re
+    if doc.get("arch"):
+        return str(doc["arch"])
+    m = re.search(r"gfx[0-9a-f]+", str(doc.get("device", "")))
+    return m.group(0) if m else None
+
+
+def _running_arch():
+    """gfx name of the current device, or None without a GPU (the CPU-only build container: nothing will run the routes)."""
+    try:
+        if torch.cuda.is_available():
+            return torch.cuda.get_device_properties(torch.cuda.current_device()).gcnArchName.split(":")[0]
+    except Exception:       # noqa: BLE001 -- a property torch does not have on this build: no check
+        pass
+    return None
+
+
+def load_routes(path, check_device=True):
+    """Pin every entry of a routes file ({"device": ..., "routes": {key: {name: value}}}); returns the number of entries pinned.
+    A table measured on another architecture than the running GPU's is skipped with a warning (timings do not carry over)."""
     import json
     with open(path) as f:
-        table = json.load(f).get("routes", {})
+        doc = json.load(f)
+    table = doc.get("routes", {})
+    if check_device:
+        want, have = _file_arch(doc), _running_arch()
+        if want and have and want != have:
+            import warnings
+            warnings.warn("devis_amd: %s was measured on %s, this GPU is %s: its %d pins are not loaded"
+                          % (path, want, have, len(table)))
+            return 0
     for key, settings in table.items():
         pin_route(key, settings)
     return len(table)

@@ -9,8 +9,9 @@ The library is several translation units (``csrc/*.hip``, one per kernel family,
 they are compiled in parallel into ``devis_amd/_build/*.o`` (each with a content-hash sidecar, so an
 edit recompiles only the unit it touches) and linked into one shared object.
 
-``MSDA_LIB=/path/to/other.so`` makes :func:`lib_path` (and hence ``_native.load``) use that file as is --
-for same-box A/B runs of an experimental build -- without touching the in-tree library.
+``MSDA_LIB=/path/to/other.so`` together with ``MSDA_ENABLE_HOOKS=1`` makes :func:`lib_path` (and hence ``_native.load``) use
+that file as is -- for same-box A/B runs of an experimental build -- without touching the in-tree library.  Without
+``MSDA_ENABLE_HOOKS=1`` the variable is an error: a production process cannot be pointed at another build by a stray variable.
 """
 import concurrent.futures
 import fcntl
@@ -59,8 +60,20 @@ def _headers():
         ([os.path.join(inc, "msda.h")] if inc else [])
 
 
+def _lib_override():
+    """$MSDA_LIB, honoured only beside MSDA_ENABLE_HOOKS=1 (measurement / A-B runs); set without it: an error, not a silent
+    switch of library (nor a silently ignored wish)."""
+    path = os.environ.get("MSDA_LIB")
+    if not path:
+        return None
+    if os.environ.get("MSDA_ENABLE_HOOKS") != "1":
+        raise RuntimeError("MSDA_LIB=%s is set without MSDA_ENABLE_HOOKS=1: another build of the library is only loaded for "
+                           "measurement runs (unset MSDA_LIB, or set MSDA_ENABLE_HOOKS=1)" % path)
+    return path
+
+
 def lib_path():
-    return os.environ.get("MSDA_LIB") or LIB
+    return _lib_override() or LIB
 
 
 def _digest(paths, extra=()):
@@ -178,10 +191,11 @@ def build(force=False, verbose=False, defines=(), out=None, jobs=None):
 def ensure():
     """What _native.load() calls: build when missing or stale (and a compiler exists); a stale library on a box
     without hipcc is loaded with a warning, a missing one raises."""
-    if os.environ.get("MSDA_LIB"):
-        if not os.path.exists(os.environ["MSDA_LIB"]):
-            raise RuntimeError("MSDA_LIB=%s does not exist" % os.environ["MSDA_LIB"])
-        return os.environ["MSDA_LIB"]
+    other = _lib_override()
+    if other:
+        if not os.path.exists(other):
+            raise RuntimeError("MSDA_LIB=%s does not exist" % other)
+        return other
     if not os.path.exists(LIB) or is_stale():
         if have_compiler():
             build()

@@ -21,7 +21,11 @@ thread_local char g_route[512] = "";     // kernels launched by the last entry-p
 
 int check_launch(const char *what)
 {
-    const size_t used = strlen(g_route);
+    size_t used = strlen(g_route);
+    if (MSDA_IS_TIMING_ONLY && used == 0) {       // a library with timing-only kernels compiled in says so in every route
+        snprintf(g_route, sizeof(g_route), "TIMING-ONLY BUILD (results are wrong by construction)");
+        used = strlen(g_route);
+    }
     if (used + 3 < sizeof(g_route)) snprintf(g_route + used, sizeof(g_route) - used, "%s%s", used ? "; " : "", what);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -64,7 +68,12 @@ struct Knobs {
     int force_generic = 0;
     int gv_storage = 1;                 // 0: msda_grad_value_dtype always answers the arithmetic type (A/B measurements)
     int dbg = 0;
+    int hooks = 0;                      // MSDA_ENABLE_HOOKS=1 was set when the knobs were read
+    unsigned forced = 0;                // route knobs that were SET in the environment (kForce* bits), whatever their value: a knob
+                                        // forced to its default (MSDA_FWD_RS=-1 for a rules-only A/B run) still wins over a pin
 };
+enum : unsigned { kForceFwdRs = 1, kForceFwdRsNt = 2, kForceFwdWin = 4, kForceFwdTileWaves = 8, kForceBwdRs = 16, kForceBwdRsTpw = 32,
+                  kForceBwdRsFsplit = 64, kForceBwdWin = 128, kForceScatterDbg = 256 };
 Knobs g_knobs;
 int g_knobs_loaded = 0;
 
@@ -74,10 +83,22 @@ int env_int(const char *name, int dflt)
     return (e && e[0]) ? atoi(e) : dflt;
 }
 
+bool env_set(const char *name)
+{
+    const char *e = getenv(name);
+    return e && e[0];
+}
+
 void load_knobs()
 {
     Knobs k;
     if (env_int("MSDA_ENABLE_HOOKS", 0) == 1) {
+        k.hooks = 1;
+        k.forced = (env_set("MSDA_FWD_RS") ? kForceFwdRs : 0u) | (env_set("MSDA_FWD_RS_NT") ? kForceFwdRsNt : 0u) |
+                   (env_set("MSDA_FWD_WIN") ? kForceFwdWin : 0u) | (env_set("MSDA_FWD_TILE_WAVES") ? kForceFwdTileWaves : 0u) |
+                   (env_set("MSDA_BWD_RS") ? kForceBwdRs : 0u) | (env_set("MSDA_BWD_RS_TPW") ? kForceBwdRsTpw : 0u) |
+                   (env_set("MSDA_BWD_RS_FSPLIT") ? kForceBwdRsFsplit : 0u) | (env_set("MSDA_BWD_WIN") ? kForceBwdWin : 0u) |
+                   (env_set("MSDA_SCATTER_DBG") ? kForceScatterDbg : 0u);
         k.fwd_rs = env_int("MSDA_FWD_RS", k.fwd_rs); k.fwd_rs_nt = env_int("MSDA_FWD_RS_NT", k.fwd_rs_nt);
         k.bwd_rs = env_int("MSDA_BWD_RS", k.bwd_rs); k.bwd_rs_tpw = env_int("MSDA_BWD_RS_TPW", k.bwd_rs_tpw);
         k.bwd_rs_fsplit = env_int("MSDA_BWD_RS_FSPLIT", k.bwd_rs_fsplit);
@@ -180,14 +201,14 @@ struct RouteScope {
             if (!found) return;
         }
         merged = knobs();
-        const Knobs dflt;
-        auto lay = [](int &dst, int dflt_v, int pinned) { if (pinned != -2 && dst == dflt_v) dst = pinned; };
-        lay(merged.fwd_rs, dflt.fwd_rs, pin.fwd_rs); lay(merged.fwd_rs_nt, dflt.fwd_rs_nt, pin.fwd_rs_nt);
-        lay(merged.fwd_win, dflt.fwd_win, pin.fwd_win); lay(merged.fwd_tile_waves, dflt.fwd_tile_waves, pin.fwd_tile_waves);
-        lay(merged.bwd_rs, dflt.bwd_rs, pin.bwd_rs); lay(merged.bwd_rs_tpw, dflt.bwd_rs_tpw, pin.bwd_rs_tpw);
-        lay(merged.bwd_rs_fsplit, dflt.bwd_rs_fsplit, pin.bwd_rs_fsplit); lay(merged.bwd_win, dflt.bwd_win, pin.bwd_win);
-        if (pin.scatter_order == 1 && (merged.scatter_dbg & 256) == 0 && merged.scatter_dbg == dflt.scatter_dbg) merged.scatter_dbg |= 256;
-        if (pin.scatter_order == 2 && merged.scatter_dbg == dflt.scatter_dbg) merged.scatter_dbg |= 2048;
+        const unsigned forced = merged.forced;
+        auto lay = [forced](int &dst, unsigned bit, int pinned) { if (pinned != -2 && !(forced & bit)) dst = pinned; };
+        lay(merged.fwd_rs, kForceFwdRs, pin.fwd_rs); lay(merged.fwd_rs_nt, kForceFwdRsNt, pin.fwd_rs_nt);
+        lay(merged.fwd_win, kForceFwdWin, pin.fwd_win); lay(merged.fwd_tile_waves, kForceFwdTileWaves, pin.fwd_tile_waves);
+        lay(merged.bwd_rs, kForceBwdRs, pin.bwd_rs); lay(merged.bwd_rs_tpw, kForceBwdRsTpw, pin.bwd_rs_tpw);
+        lay(merged.bwd_rs_fsplit, kForceBwdRsFsplit, pin.bwd_rs_fsplit); lay(merged.bwd_win, kForceBwdWin, pin.bwd_win);
+        if (pin.scatter_order == 1 && !(forced & kForceScatterDbg)) merged.scatter_dbg |= 256;
+        if (pin.scatter_order == 2 && !(forced & kForceScatterDbg)) merged.scatter_dbg |= 2048;
         tl_route_knobs = &merged;
         active = true;
     }
@@ -673,6 +694,9 @@ bool fast_path_takes(int dtype, const Params &p, bool bwd)
 int run(int dtype, const Params &p_in, bool bwd, hipStream_t stream)
 {
     if (dtype < MSDA_F32 || dtype > MSDA_F16_LOC32) return fail(MSDA_ERR_DTYPE, "msda: unknown dtype code%s");
+    if (MSDA_IS_TIMING_ONLY && !knobs().hooks)
+        return fail(MSDA_ERR_ARG, "msda: this library is a TIMING-ONLY build (kernels that skip work: wrong results); it runs only "
+                                  "with MSDA_ENABLE_HOOKS=1%s");
     Params p = p_in;
     const RouteScope pinned(bwd, dtype, p);     // (the pinned settings of this call shape, if any, are what knobs() answers below)
     p.dbg = knobs().dbg;
@@ -776,6 +800,11 @@ using namespace msda;
 extern "C" {
 
 int msda_version(void) { return MSDA_ABI_VERSION; }
+
+const char *msda_build_info(void)
+{
+    return MSDA_IS_TIMING_ONLY ? "abi=13 arch=gfx950 timing_only=1" : "abi=13 arch=gfx950 timing_only=0";
+}
 
 void msda_reload_knobs(void) { load_knobs(); }
 

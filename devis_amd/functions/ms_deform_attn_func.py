@@ -264,27 +264,49 @@ class _PaddedValueProj(Function):
         return grad_x, grad_w, grad_b, None, None, None, None
 
 
+_BMM_F32_OUT = {}       # device type -> does torch.bmm(16-bit, 16-bit, out_dtype=float32) run there (probed at first use)
+
+
+def _bmm_f32(a, b):
+    """Batched product of 16-bit operands with FLOAT32 results (the GEMM's own fp32 accumulators written out unrounded), or None
+    where this torch build has no such kernel for the device (``aten::bmm.dtype``: GPU backends only)."""
+    kind = a.device.type
+    if _BMM_F32_OUT.get(kind, True):
+        try:
+            out = torch.bmm(a, b, out_dtype=torch.float32)
+            _BMM_F32_OUT[kind] = True
+            return out
+        except (NotImplementedError, RuntimeError, TypeError):
+            _BMM_F32_OUT[kind] = False
+    return None
+
+
 def _split_k_wgrad(g2d, x2d, rows_per_split=1024):
     """``g2d.t() @ x2d`` for a LONG reduction (rows = every pixel of a clip, 28 920 at 360x640 x 6 frames) onto a small
     ``[out, in]`` result: the BLAS library runs that as 32 workgroups of one 32x64 tile each (0.109 ms for 256 x 256 in fp32,
     0.104 in bf16 on MI355X -- the largest single kernel of a decoder-layer step, profiles/r04_logs/module_kernels.txt).
     Cut into slices of ~``rows_per_split`` rows it is one batched product plus a sum over the slices: 0.067 / 0.047 ms
-    (scripts/wgrad_probe.py).  For 16-bit tensors the slices' partial results are summed in float32 and rounded ONCE -- a single
-    GEMM accumulates all rows in fp32, and rounding each of the ~28 partials to 16 bits first cost the weight gradient a
-    digit."""
+    (scripts/wgrad_probe.py).  For 16-bit tensors the partial products are taken in FLOAT32 (``bmm(..., out_dtype=float32)``: the
+    GEMM's accumulators, unrounded), summed in float32 and rounded ONCE, exactly as a single GEMM does.  (Round 5 summed 16-bit
+    partials in fp32, which changed nothing: ``bmm`` had already rounded each of the ~28 partials -- relative RMS error 2.35e-3
+    against 1.66e-3 for the single GEMM)  Where torch has no fp32-output product for the device, the single GEMM is
+    used: slower, never less accurate."""
     R = g2d.shape[0]
     k = R // rows_per_split
     if k < 4 or not g2d.is_contiguous() or not x2d.is_contiguous():
         return g2d.t() @ x2d
     r = R // k
     main = r * k
-    parts = torch.bmm(g2d[:main].view(k, r, -1).transpose(1, 2), x2d[:main].view(k, r, -1))
-    if parts.dtype in (torch.bfloat16, torch.float16):
-        w = parts.sum(0, dtype=torch.float32)
+    a, b = g2d[:main].view(k, r, -1).transpose(1, 2), x2d[:main].view(k, r, -1)
+    if g2d.dtype in (torch.bfloat16, torch.float16):
+        parts = _bmm_f32(a, b)
+        if parts is None:
+            return g2d.t() @ x2d
+        w = parts.sum(0)
         if main < R:
-            w = w + (g2d[main:].t() @ x2d[main:]).float()
+            w = w + torch.mm(g2d[main:].t().float(), x2d[main:].float())       # (< k rows: a sliver)
         return w.to(g2d.dtype)
-    w = parts.sum(0)
+    w = torch.bmm(a, b).sum(0)
     if main < R:
         w.addmm_(g2d[main:].t(), x2d[main:])
     return w

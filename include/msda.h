@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 12
+#define MSDA_ABI_VERSION 13
 #define MSDA_BWD_WORKSPACE_BYTES 64   /* minimum device scratch of the backward entry points (ticket counters) */
 
 enum msda_dtype {
@@ -82,6 +82,12 @@ enum msda_status {
 
 /* ABI version of the loaded library (== MSDA_ABI_VERSION it was built with). */
 int msda_version(void);
+
+/* "abi=13 arch=gfx950 timing_only=0" (ABI v13).  timing_only=1: the library was compiled with timing-only experiment macros
+ * (kernels that skip part of their work to measure floors; wrong results by construction -- such a build needs
+ * -DMSDA_TIMING_ONLY_BUILD to compile at all).  It prefixes every msda_last_route() with "TIMING-ONLY BUILD", its operator entry
+ * points fail with MSDA_ERR_ARG unless MSDA_ENABLE_HOOKS=1, and the bindings refuse to load it without that variable. */
+const char *msda_build_info(void);
 
 /* Thread-local description of the last failure on this thread ("" if none). */
 const char *msda_last_error(void);
@@ -106,8 +112,8 @@ const char *msda_last_route(void);
  *                     window = 0.
  *   msda_pin_route    settings = "name=value name=value ..." with names fwd_rs, fwd_rs_nt, fwd_win, fwd_tile_waves, bwd_rs,
  *                     bwd_rs_tpw, bwd_rs_fsplit, bwd_win (the MSDA_* knobs of the same names, see Conventions) and
- *                     scatter_order (1 = level order, 2 = image order).  An empty string removes the pin.  A knob forced through
- *                     the environment (MSDA_ENABLE_HOOKS=1) wins over a pin.
+ *                     scatter_order (1 = level order, 2 = image order).  An empty string removes the pin.  A knob SET in
+ *                     the environment (MSDA_ENABLE_HOOKS=1) wins over a pin, whatever its value (also its default).
  *   msda_clear_routes removes every pin;  msda_route_count: pins held.
  * devis_amd.tune() measures and pins; devis_amd/routes.json is the table audited on MI355X, loaded with the library.
  */

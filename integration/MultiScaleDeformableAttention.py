@@ -38,6 +38,11 @@ def _library_path():
 
 _lib = ctypes.CDLL(_library_path())
 _vp, _ci = ctypes.c_void_p, ctypes.c_int
+# a library compiled with timing-only experiment kernels (include/msda.h msda_build_info) is never a production library
+_lib.msda_build_info.restype = ctypes.c_char_p
+if b"timing_only=1" in _lib.msda_build_info() and os.environ.get("MSDA_ENABLE_HOOKS") != "1":
+    raise ImportError("MultiScaleDeformableAttention: %s is a TIMING-ONLY build of libmsda_hip.so (wrong results by construction)"
+                      % _library_path())
 _lib.msda_last_error.restype = ctypes.c_char_p
 _lib.msda_forward.restype = _ci
 _lib.msda_forward.argtypes = [_ci] + [_vp] * 5 + [_ci] * 7 + [_vp, _vp, _vp, _vp]

@@ -32,6 +32,52 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert _native.BWD_WORKSPACE_BYTES == int(re.search(r"#define MSDA_BWD_WORKSPACE_BYTES (\d+)", header).group(1))
 
 
+def test_build_info_and_timing_only_guards(tmp_path, monkeypatch):
+    """ABI v13 hygiene: the shipped library is not a timing-only build and says so; the timing-only
+    experiment macros do not compile without -DMSDA_TIMING_ONLY_BUILD; MSDA_LIB is an error without MSDA_ENABLE_HOOKS=1."""
+    import shutil
+    import subprocess
+    from devis_amd import _native, build
+    lib = _native.load()
+    info = lib.msda_build_info().decode()
+    assert "abi=%d" % _native.MSDA_ABI_VERSION in info and "gfx950" in info and "timing_only=0" in info
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if os.path.exists(hipcc):
+        probe = tmp_path / "probe.hip"
+        probe.write_text('#include "msda_common.h"\n')
+        base = [hipcc, "--offload-arch=gfx950", "-E", "-I", os.path.join(ROOT, "include"), "-I", build.CSRC, str(probe), "-o", os.devnull]
+        for macro in ("-DMSDA_RS_EXP=6", "-DMSDA_WIN_EXP=1"):
+            r = subprocess.run(base + [macro], capture_output=True, text=True)
+            assert r.returncode != 0 and "MSDA_TIMING_ONLY_BUILD" in r.stderr, (macro, r.stderr[-400:])
+            r = subprocess.run(base + [macro, "-DMSDA_TIMING_ONLY_BUILD"], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-400:]
+    monkeypatch.setenv("MSDA_LIB", build.LIB)
+    monkeypatch.delenv("MSDA_ENABLE_HOOKS", raising=False)
+    with pytest.raises(RuntimeError, match="MSDA_ENABLE_HOOKS"):
+        build.lib_path()
+    monkeypatch.setenv("MSDA_ENABLE_HOOKS", "1")
+    assert build.lib_path() == build.LIB and build.ensure() == build.LIB
+
+
+def test_routes_file_of_another_architecture_is_skipped(tmp_path, monkeypatch):
+    import json
+    from devis_amd import _native
+    _native.load()
+    before = _native.route_count()
+    key = _native.route_key(False, 0, 3, 6, 5, 4820, 8, 32, 4, 77, 4, 4, [[45, 80], [23, 40], [12, 20], [6, 10]])
+    path = tmp_path / "routes.json"
+    path.write_text(json.dumps({"device": "something else (gfx942)", "routes": {key: {"fwd_rs_nt": 1}}}))
+    monkeypatch.setattr(_native, "_running_arch", lambda: "gfx950")
+    with pytest.warns(UserWarning, match="gfx942"):
+        assert _native.load_routes(str(path)) == 0
+    assert _native.route_count() == before
+    path.write_text(json.dumps({"device": "MI355X (gfx950)", "routes": {key: {"fwd_rs_nt": 1}}}))
+    try:
+        assert _native.load_routes(str(path)) == 1 and _native.route_count() == before + 1
+    finally:
+        _native.pin_route(key, "")
+
+
 def test_abi_argument_errors_without_gpu():
     from devis_amd import _native
     lib = _native.load()
@@ -412,3 +458,28 @@ def test_split_k_weight_gradient_of_value_proj_matches_the_plain_product():
     want = torch.autograd.grad((lin(inp).view(3, 1500, 4, 6) * wgt).sum(), (inp, lin.weight, lin.bias))
     for a, b in zip(got, want):
         torch.testing.assert_close(a, b, rtol=1e-11, atol=1e-11)
+
+
+def test_split_k_weight_gradient_on_16_bit_inputs_is_as_accurate_as_one_gemm():
+    """16-bit partial products must not be rounded before they are summed.  On the CPU torch has no fp32-output bmm,
+    so `_split_k_wgrad` takes the single GEMM (identical error); the fp32-partials branch is checked with a stand-in for
+    `_bmm_f32` (float casts -- what the GPU kernel computes), and on the GPU itself in tests/test_modules_gpu.py."""
+    from devis_amd.functions import ms_deform_attn_func as F
+    gen = torch.Generator().manual_seed(11)
+    R = 28 * 1024 + 200
+    g = torch.randn(R, 32, generator=gen).to(torch.bfloat16)
+    x = torch.randn(R, 16, generator=gen).to(torch.bfloat16)
+    exact = g.double().t() @ x.double()
+    rms = lambda w: float(((w.double() - exact) ** 2).mean().sqrt() / (exact ** 2).mean().sqrt())
+    single = rms(g.t() @ x)
+    assert rms(F._split_k_wgrad(g, x)) <= single * 1.001          # CPU: falls back to the single GEMM
+    old = F._bmm_f32
+    F._bmm_f32 = lambda a, b: torch.bmm(a.float(), b.float())
+    try:
+        split = rms(F._split_k_wgrad(g, x))
+    finally:
+        F._bmm_f32 = old
+    assert split <= single * 1.05, (split, single)
+    rounded = rms((torch.bmm(g[:28 * 1024].view(28, 1024, -1).transpose(1, 2), x[:28 * 1024].view(28, 1024, -1)).sum(0, dtype=torch.float32)
+                   + (g[28 * 1024:].t() @ x[28 * 1024:]).float()).to(torch.bfloat16))
+    assert rounded > single * 1.2                                   # what round 5 shipped: measurably worse

@@ -439,3 +439,19 @@ def test_value_proj_gradients_at_clip_size_through_the_split_k_product(dtype, to
     for got, ref in zip((gx.reshape(-1, C), gw, gb), want):
         err = float((got.double().cpu() - ref).abs().max())
         assert err <= tol * max(1.0, float(ref.abs().max())), (err, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_split_k_weight_gradient_on_16_bit_inputs_is_as_accurate_as_one_gemm_on_the_gpu(dtype):
+    """the split-K weight gradient takes its partial products in float32 (`bmm(..., out_dtype=float32)`) and rounds
+    once -- its error against the fp64 product of the same rounded inputs is the single GEMM's, not that of ~28 rounded partials."""
+    from devis_amd.functions import ms_deform_attn_func as F
+    gen = torch.Generator().manual_seed(23)
+    R = 28920
+    g = torch.randn(R, 256, generator=gen).to("cuda:0", dtype)
+    x = torch.randn(R, 256, generator=gen).to("cuda:0", dtype)
+    exact = g.double().t() @ x.double()
+    rms = lambda w: float(((w.double() - exact) ** 2).mean().sqrt() / (exact ** 2).mean().sqrt())
+    single, split = rms(g.t() @ x), rms(F._split_k_wgrad(g, x))
+    assert F._split_k_wgrad(g, x).dtype == dtype
+    assert split <= single * 1.05, (split, single, F._BMM_F32_OUT)
