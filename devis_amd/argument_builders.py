@@ -49,7 +49,8 @@ def get_reference_points(spatial_shapes, valid_ratios, device):
     capturing = torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()
     grids = _grid_cache.get(key)
     if grids is not None and capturing:
-        _captured.setdefault(key, grids)        # a HIP graph now holds these addresses: out of the cache's reach for good
+        _captured[id(grids)] = grids            # a HIP graph now holds these addresses: out of the cache's reach for good (keyed by
+                                                # the grid set itself: after an eviction one key may have had several live sets)
     if grids is None:
         grids = []
         for H_, W_ in shapes:

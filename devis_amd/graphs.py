@@ -50,9 +50,11 @@ def graph_stream(device=None):
     if side is None:
         side = _graph_streams[device] = torch.cuda.Stream(device)
     side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        yield side
-    cur.wait_stream(side)
+    try:
+        with torch.cuda.stream(side):
+            yield side
+    finally:
+        cur.wait_stream(side)       # also when the body raised: what it queued on the side stream stays ordered before the caller's next work
 
 
 def _is_flowing(x):

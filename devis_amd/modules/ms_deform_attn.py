@@ -267,7 +267,8 @@ class _FrameTables:
         return len(held) == len(offsets) and all(a is b and a._version == v for (a, v), b in zip(held, offsets))
 
     def get(self, temporal_offsets, n_frames, device):
-        self.raise_on_bad_offsets()
+        if not (torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            self.raise_on_bad_offsets()     # (polls events and may raise: not inside a HIP-graph capture, like _flush_offset_checks)
         with self._lock:
             for i, (held, nf, dev, table) in enumerate(self._entries):
                 if nf == n_frames and dev == device and self._same(held, temporal_offsets):
