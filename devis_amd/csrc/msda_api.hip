@@ -65,6 +65,8 @@ struct Knobs {
     int bwd_summary = 1;                // 64-query block summaries for long candidate ranges
     int scatter_lds_kb = 144, scatter_dbg = 0;
     int scatter_own = -1;               // owner-computes scatter: -1 auto, 0 off (the LDS-atomic scatter instead)
+    int scatter_mfma = -1;              // matrix-pipe scatter of the coarse levels (msda_mfma.hip): -1 auto, 0 off, 1 wherever it applies
+    int scatter_own_levels = -1;        // measurement: the owner-computes scatter handles only the first n levels (grad_value of the others is NOT computed)
     int force_generic = 0;
     int gv_storage = 1;                 // 0: msda_grad_value_dtype always answers the arithmetic type (A/B measurements)
     int dbg = 0;
@@ -73,7 +75,7 @@ struct Knobs {
                                         // forced to its default (MSDA_FWD_RS=-1 for a rules-only A/B run) still wins over a pin
 };
 enum : unsigned { kForceFwdRs = 1, kForceFwdRsNt = 2, kForceFwdWin = 4, kForceFwdTileWaves = 8, kForceBwdRs = 16, kForceBwdRsTpw = 32,
-                  kForceBwdRsFsplit = 64, kForceBwdWin = 128, kForceScatterDbg = 256 };
+                  kForceBwdRsFsplit = 64, kForceBwdWin = 128, kForceScatterDbg = 256, kForceScatterMfma = 512 };
 Knobs g_knobs;
 int g_knobs_loaded = 0;
 
@@ -98,7 +100,7 @@ void load_knobs()
                    (env_set("MSDA_FWD_WIN") ? kForceFwdWin : 0u) | (env_set("MSDA_FWD_TILE_WAVES") ? kForceFwdTileWaves : 0u) |
                    (env_set("MSDA_BWD_RS") ? kForceBwdRs : 0u) | (env_set("MSDA_BWD_RS_TPW") ? kForceBwdRsTpw : 0u) |
                    (env_set("MSDA_BWD_RS_FSPLIT") ? kForceBwdRsFsplit : 0u) | (env_set("MSDA_BWD_WIN") ? kForceBwdWin : 0u) |
-                   (env_set("MSDA_SCATTER_DBG") ? kForceScatterDbg : 0u);
+                   (env_set("MSDA_SCATTER_DBG") ? kForceScatterDbg : 0u) | (env_set("MSDA_SCATTER_MFMA") ? kForceScatterMfma : 0u);
         k.fwd_rs = env_int("MSDA_FWD_RS", k.fwd_rs); k.fwd_rs_nt = env_int("MSDA_FWD_RS_NT", k.fwd_rs_nt);
         k.bwd_rs = env_int("MSDA_BWD_RS", k.bwd_rs); k.bwd_rs_tpw = env_int("MSDA_BWD_RS_TPW", k.bwd_rs_tpw);
         k.bwd_rs_fsplit = env_int("MSDA_BWD_RS_FSPLIT", k.bwd_rs_fsplit);
@@ -114,6 +116,8 @@ void load_knobs()
         k.scatter_lds_kb = env_int("MSDA_SCATTER_LDS_KB", k.scatter_lds_kb);
         k.scatter_dbg = env_int("MSDA_SCATTER_DBG", k.scatter_dbg);
         k.scatter_own = env_int("MSDA_SCATTER_OWN", k.scatter_own);
+        k.scatter_own_levels = env_int("MSDA_SCATTER_OWN_LEVELS", k.scatter_own_levels);
+        k.scatter_mfma = env_int("MSDA_SCATTER_MFMA", k.scatter_mfma);
         k.force_generic = env_int("MSDA_FORCE_GENERIC", 0) == 1;
         k.gv_storage = env_int("MSDA_GV_STORAGE", k.gv_storage);
         k.dbg = env_int("MSDA_DBG", 0);
@@ -143,7 +147,7 @@ inline const Knobs &knobs()
 struct RoutePin {
     std::string key;
     int fwd_rs = -2, fwd_rs_nt = -2, fwd_win = -2, fwd_tile_waves = -2;        // -2 = not pinned
-    int bwd_rs = -2, bwd_rs_tpw = -2, bwd_rs_fsplit = -2, bwd_win = -2, scatter_order = -2;
+    int bwd_rs = -2, bwd_rs_tpw = -2, bwd_rs_fsplit = -2, bwd_win = -2, scatter_order = -2, scatter_mfma = -2;
 };
 std::mutex g_routes_mutex;
 std::vector<RoutePin> g_routes;
@@ -176,7 +180,7 @@ bool parse_route_settings(const char *text, RoutePin &pin)
         else if (name == "fwd_win") pin.fwd_win = v; else if (name == "fwd_tile_waves") pin.fwd_tile_waves = v;
         else if (name == "bwd_rs") pin.bwd_rs = v; else if (name == "bwd_rs_tpw") pin.bwd_rs_tpw = v;
         else if (name == "bwd_rs_fsplit") pin.bwd_rs_fsplit = v; else if (name == "bwd_win") pin.bwd_win = v;
-        else if (name == "scatter_order") pin.scatter_order = v;
+        else if (name == "scatter_order") pin.scatter_order = v; else if (name == "scatter_mfma") pin.scatter_mfma = v;
         else return false;
         i = end;
     }
@@ -207,6 +211,7 @@ struct RouteScope {
         lay(merged.fwd_win, kForceFwdWin, pin.fwd_win); lay(merged.fwd_tile_waves, kForceFwdTileWaves, pin.fwd_tile_waves);
         lay(merged.bwd_rs, kForceBwdRs, pin.bwd_rs); lay(merged.bwd_rs_tpw, kForceBwdRsTpw, pin.bwd_rs_tpw);
         lay(merged.bwd_rs_fsplit, kForceBwdRsFsplit, pin.bwd_rs_fsplit); lay(merged.bwd_win, kForceBwdWin, pin.bwd_win);
+        lay(merged.scatter_mfma, kForceScatterMfma, pin.scatter_mfma);
         if (pin.scatter_order == 1 && !(forced & kForceScatterDbg)) merged.scatter_dbg |= 256;
         if (pin.scatter_order == 2 && !(forced & kForceScatterDbg)) merged.scatter_dbg |= 2048;
         tl_route_knobs = &merged;
@@ -658,7 +663,30 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             rc = launch_zero_unowned(p, kOwnPix * p.D, p.gv_storage ? 2 : 4, stream);
             if (rc) return rc;
         }
-        return launch_scatter_grp(dtype, p.gv_storage != 0, p, grid * (1024 / kOwnThreads), (knobs().scatter_dbg & (511 | 2048)) | (fused_zero ? 512 : 0), stream);
+        Params pg = p;
+        if (knobs().scatter_own_levels >= 0 && knobs().scatter_own_levels < p.L) pg.own_levels = knobs().scatter_own_levels;     // (measurement only: wrong results)
+        // The coarse levels -- the last one or two of the pyramid, together at most ~300 pixels -- on the matrix pipe (msda_mfma.hip):
+        // the owner-computes kernel then runs on levels [0, l0).  Needs the host copy of the shapes (a true copy: include/msda.h)
+        // and at least 16 queries (a step is 16 groups).  Automatic for decoder-shaped batches: an item walks (1 + sources) x Lq
+        // groups in 8 waves, so a handful of items of encoder length would be the kernel's whole duration.
+        int l0 = p.L, tiles = 0;
+        if (knobs().scatter_mfma != 0 && p.shapes_host && p.Lq >= 16 && p.L >= 2 && pg.own_levels == p.L) {
+            long long px = 0;
+            for (int l = p.L - 1; l >= 1 && l >= p.L - 2; --l) {
+                const long long hw = p.shapes_host[2 * l] * p.shapes_host[2 * l + 1];
+                if (p.shapes_host[2 * l] <= 0 || p.shapes_host[2 * l + 1] <= 0 || !mfma_scatter_tiles(px + hw)) break;
+                px += hw; l0 = l; tiles = mfma_scatter_tiles(px);
+            }
+            const long long items = (long long)p.groups * p.M, per_item = (long long)p.Lq * (1 + p.window);
+            // (measured, 16 clips of 300 queries, T = 6: the two coarse levels of the 360x640 pyramid cost the owner kernel 0.19 ms
+            // and this one 0.12; the single 273-pixel level of the 800x1333 pyramid 0.105 against 0.07; the 96-pixel last level
+            // of the SwinL pyramid 0.07 against 0.06 -- not worth a launch; one clip = 48 items on 48 CUs: 0.053 -> 0.088 ms)
+            if (tiles && knobs().scatter_mfma < 0 && !(per_item <= 8192 && items >= 128 && (p.L - l0 == 2 || px >= 200))) { l0 = p.L; tiles = 0; }
+        }
+        if (l0 < p.L) pg.own_levels = l0;
+        rc = launch_scatter_grp(dtype, p.gv_storage != 0, pg, grid * (1024 / kOwnThreads), (knobs().scatter_dbg & (511 | 2048 | 4096)) | (fused_zero ? 512 : 0), stream);
+        if (rc || !tiles) return rc;
+        return launch_scatter_mfma(dtype, p.gv_storage != 0, p, l0, tiles, stream);
     }
     if (p.gv_storage) return fail(MSDA_ERR_ARG, "msda backward: this call needs grad_value in the arithmetic type (see msda_grad_value_dtype)%s");
     // LDS-atomic scatter: 144 KiB of 8-byte accumulators per workgroup
@@ -698,6 +726,7 @@ int run(int dtype, const Params &p_in, bool bwd, hipStream_t stream)
         return fail(MSDA_ERR_ARG, "msda: this library is a TIMING-ONLY build (kernels that skip work: wrong results); it runs only "
                                   "with MSDA_ENABLE_HOOKS=1%s");
     Params p = p_in;
+    p.own_levels = p.L;
     const RouteScope pinned(bwd, dtype, p);     // (the pinned settings of this call shape, if any, are what knobs() answers below)
     p.dbg = knobs().dbg;
     // culling records per point (4 x int16) when the owner-computes scatter will read them; (min, max) intervals for the

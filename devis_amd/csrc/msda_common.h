@@ -268,6 +268,8 @@ struct Params {
     int wide_loads;             // loc / attn arrays are 16-byte aligned (resident-slab kernels: whole-row loads)
     int dbg;                    // measurement hooks (MSDA_DBG env), 0 in production
     int gv_storage;             // bwd: grad_value is in the STORAGE type (16-bit), not the arithmetic type (owner-computes scatter only)
+    int own_levels;             // bwd: the owner-computes scatter handles levels [0, own_levels); the trailing (coarse) levels are
+                                // the matrix-pipe scatter's (msda_mfma.hip).  = L when that kernel does not run
 };
 
 struct Level { int H, W, start, pad; };   // start = first pixel of the level inside the CLIP slab
@@ -517,6 +519,9 @@ int launch_zero_unowned(const Params &p, int cap_slots, int grad_value_elem_byte
 int launch_cull_summary(const Params &p, hipStream_t stream);
 int launch_scatter_lds(int dtype, int G, const Params &p, unsigned grid, int cap_bytes, int dbg, hipStream_t stream);
 int launch_scatter_grp(int dtype, bool storage_typed_grad_value, const Params &p, unsigned grid, int dbg, hipStream_t stream);
+// msda_mfma.hip: grad_value of the trailing levels [l0, L) (at most 2, `tiles` = mfma_scatter_tiles(their pixels)) on the matrix pipe
+int mfma_scatter_tiles(long long pixels);
+int launch_scatter_mfma(int dtype, bool storage_typed_grad_value, const Params &p, int l0, int tiles, hipStream_t stream);
 // msda_generic.hip: any-shape kernels, the modules' fused pre-op pass, the padding-mask pass
 int launch_generic(int dtype, const Params &p, bool bwd, hipStream_t stream);
 int launch_prep(int dtype, const PrepParams &p, bool bwd, hipStream_t stream);

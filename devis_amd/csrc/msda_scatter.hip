@@ -523,7 +523,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             const int R = min(H, kOwnPix / max(1, W));          // rows per band; 0 = "direct" level (row wider than a band)
             s_H[l] = H; s_W[l] = W; s_R[l] = R; s_lsi[l] = (int)p.lsi[l];
             s_first[l] = first;
-            first += (R > 0) ? (H + R - 1) / R : 1;
+            first += l >= p.own_levels ? 0 : (R > 0) ? (H + R - 1) / R : 1;       // (levels from own_levels on: no items here, msda_mfma.hip)
         }
         s_first[L] = first;
         s_cnt[0] = s_cnt[1] = s_cnt[2] = 0;
@@ -636,11 +636,16 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                 f = (int)(rest % F);
                 if (!clip_major) clip = (int)(rest / F);
             } else {
+                // static stride: the bands of one (clip, frame) adjacent, ROTATED by the (clip, frame) index -- a workgroup walks
+                // (item / M) in steps of gridDim / M (64), so with a band count that shares a factor with it (24 bands: every third
+                // band only) it saw the same few bands of every frame, all heavy or all light (round 6: the 800x1333 pyramid without
+                // its last level 0.51 -> 0.67 ms); the rotation walks all of them (MSDA_SCATTER_DBG = 4096: without it)
                 m = (int)(item % M);
                 unsigned rest = item / M;
-                part = (int)(rest % (unsigned)NB); rest /= (unsigned)NB;
-                f = (int)(rest % F);
-                clip = (int)(rest / F);
+                const unsigned fc = rest / (unsigned)NB;
+                part = (int)((rest + ((dbg & 4096) ? 0u : fc)) % (unsigned)NB);
+                f = (int)(fc % F);
+                clip = (int)(fc / F);
                 while (l + 1 < L && s_first[l + 1] <= part) ++l;
             }
         }
@@ -1169,7 +1174,7 @@ int launch_scatter_grp(int dtype, bool storage_typed, const Params &p, unsigned 
         // (a pinned route, msda_pin_route scatter_order: 1 = level order (bit 256), 2 = image order wherever the bands can be sorted (bit 2048))
         bool sorted = ((p.Lq >= 8192 && p.frames > 1) || (dbg & 2048)) && p.shapes_host != nullptr && (dbg & 256) == 0;
         int bands = 0;
-        for (int l = 0; sorted && l < p.L; ++l) {
+        for (int l = 0; sorted && l < p.own_levels; ++l) {
             const long long H = p.shapes_host[2 * l], W = p.shapes_host[2 * l + 1];
             if (H <= 0 || W <= 0) { sorted = false; break; }         // (degenerate level: the device counts its bands differently)
             const long long R = W > 0 ? std::min<long long>(H, kOwnPix / W) : 0;

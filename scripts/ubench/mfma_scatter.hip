@@ -38,42 +38,54 @@ struct Args {
     float *gv;
     const int *ftab;                 // [T][W]
     int clips, T, M, Lq, L, P, W, S;
-    int H, Wd, lvl, lsi;             // the level this launch handles
+    int l0, nl;                      // the trailing levels [l0, l0 + nl) this launch handles (nl <= 2), fused in one pixel space
+    int H[2], Wd[2], poff[2], npix, lsi;
 };
 
-__device__ __forceinline__ float dppf(float v, int) { return v; }
-template <int CTRL> __device__ __forceinline__ float quad(float v)
+template <int CTRL> __device__ __forceinline__ float quad(float v)       // quad_perm broadcast of one lane of each quad
 {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float tent(float d)      // max(0, 1 - |d|)
+__device__ __forceinline__ float tent(float d)      // max(0, 1 - |d|): one v_sub with |src| and clamp
 {
     return __builtin_amdgcn_fmed3f(1.f - __builtin_fabsf(d), 0.f, 1.f);
 }
+__device__ __forceinline__ unsigned lds_off(const void *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p; }
 
-template <int MT, int NPROD>
-__global__ void __launch_bounds__(256, MT == 8 ? 2 : 4)
+// LDS image of one A tile (hi or lo): [2 k-chunks][NP pixel rows][8 k] bf16 -- cell (pix, k) at ((k >> 3) * NP + pix) * 16 +
+// (k & 7) * 2.  The MFMA A operand of 32-pixel tile t (lane = pixel 32 t + (lane & 31), k-chunk lane >> 5) is one ds_read_b128 at
+// ((lane >> 5) * NP + 32 t + (lane & 31)) * 16: the 16 lanes of a ds_read_b128 group read 16 consecutive 16-byte slots (no
+// swizzle needed), and a point's four cells are cell00 + {0, 16, W * 16, W * 16 + 16}.
+template <int MT, int NL, int NPROD>
+__global__ void __launch_bounds__(256, MT >= 8 ? 2 : 4)
 mfma_scatter_kernel(const Args p)
 {
-    constexpr int D = 32, kTile = MT * 32 * 32 + 64;            // bytes of one A tile (hi or lo) + a trash row for masked-out cells
-    constexpr int kHalf = MT == 8 ? 4 : MT, kRed = 4 * kHalf * 4096;          // reduction buffer: 4 waves x kHalf tiles x 4 KiB
-    constexpr int kLds = (4 * 2 * kTile > kRed) ? 4 * 2 * kTile : kRed;
+    constexpr int D = 32;
+    constexpr int NP = MT == 10 ? 304 : MT * 32 + 16;           // pixel rows per k-chunk: npix + 1 (trash row) <= NP
+    constexpr int kTile = 2 * NP * 16;                          // bytes of one A tile (hi or lo)
+    constexpr int kPhase = MT >= 8 ? 4 : MT;                    // tiles per reduction phase: 4 waves x kPhase x 4 KiB
     extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
-    __shared__ int s_src[64], s_nsrc;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char *Ahi = lds + wave * (2 * kTile), *Alo = Ahi + kTile;
-    for (int i = tid * 16; i < kLds; i += 256 * 16) *reinterpret_cast<u32x4 *>(lds + i) = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid * 16; i < 4 * 2 * kTile + 256; i += 256 * 16) *reinterpret_cast<u32x4 *>(lds + i) = u32x4{0u, 0u, 0u, 0u};
 
     const int m = blockIdx.x % p.M, f = (blockIdx.x / p.M) % p.T, clip = blockIdx.x / (p.M * p.T);
-    const int MD = p.M * D, l = p.lvl, H = p.H, Wd = p.Wd, npix = H * Wd;
-    if (wave == 0) {      // sources reading frame f: -1 = its own current-frame points, else t * W + w with ftab[t][w] == f
+    const int MD = p.M * D, npix = p.npix;
+    // sources reading frame f: lane s of every wave holds source s (-1 = the frame's own current-frame points, else t * W + w
+    // with ftab[t][w] == f); a step reads its source with a readlane
+    int my_src = -1, nsrc = 1;
+    {
         const bool hit = lane < p.T * p.W && p.ftab[lane] == f;
         const unsigned long long bal = __ballot(hit);
-        if (lane == 0) { s_src[0] = -1; s_nsrc = 1 + __popcll(bal); }
-        if (hit) s_src[1 + __popcll(bal & ((1ull << lane) - 1ull))] = lane;
+        nsrc = 1 + __popcll(bal);
+        // lane s >= 1 wants the position of the s-th set bit of bal
+        int pos = -1, cnt = 0;
+        for (int b = 0; b < 64; ++b)
+            if ((bal >> b) & 1ull) { ++cnt; if (cnt == lane) pos = b; }
+        if (lane >= 1) my_src = pos;
     }
-    __syncthreads();
-    const int nsrc = s_nsrc, nst = (p.Lq + 15) / 16;
+    const int nst = (p.Lq + 15) / 16, nsteps = nsrc * nst;
+    __syncthreads();                                      // the tiles are zero before any wave writes a cell
 
     f32x16 acc[MT];
 #pragma unroll
@@ -82,88 +94,111 @@ mfma_scatter_kernel(const Args p)
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const int g = lane >> 2, pt = lane & 3;               // builder role: point pt of group g of the step
-    const int n = lane & 31, kh = lane >> 5;              // MFMA role: channel n / pixel n of a tile, k half kh
-    // A-operand read address of tile 0: pixel n, 16-byte chunk kh ^ bit 4 of the pixel
-    const unsigned rd0 = (unsigned)n * 32u + (unsigned)((kh ^ ((n >> 4) & 1)) << 4);
-    const float Hf = (float)H, Wf = (float)Wd;
+    const int n = lane & 31, kh = lane >> 5;              // MFMA role: channel n / pixel n of a tile, k-chunk kh
+    const unsigned wr_hi = lds_off(Ahi) + (unsigned)((g >> 3) * NP) * 16u + (unsigned)(g & 7) * 2u;      // + pix * 16
+    const unsigned trash = (unsigned)npix * 16u;          // row npix of the tile: written, never stored
+    // lane parts of the point index: current-frame points [.., M, L, P], temporal points [.., M, W * L, P]
+    const int lane_c = (g * p.M * p.L) * p.P + pt, lane_t = (g * p.M * p.W * p.L) * p.P + pt;
+    const int lane_g = (8 * kh * MD + n);                 // lane part of a G element: row 8 kh (+ j), channel n
 
-    // the loads of a step: this thread's point (x, y, attention) and its 8 rows x 1 channel of G; issued one step AHEAD.  Every
-    // load is UNCONDITIONAL (indices clamped into the source's rows; what lies beyond is masked where it is used): with loads
-    // inside branches the compiler cannot count them and waits for vmcnt(0) right behind the issue -- no prefetch at all
-    const int nsteps = nsrc * nst;
-    auto issue = [&](int st_, float &x, float &y, float &a, float (&gr)[8]) {
+    struct Step { const float *loc, *aw, *go; int gmin, temporal; };
+    // scalar description of step st (clamped): the source's point and row bases at the step's first query
+    auto describe = [&](int st_) -> Step {
         const int st = min(st_, nsteps - 1);
-        const int s = st / nst, q0 = (st - s * nst) * 16;
-        const int src = __builtin_amdgcn_readfirstlane(s_src[s]);
+        const int s = st / nst, j = st - s * nst;
+        const int q0 = min(16 * j, p.Lq - 16);                                      // the last step of a source overlaps the one before
+        const int src = __builtin_amdgcn_readlane(my_src, s);
         const int t_src = src < 0 ? f : src / p.W, w_src = src < 0 ? 0 : src - (src / p.W) * p.W;
-        const long long grow = ((long long)clip * p.T + t_src) * p.Lq;          // first query row of the source frame
-        const int q = min(q0 + g, p.Lq - 1);
-        const float *loc = src < 0 ? p.loc_c : p.loc_t;
-        const float *aw = src < 0 ? p.aw_c : p.aw_t;
+        const long long row = ((long long)clip * p.T + t_src) * p.Lq + q0;          // first query row of the step
+        Step d;
         const long long lv = src < 0 ? (long long)p.L : (long long)p.W * p.L;
-        const long long idx = (((grow + q) * p.M + m) * lv + (src < 0 ? l : w_src * p.L + l)) * p.P + pt;
-        const float2 xy = *reinterpret_cast<const float2 *>(loc + 2 * idx);
-        x = xy.x; y = xy.y; a = aw[idx];
-        const float *gp = p.go + (grow + q0 + 8 * kh) * MD + m * D + n;
-        const int left = p.Lq - 1 - (q0 + 8 * kh);                               // last valid j (may be negative: clamp to row 0 of the half)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) gr[j] = gp[(long long)max(min(j, left), -8 * kh) * MD];
+        const long long sbase = ((row * p.M + m) * lv + (src < 0 ? p.l0 : w_src * p.L + p.l0)) * p.P;
+        d.loc = (src < 0 ? p.loc_c : p.loc_t) + 2 * sbase;
+        d.aw = (src < 0 ? p.aw_c : p.aw_t) + sbase;
+        d.go = p.go + row * MD + m * D;
+        d.gmin = 16 * j - q0;
+        d.temporal = src < 0 ? 0 : 1;
+        return d;
     };
-    float nx, ny, na, ngr[8];
-    issue(wave, nx, ny, na, ngr);
-    for (int st = wave; st < nsteps; st += 4) {
-        float x = nx, y = ny, a = na, gr[8];
-        const int q0s = (st - (st / nst) * nst) * 16;
-        const bool act = q0s + g < p.Lq;
+    // the loads of a step, issued one step AHEAD, all unconditional (the compiler must be able to count them: s_waitcnt vmcnt(N))
+    auto issue = [&](const Step &d, float (&x)[NL], float (&y)[NL], float (&a)[NL], float (&gr)[8]) {
+        const int lo = d.temporal ? lane_t : lane_c;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) gr[j] = (q0s + 8 * kh + j < p.Lq) ? ngr[j] : 0.f;
-        issue(st + 4, nx, ny, na, ngr);
-        // ---- geometry (reference arithmetic: rounded product, then the subtraction; cuh:288 range test)
-        float h_im = y * Hf - 0.5f, w_im = x * Wf - 0.5f;
-        const bool inr = act && h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
-        if (!inr) { h_im = -100.f; w_im = -100.f; a = 0.f; }
-        const float r0f = floorf(h_im), c0f = floorf(w_im), r1f = r0f + 1.f, c1f = c0f + 1.f;
-        const int hl = (int)r0f, wl = (int)c0f;
-        // ---- merge: totals of all four points of the quad at my four corner pixels, in point order
-        float t00 = 0.f, t01 = 0.f, t10 = 0.f, t11 = 0.f;
+        for (int li = 0; li < NL; ++li) {
+            const float2 xy = *reinterpret_cast<const float2 *>(d.loc + 2 * (lo + li * p.P));
+            x[li] = xy.x; y[li] = xy.y; a[li] = d.aw[lo + li * p.P];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gr[j] = (d.go + (long long)j * MD)[lane_g];
+    };
+    float nx[NL], ny[NL], na[NL], ngr[8];
+    Step cur = describe(wave);
+    issue(cur, nx, ny, na, ngr);
+    for (int st = wave; st < nsteps; st += 4) {
+        float xs[NL], ys[NL], as[NL], gr[8];
+        const bool act = g >= cur.gmin;
+#pragma unroll
+        for (int li = 0; li < NL; ++li) { xs[li] = nx[li]; ys[li] = ny[li]; as[li] = na[li]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gr[j] = ngr[j];
+        cur = describe(st + 4);
+        issue(cur, nx, ny, na, ngr);
+        unsigned cells[NL][4];
+#pragma unroll
+        for (int li = 0; li < NL; ++li) {
+            const int H = p.H[li], Wd = p.Wd[li];
+            const float Hf = (float)H, Wf = (float)Wd;
+            float a = as[li];
+            // ---- geometry (reference arithmetic: rounded product, then the subtraction; cuh:288 range test)
+            float h_im = ys[li] * Hf - 0.5f, w_im = xs[li] * Wf - 0.5f;
+            const bool inr = act && h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
+            if (!inr) { h_im = -100.f; w_im = -100.f; a = 0.f; }
+            const float r0f = floorf(h_im), c0f = floorf(w_im), r1f = r0f + 1.f, c1f = c0f + 1.f;
+            const int hl = (int)r0f, wl = (int)c0f;
+            // ---- merge: totals of all four points of the quad at my four corner pixels, in point order
+            float t00 = 0.f, t01 = 0.f, t10 = 0.f, t11 = 0.f;
 #define MERGE(CTRL) { \
-            const float hj = quad<CTRL>(h_im), wj = quad<CTRL>(w_im), aj = quad<CTRL>(a); \
-            const float th0 = tent(hj - r0f) * aj, th1 = tent(hj - r1f) * aj, tw0 = tent(wj - c0f), tw1 = tent(wj - c1f); \
-            t00 = fmaf(th0, tw0, t00); t01 = fmaf(th0, tw1, t01); t10 = fmaf(th1, tw0, t10); t11 = fmaf(th1, tw1, t11); }
-        MERGE(0x00) MERGE(0x55) MERGE(0xaa) MERGE(0xff)
+                const float th0 = tent(quad<CTRL>(h_im) - r0f) * quad<CTRL>(a), th1 = tent(quad<CTRL>(h_im) - r1f) * quad<CTRL>(a); \
+                const float tw0 = tent(quad<CTRL>(w_im) - c0f), tw1 = tent(quad<CTRL>(w_im) - c1f); \
+                t00 = fmaf(th0, tw0, t00); t01 = fmaf(th0, tw1, t01); t10 = fmaf(th1, tw0, t10); t11 = fmaf(th1, tw1, t11); }
+            MERGE(0x00) MERGE(0x55) MERGE(0xaa) MERGE(0xff)
 #undef MERGE
-        // ---- cells: (pixel, k = g) of the hi and lo tiles; masked-out corners go to the trash row
-        const bool rv0 = inr && (unsigned)hl < (unsigned)H, rv1 = inr && (unsigned)(hl + 1) < (unsigned)H;
-        const bool cv0 = (unsigned)wl < (unsigned)Wd, cv1 = (unsigned)(wl + 1) < (unsigned)Wd;
-        const int pix00 = hl * Wd + wl;
-        auto cell = [&](int pix, bool ok) -> unsigned {
-            return ok ? (unsigned)pix * 32u + (unsigned)((((g >> 3) ^ ((pix >> 4) & 1)) << 4) + (g & 7) * 2) : (unsigned)(MT * 32 * 32) + (unsigned)lane % 32u * 2u;
-        };
-        const unsigned c00 = cell(pix00, rv0 && cv0), c01 = cell(pix00 + 1, rv0 && cv1),
-                       c10 = cell(pix00 + Wd, rv1 && cv0), c11 = cell(pix00 + Wd + 1, rv1 && cv1);
-        auto put = [&](unsigned c, float v) {
-            const __bf16 hi = (__bf16)v;
-            const __bf16 lo = (__bf16)(v - (float)hi);
-            *reinterpret_cast<__bf16 *>(Ahi + c) = hi;
-            *reinterpret_cast<__bf16 *>(Alo + c) = lo;
-        };
-        put(c00, t00); put(c01, t01); put(c10, t10); put(c11, t11);
+            // ---- cells; masked-out corners go to the trash row
+            const bool rv0 = inr && (unsigned)hl < (unsigned)H, rv1 = inr && (unsigned)(hl + 1) < (unsigned)H;
+            const bool cv0 = (unsigned)wl < (unsigned)Wd, cv1 = (unsigned)(wl + 1) < (unsigned)Wd;
+            const unsigned c00 = (unsigned)(p.poff[li] + hl * Wd + wl) * 16u, wrow = (unsigned)Wd * 16u;
+            cells[li][0] = wr_hi + ((rv0 && cv0) ? c00 : trash); cells[li][1] = wr_hi + ((rv0 && cv1) ? c00 + 16u : trash);
+            cells[li][2] = wr_hi + ((rv1 && cv0) ? c00 + wrow : trash); cells[li][3] = wr_hi + ((rv1 && cv1) ? c00 + wrow + 16u : trash);
+            // hi = bf16(t) (round to nearest even), lo = bf16(t - hi); two cells per conversion
+            const float tt[4] = {t00, t01, t10, t11};
+#pragma unroll
+            for (int c = 0; c < 4; c += 2) {
+                const bf16x2 hi = {(__bf16)tt[c], (__bf16)tt[c + 1]};
+                const unsigned hb = __builtin_bit_cast(unsigned, hi);
+                const bf16x2 lo = {(__bf16)(tt[c] - __uint_as_float(hb << 16)), (__bf16)(tt[c + 1] - __uint_as_float(hb & 0xffff0000u))};
+                const unsigned lb = __builtin_bit_cast(unsigned, lo);
+                asm volatile("ds_write_b16 %0, %1" : : "v"(cells[li][c]), "v"(hb) : "memory");
+                asm volatile("ds_write_b16_d16_hi %0, %1" : : "v"(cells[li][c + 1]), "v"(hb) : "memory");
+                asm volatile("ds_write_b16 %0, %1 offset:%2" : : "v"(cells[li][c]), "v"(lb), "n"(kTile) : "memory");
+                asm volatile("ds_write_b16_d16_hi %0, %1 offset:%2" : : "v"(cells[li][c + 1]), "v"(lb), "n"(kTile) : "memory");
+            }
+        }
         // ---- B operand: G[k = 8 kh + j][n], hi + lo
         bf16x8 bhi, blo;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const __bf16 hi = (__bf16)gr[j];
-            bhi[j] = hi;
-            blo[j] = (__bf16)(gr[j] - (float)hi);
+        for (int j = 0; j < 8; j += 2) {
+            const bf16x2 hi = {(__bf16)gr[j], (__bf16)gr[j + 1]};
+            const unsigned hb = __builtin_bit_cast(unsigned, hi);
+            bhi[j] = hi[0]; bhi[j + 1] = hi[1];
+            blo[j] = (__bf16)(gr[j] - __uint_as_float(hb << 16));
+            blo[j + 1] = (__bf16)(gr[j + 1] - __uint_as_float(hb & 0xffff0000u));
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- the products, tile by tile
+        // ---- the products, tile by tile (LDS operations of one wave complete in order: the reads see the writes above)
         bf16x8 ahi[MT], alo[MT];
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            ahi[t] = *reinterpret_cast<const bf16x8 *>(Ahi + rd0 + t * 1024);
-            alo[t] = *reinterpret_cast<const bf16x8 *>(Alo + rd0 + t * 1024);
+            ahi[t] = *reinterpret_cast<const bf16x8 *>(Ahi + (kh * NP + n) * 16 + t * 512);
+            alo[t] = *reinterpret_cast<const bf16x8 *>(Alo + (kh * NP + n) * 16 + t * 512);
         }
 #pragma unroll
         for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[t], bhi, acc[t], 0, 0, 0);
@@ -175,34 +210,37 @@ mfma_scatter_kernel(const Args p)
 #pragma unroll
             for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[t], blo, acc[t], 0, 0, 0);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
         // ---- cells back to zero
-        const __bf16 z = (__bf16)0.f;
-        *reinterpret_cast<__bf16 *>(Ahi + c00) = z; *reinterpret_cast<__bf16 *>(Alo + c00) = z;
-        *reinterpret_cast<__bf16 *>(Ahi + c01) = z; *reinterpret_cast<__bf16 *>(Alo + c01) = z;
-        *reinterpret_cast<__bf16 *>(Ahi + c10) = z; *reinterpret_cast<__bf16 *>(Alo + c10) = z;
-        *reinterpret_cast<__bf16 *>(Ahi + c11) = z; *reinterpret_cast<__bf16 *>(Alo + c11) = z;
+        const unsigned zero = 0u;
+#pragma unroll
+        for (int li = 0; li < NL; ++li)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                asm volatile("ds_write_b16 %0, %1" : : "v"(cells[li][c]), "v"(zero) : "memory");
+                asm volatile("ds_write_b16 %0, %1 offset:%2" : : "v"(cells[li][c]), "v"(zero), "n"(kTile) : "memory");
+            }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
 
-    // ---- the four waves' accumulators -> one, through LDS; wave w adds up tile (phase * kHalf + w) and stores it
+    // ---- the four waves' accumulators -> one, through LDS, kPhase tiles at a time; wave w adds up tile (phase * kPhase + w)
     float *red = reinterpret_cast<float *>(lds);
     float *gmap = p.gv + (((long long)clip * p.T + f) * p.S + p.lsi) * MD + m * D;
 #pragma unroll
-    for (int ph = 0; ph < MT / kHalf; ++ph) {
+    for (int ph = 0; ph * kPhase < MT; ++ph) {
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < kHalf; ++t)
+        for (int t = 0; t < kPhase; ++t)
+            if (ph * kPhase + t < MT)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[((wave * kHalf + t) * 16 + r) * 64 + lane] = acc[ph * kHalf + t][r];
+                for (int r = 0; r < 16; ++r) red[((wave * kPhase + t) * 16 + r) * 64 + lane] = acc[ph * kPhase + t][r];
         __syncthreads();
-        if (wave < kHalf) {
-            const int t = ph * kHalf + wave;
+        for (int tw = wave; tw < kPhase && ph * kPhase + tw < MT; tw += 4) {
+            const int t = ph * kPhase + tw;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = 0.f;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) v += red[((w * kHalf + wave) * 16 + r) * 64 + lane];
+                for (int w = 0; w < 4; ++w) v += red[((w * kPhase + tw) * 16 + r) * 64 + lane];
                 const int pix = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (pix < npix) gmap[(long long)pix * MD + n] = v;
             }
@@ -210,10 +248,10 @@ mfma_scatter_kernel(const Args p)
     }
 }
 
-template <int MT, int NPROD> static size_t lds_bytes()
+template <int MT> static size_t lds_bytes()
 {
-    const size_t tile = MT * 32 * 32 + 64, half = MT == 8 ? 4 : MT, red = 4 * half * 4096;
-    return std::max<size_t>(4 * 2 * tile, red);
+    const size_t tile = 2 * (MT == 10 ? 304 : MT * 32 + 16) * 16, phase = MT >= 8 ? 4 : MT, red = 4 * phase * 4096;
+    return std::max<size_t>(4 * 2 * tile + 256, red);
 }
 
 static double frand(unsigned long long &s) { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)(s >> 11) / 9007199254740992.0; }
@@ -262,14 +300,15 @@ int main(int argc, char **argv)
     a.clips = clips; a.T = T; a.M = M; a.Lq = Lq; a.L = L; a.P = P; a.W = W; a.S = S;
 
     const int items = clips * T * M;
-    auto launch = [&](int lvl, int nprod) {
-        a.lvl = lvl; a.H = Hs[lvl]; a.Wd = Ws[lvl]; a.lsi = lsi[lvl];
-        const int npix = a.H * a.Wd;
-#define GO(MT, NP) { static bool once = false; if (!once) { once = true; CHECK(hipFuncSetAttribute((const void *)mfma_scatter_kernel<MT, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<MT, NP>())); } \
-            mfma_scatter_kernel<MT, NP><<<items, 256, lds_bytes<MT, NP>(), 0>>>(a); }
-        if (npix <= 64) { if (nprod == 3) GO(2, 3) else if (nprod == 2) GO(2, 2) else GO(2, 1) }
-        else if (npix <= 256) { if (nprod == 3) GO(8, 3) else if (nprod == 2) GO(8, 2) else GO(8, 1) }
-        else { printf("level %d too large\n", lvl); exit(1); }
+    auto launch = [&](int l0, int nl, int nprod) {
+        a.l0 = l0; a.nl = nl; a.lsi = lsi[l0]; a.npix = 0;
+        for (int li = 0; li < nl; ++li) { a.H[li] = Hs[l0 + li]; a.Wd[li] = Ws[l0 + li]; a.poff[li] = a.npix; a.npix += Hs[l0 + li] * Ws[l0 + li]; }
+#define GO(MT, NL, NP) { static bool once = false; if (!once) { once = true; CHECK(hipFuncSetAttribute((const void *)mfma_scatter_kernel<MT, NL, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<MT>())); } \
+            mfma_scatter_kernel<MT, NL, NP><<<items, 256, lds_bytes<MT>(), 0>>>(a); }
+        if (nl == 2) { if (a.npix > 320) { printf("too large\n"); exit(1); } if (nprod == 3) GO(10, 2, 3) else GO(10, 2, 1) }
+        else if (a.npix <= 64) { if (nprod == 3) GO(2, 1, 3) else GO(2, 1, 1) }
+        else if (a.npix <= 256) { if (nprod == 3) GO(8, 1, 3) else GO(8, 1, 1) }
+        else { printf("level %d too large\n", l0); exit(1); }
 #undef GO
         CHECK(hipGetLastError());
     };
@@ -287,13 +326,15 @@ int main(int argc, char **argv)
         return ts[ts.size() / 2];
     };
     printf("mfma_scatter: %d clips, T=%d, %d queries/frame, M=%d, %s locations; items per level %d\n", clips, T, Lq, M, clustered ? "clustered" : "uniform", items);
-    for (int nprod = 3; nprod >= 1; --nprod) {
-        const float t2 = time_ms([&] { launch(2, nprod); }), t3 = time_ms([&] { launch(3, nprod); });
-        const float both = time_ms([&] { launch(2, nprod); launch(3, nprod); });
-        printf("  %d products: level 2 (12x20) %.4f ms   level 3 (6x10) %.4f ms   both, back to back %.4f ms\n", nprod, t2, t3, both);
+    for (int nprod = 3; nprod >= 1; nprod -= 2) {
+        const float t2 = time_ms([&] { launch(2, 1, nprod); }), t3 = time_ms([&] { launch(3, 1, nprod); });
+        const float both = time_ms([&] { launch(2, 1, nprod); launch(3, 1, nprod); });
+        const float fused = time_ms([&] { launch(2, 2, nprod); });
+        printf("  %d products: level 2 (12x20) %.4f ms   level 3 (6x10) %.4f ms   both, back to back %.4f ms   FUSED (one launch, 10 tiles) %.4f ms\n", nprod, t2, t3, both, fused);
     }
     // ---- check (3 products) against a CPU double sum on a sample of items
-    launch(2, 3); launch(3, 3);
+    CHECK(hipMemset(d_gv, 0, n_gv * 4));
+    if (getenv("UNFUSED")) { launch(2, 1, 3); launch(3, 1, 3); } else launch(2, 2, 3);
     CHECK(hipDeviceSynchronize());
     std::vector<float> gv(n_gv);
     CHECK(hipMemcpy(gv.data(), d_gv, n_gv * 4, hipMemcpyDeviceToHost));
