@@ -291,14 +291,50 @@ def head_major(value):
 
 
 _shape_hints = {}       # (data_ptr, _version, device) -> (tensor kept alive, ctypes int64 array): host copies of spatial_shapes
+_registered = {}        # the same, for tensors whose host values were GIVEN (register_host_values): never evicted, never read back
+_hint_log = None        # while a list: every tensor shapes_hint() serves is appended (devis_amd.graphed learns which of a layer's
+                        # integer arguments steer kernel selection)
+
+
+def _hint_key(t):
+    return (t.data_ptr(), t._version, t.device)
+
+
+def register_host_values(tensor, values):
+    """Tell the binding the host values of an integer device tensor it will be handed as ``spatial_shapes`` (or that
+    :func:`known_host_values` will be asked about): the interned pyramids of ``devis_amd.patch_transformer`` are built from Python
+    ints, so their host copy exists before the device one -- ``shapes_hint`` then never reads the device (the
+    reference rebuilds ``spatial_shapes`` on every forward, deformable_transformer.py:74-87, and every new tensor cost one
+    synchronising device-to-host copy here).  The tensor is kept alive; the caller must not change it in place."""
+    flat = [int(v) for v in values]
+    if len(flat) != tensor.numel():
+        raise ValueError("register_host_values: %d values for a tensor of %d elements" % (len(flat), tensor.numel()))
+    _registered[_hint_key(tensor)] = (tensor, (ctypes.c_int64 * len(flat))(*flat))
+
+
+def known_host_values(t):
+    """Host values of an integer tensor as a tuple WITHOUT touching the device, or None when they are not known (CPU tensors:
+    read; device tensors: registered, or served by shapes_hint before)."""
+    if not isinstance(t, torch.Tensor) or t.is_floating_point():
+        return None
+    if not t.is_cuda:
+        return tuple(t.reshape(-1).tolist())
+    for table in (_registered, _shape_hints):
+        hit = table.get(_hint_key(t))
+        if hit is not None and hit[0] is t:
+            return tuple(hit[1])
+    return None
 
 
 def shapes_hint(shapes):
     """include/msda.h `spatial_shapes_host`: a host copy of the device tensor `spatial_shapes`, for kernel selection
     only.  Cached per tensor (the transformer hands the same tensor to every layer of every
-    step), so the device-to-host copy -- the only synchronisation -- happens once per distinct tensor."""
-    key = (shapes.data_ptr(), shapes._version, shapes.device)
-    hit = _shape_hints.get(key)
+    step), so the device-to-host copy -- the only synchronisation -- happens once per distinct tensor, and never for a tensor
+    whose values were registered (``register_host_values``: the interned pyramids of ``devis_amd.patch_transformer``)."""
+    if _hint_log is not None:
+        _hint_log.append(shapes)
+    key = _hint_key(shapes)
+    hit = _registered.get(key) or _shape_hints.get(key)
     if hit is not None and hit[0] is shapes:
         return hit[1]
     if shapes.is_cuda and torch.cuda.is_current_stream_capturing():
@@ -313,6 +349,21 @@ def shapes_hint(shapes):
         _shape_hints.clear()
     _shape_hints[key] = (shapes, arr)
     return arr
+
+
+class hint_log:
+    """``with hint_log() as served:`` -- the tensors shapes_hint() was asked about inside the block (by identity)."""
+
+    def __enter__(self):
+        global _hint_log
+        self._previous, _hint_log = _hint_log, []
+        self.served = _hint_log
+        return self.served
+
+    def __exit__(self, *exc):
+        global _hint_log
+        _hint_log = self._previous
+        return False
 
 
 def forward(value, shapes, lsi, loc, aw, out):

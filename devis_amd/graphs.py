@@ -16,13 +16,20 @@ synchronisation), so a layer can be captured into a HIP graph as it is; this mod
   in that part of the pool, silently (``scripts/repro_graph_default_stream.py``: forty lines of pure torch, no code of this
   package; outputs and input gradients are right, any non-default stream is right).  A training call made on the default
   stream therefore runs the module EAGERLY (one warning; ``layer.eager_calls`` counts them); inference calls replay anywhere;
-* one graph per SIGNATURE -- shapes / dtypes / ``requires_grad`` of the floating-point tensor arguments, and the identity (object
-  and version) of every other argument: the integer tensors (``spatial_shapes``, ``level_start_index``), the list of
-  ``temporal_offsets``, ``None`` masks.  Those are bound into the graph at capture: the library chooses kernels, grids and LDS plans
-  from a host copy of ``spatial_shapes``, so a graph is only valid for the pyramid it was captured with.  A call with another
-  signature captures (and caches) another graph; keep the integer tensors alive across steps -- the reference's transformer
-  rebuilds ``spatial_shapes`` on every forward (deformable_transformer.py:87): hoist it, or accept one capture per step, which
-  is slower than eager.
+* one graph per SIGNATURE -- shapes / dtypes / ``requires_grad`` of the floating-point tensor arguments, and of the other
+  arguments (the integer tensors ``spatial_shapes`` / ``level_start_index``, the list of ``temporal_offsets``, ``None`` masks):
+  - an integer tensor the library reads a HOST COPY of (``spatial_shapes``: it chooses kernels, grids and LDS plans from it --
+    found out during the warm-up call) counts by VALUE: the graph is only valid for the pyramid it was captured with, and any
+    tensor holding that pyramid replays it.  The values come from the binding without touching the device when the tensor is an
+    interned one of ``devis_amd.patch_transformer`` (which wraps the reference's ``prepare_data``, deformable_transformer.py:69-94)
+    or was seen before; a brand-new tensor costs one device-to-host read, as in an eager call;
+  - every other integer DEVICE tensor (``level_start_index``, the temporal copies of both, each frame's ``temporal_offsets`` --
+    the reference's stacks rebuild them on every forward, devis_transformer.py:97-118,146-158) counts by shape and is a graph
+    INPUT: its current contents are copied into the captured tensor before each replay (a few bytes, device to device), so the
+    replay computes with the values of THIS call;
+  - anything else (host tensors, Python values) counts by identity / value and is bound at capture.
+  With ``patch_transformer`` in place the reference's own stack therefore replays ONE graph per layer step after step, with no
+  host synchronisation (``tests/test_modules_gpu.py``: three training steps under ``torch.cuda.set_sync_debug_mode("error")``).
 """
 import contextlib
 import threading
@@ -68,6 +75,22 @@ def _static_key(x):
     if isinstance(x, (list, tuple)):
         return ("l", type(x).__name__) + tuple(_static_key(e) for e in x)
     return ("v", x)
+
+
+def _int_leaves(x, path=()):
+    """(path, tensor) of every integer DEVICE tensor inside a non-flowing argument (tuples / lists walked)."""
+    if isinstance(x, torch.Tensor):
+        if not x.is_floating_point() and x.is_cuda:
+            yield path, x
+    elif isinstance(x, (list, tuple)):
+        for i, e in enumerate(x):
+            yield from _int_leaves(e, path + (i,))
+
+
+def _at(x, path):
+    for i in path:
+        x = x[i]
+    return x
 
 
 class _Bound(nn.Module):
@@ -123,7 +146,8 @@ class GraphedLayer:
         self.num_warmup_iters = num_warmup_iters
         self.aux_grad = aux_grad
         self._cache = {}
-        self._keep = {}                     # signature -> the bound arguments (kept alive: their identity is the key)
+        self._keep = {}                     # signature -> the bound arguments (kept alive: the graph reads their memory)
+        self._hinted = None                 # (argument index, path...) of the integer tensors the library reads a host copy of
         self._lock = threading.Lock()
         self.eager_calls = 0                # training calls made on the default stream (run eagerly: see the module docstring)
 
@@ -131,13 +155,40 @@ class GraphedLayer:
     def graphs(self):
         return len(self._cache)
 
+    def _learn_hinted(self, args):
+        """One eager call (no gradients): the library reads its host copy of ``spatial_shapes`` outside any capture, so that the
+        graph records the routes that hint enables, and the binding tells which integer arguments it was asked about -- those
+        steer kernel selection and count by value; the other integer device tensors become graph inputs."""
+        from . import _native
+        with torch.no_grad(), _native.hint_log() as served:
+            self.module(*args)
+        ids = {id(t) for t in served}
+        self._hinted = {(i,) + path for i, a in enumerate(args) if not _is_flowing(a) for path, t in _int_leaves(a) if id(t) in ids}
+
     def _signature(self, args):
+        from . import _native
         sig = []
-        for a in args:
+        for i, a in enumerate(args):
             if _is_flowing(a):
                 sig.append(("f", tuple(a.shape), a.dtype, a.device, a.requires_grad))
-            else:
+                continue
+            leaves = dict(_int_leaves(a))
+            if not leaves:
                 sig.append(_static_key(a))
+                continue
+
+            def key(x, path):
+                if isinstance(x, torch.Tensor) and path in leaves:
+                    if (i,) + path in self._hinted:
+                        vals = _native.known_host_values(x)
+                        if vals is None:        # a tensor never seen before: one device read, as an eager call would make
+                            vals = tuple(_native.shapes_hint(x))
+                        return ("hv", tuple(x.shape), vals)
+                    return ("in", tuple(x.shape), x.dtype, x.device)
+                if isinstance(x, (list, tuple)):
+                    return ("l", type(x).__name__) + tuple(key(e, path + (j,)) for j, e in enumerate(x))
+                return _static_key(x)
+            sig.append(key(a, ()))
         # (+ what else changes the captured kernels: train / eval, and the ambient autocast state -- under torch.autocast use
         # ``cache_enabled=False``, as torch.cuda.make_graphed_callables asks)
         autocast = (torch.get_autocast_dtype("cuda"),) if torch.is_autocast_enabled("cuda") else ()
@@ -147,10 +198,13 @@ class GraphedLayer:
         """Capture (or fetch) the graph for this signature without running it: call once per shape before timing."""
         if not any(_is_flowing(a) and a.is_cuda for a in args):
             raise RuntimeError("devis_amd.graphed: needs CUDA (HIP) tensor arguments -- there is no CPU path to capture")
-        sig = self._signature(args)
         with self._lock:
+            if self._hinted is None:
+                self._learn_hinted(args)
+            sig = self._signature(args)
             fn = self._cache.get(sig)
             if fn is not None:
+                self._refresh_inputs(sig, args)
                 return fn
             template = [_FLOW if _is_flowing(a) else a for a in args]
             flowing = tuple(a for a in args if _is_flowing(a))
@@ -165,11 +219,24 @@ class GraphedLayer:
             with graph_stream(next(t.device for t in flowing if t.is_cuda)), torch.enable_grad():
                 fn = torch.cuda.make_graphed_callables(bound, samples, num_warmup_iters=self.num_warmup_iters)
             self._cache[sig] = fn
-            self._keep[sig] = [a for a in args if not _is_flowing(a)]
+            self._keep[sig] = list(args)        # (the flowing ones too: positions must line up; they are tiny references)
             while len(self._cache) > self.max_graphs:
                 oldest = next(iter(self._cache))
                 del self._cache[oldest], self._keep[oldest]
             return fn
+
+    def _refresh_inputs(self, sig, args):
+        """Before a replay: the integer device tensors that are graph inputs (module docstring) take this call's contents."""
+        kept = self._keep[sig]
+        for i, a in enumerate(args):
+            if _is_flowing(a):
+                continue
+            for path, t in _int_leaves(a):
+                if (i,) + path in self._hinted:
+                    continue
+                mine = _at(kept[i], path)
+                if mine is not t:
+                    mine.copy_(t, non_blocking=True)
 
     def _wants_gradients(self, args):
         return torch.is_grad_enabled() and (any(_is_flowing(a) and a.requires_grad for a in args) or

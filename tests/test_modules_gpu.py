@@ -455,3 +455,134 @@ def test_split_k_weight_gradient_on_16_bit_inputs_is_as_accurate_as_one_gemm_on_
     single, split = rms(g.t() @ x), rms(F._split_k_wgrad(g, x))
     assert F._split_k_wgrad(g, x).dtype == dtype
     assert split <= single * 1.05, (split, single, F._BMM_F32_OUT)
+
+
+def test_reference_shaped_stack_replays_one_graph_per_layer_without_host_synchronisation():
+    """SURVEY 8 row f-4 as written: a stack that builds its call-site tensors the way the reference does --
+    ``spatial_shapes`` / ``level_start_index`` from the feature maps' Python sizes on every forward
+    (deformable_transformer.py:69-94), each frame's ``temporal_offsets`` with ``torch.tensor(list, device=...)``, ``repeat``-ed
+    temporal shapes and their start indices on every forward (devis_transformer.py:146-158) -- driven for three training steps
+    with ``devis_amd.patch_transformer(dt, dvt)`` + ``devis_amd.graphed`` layers under
+    ``torch.cuda.set_sync_debug_mode("error")``: no host synchronisation, ONE graph per layer, and the same outputs and
+    gradients as the eager layers.  (Unpatched, the stand-in's own ``torch.as_tensor(..., device=...)`` -- the reference's line
+    87 -- already raises under that mode.)"""
+    import types
+    import devis_amd
+    from devis_amd import _native
+    from devis_amd.modules import TemporalMSDeformAttnDecoder, TemporalMSDeformAttnEncoder
+    torch.manual_seed(7)
+    T, C, M, L, Lq = 4, 256, 8, 4, 50
+    pyr = [(24, 40), (12, 20), (6, 10), (3, 5)]
+    S = sum(h * w for h, w in pyr)
+
+    class Encoder(torch.nn.Module):                       # the method the reference's encoder stacks look up on their class
+        @staticmethod
+        def get_reference_points(spatial_shapes, valid_ratios, device):
+            raise AssertionError("patched away")
+
+    class Stack(torch.nn.Module):
+        """What the replacement needs of DeformableTransformer (deformable_transformer.py:17-68): level_embed, get_valid_ratio,
+        and a prepare_data of the reference's shape -- everything from Python sizes, new device tensors on every call."""
+
+        def __init__(self):
+            super().__init__()
+            self.level_embed = torch.nn.Parameter(torch.randn(L, C) * 0.02)
+
+        def get_valid_ratio(self, mask):
+            _, H, W = mask.shape
+            return torch.stack([torch.sum(~mask[:, 0, :], 1).float() / W, torch.sum(~mask[:, :, 0], 1).float() / H], -1)
+
+        def prepare_data(self, srcs, masks, pos_embeds):
+            flat = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+            spatial_shapes = torch.as_tensor([(s.shape[2], s.shape[3]) for s in srcs], dtype=torch.long, device=flat.device)
+            level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+            return flat, None, None, spatial_shapes, level_start_index, None
+
+    # a module namespace of its own, as src.models.devis_transformer is one: its `torch` is what patch_transformer replaces
+    dvt = types.ModuleType("stand_in_devis_transformer")
+    exec("import torch\n\n\n"
+         "def build_temporal_arguments(spatial_shapes, T_, device):\n"
+         "    temporal_offsets = [torch.tensor([t for t in range(-f, T_ - f) if t != 0], device=device) for f in range(T_)]\n"
+         "    temporal_spatial_shapes = spatial_shapes.repeat(T_ - 1, 1)\n"
+         "    temporal_start = torch.cat((temporal_spatial_shapes.new_zeros((1,)), temporal_spatial_shapes.prod(1).cumsum(0)[:-1]))\n"
+         "    return temporal_offsets, temporal_spatial_shapes, temporal_start\n", dvt.__dict__)
+    ns = types.SimpleNamespace(DeformableTransformerEncoder=Encoder, DeformableTransformer=Stack)
+    stack = Stack().to(DEV)
+    enc = TemporalMSDeformAttnEncoder(T, C, L, T - 1, M, 4, 2).to(DEV)
+    dec = TemporalMSDeformAttnDecoder(T, C, L, T - 1, M, 4, 2).to(DEV)
+    with torch.no_grad():
+        for p in list(enc.parameters()) + list(dec.parameters()):
+            p.normal_(0, 0.05)
+    gen = torch.Generator(device="cpu")
+    steps = []          # inputs of all steps made up front (host-side random numbers + their copies are not what is being tested)
+    for seed in range(4):
+        gen.manual_seed(100 + seed)
+        srcs = [torch.randn(T, C, h, w, generator=gen).to(DEV) for h, w in pyr]
+        masks = [torch.zeros(T, h, w, dtype=torch.bool, device=DEV) for h, w in pyr]
+        q_enc = torch.randn(T, S, C, generator=gen).to(DEV).requires_grad_(True)
+        q_dec = torch.randn(1, T * Lq, C, generator=gen).to(DEV).requires_grad_(True)       # the decoder's layout: frames x queries flattened
+        ref_enc = (torch.rand(T, S, L, 2, generator=gen) * 0.8 + 0.1).to(DEV)
+        ref_dec = (torch.rand(1, T * Lq, L, 2, generator=gen) * 0.8 + 0.1).to(DEV)
+        w_enc, w_dec = torch.randn(T, S, C, generator=gen).to(DEV), torch.randn(1, T * Lq, C, generator=gen).to(DEV)
+        steps.append((srcs, masks, q_enc, q_dec, ref_enc, ref_dec, w_enc, w_dec))
+    torch.cuda.synchronize()
+
+    def one_step(step, enc_layer, dec_layer):
+        srcs, masks, q_enc, q_dec, ref_enc, ref_dec, w_enc, w_dec = step
+        flat, _, _, spatial_shapes, level_start_index, _ = stack.prepare_data(srcs, masks, srcs)
+        flat = flat.detach().requires_grad_(True)
+        temporal_offsets, t_shapes, t_lsi = dvt.build_temporal_arguments(spatial_shapes, T, flat.device)
+        memory = enc_layer(q_enc, ref_enc, flat, (spatial_shapes, t_shapes), (level_start_index, t_lsi), temporal_offsets)
+        memory = memory[0] if isinstance(memory, tuple) else memory
+        out = dec_layer(q_dec, ref_dec, memory, (spatial_shapes, t_shapes), (level_start_index, t_lsi), temporal_offsets)[0]
+        leaves = [q_enc, q_dec, flat] + list(enc.parameters()) + list(dec.parameters())
+        grads = torch.autograd.grad((out * w_dec).sum() + (memory * w_enc).sum(), leaves)
+        return out, grads, spatial_shapes, temporal_offsets
+
+    # unpatched: the stand-in's own as_tensor (the reference's line 87) is a synchronising operation
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        with pytest.raises(RuntimeError, match="synchronizing"):
+            stack.prepare_data(steps[0][0], steps[0][1], steps[0][0])
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+
+    previous = devis_amd.patch_transformer(ns, dvt)
+    try:
+        g_enc, g_dec = devis_amd.graphed(enc), devis_amd.graphed(dec)
+        with devis_amd.graph_stream():
+            one_step(steps[0], g_enc, g_dec)                # interns the pyramid and the offsets, captures both layers
+            torch.cuda.synchronize()
+            seen, results = [], []
+            torch.cuda.set_sync_debug_mode("error")
+            try:
+                for step in steps[1:]:
+                    out, grads, shapes_t, offs_t = one_step(step, g_enc, g_dec)
+                    results.append((out.detach().clone(), [g.clone() for g in grads]))      # (a graph's outputs are static buffers: the next replay overwrites them)
+                    seen.append((shapes_t, offs_t))
+            finally:
+                torch.cuda.set_sync_debug_mode("default")
+            torch.cuda.synchronize()
+            assert g_enc.graphs == 1 and g_dec.graphs == 1 and g_enc.eager_calls == 0 and g_dec.eager_calls == 0
+            assert all(s is seen[0][0] for s, _ in seen)                                          # the interned pyramid ...
+            assert all(a is b for _, offs in seen for a, b in zip(offs, seen[0][1]))              # ... and offsets
+            assert _native.known_host_values(seen[0][0]) == tuple(v for hw in pyr for v in hw)
+            for step, (out_g, grads_g) in zip(steps[1:], results):
+                out_e, grads_e, _, _ = one_step(step, enc, dec)
+                torch.cuda.synchronize()
+                assert torch.allclose(out_g, out_e, rtol=1e-5, atol=1e-6)
+                for x, y in zip(grads_g, grads_e):
+                    assert torch.allclose(x, y, rtol=1e-4, atol=2e-5 * max(1e-6, float(y.abs().max())))
+        # without the second argument the offsets are new tensors every step: still one graph (they are graph inputs, copied in)
+        devis_amd.argument_builders.unpatch_transformer(ns, previous, dvt)
+        previous = devis_amd.patch_transformer(ns)
+        with devis_amd.graph_stream():
+            for step in steps[:3]:
+                out_g, grads_g, _, _ = one_step(step, g_enc, g_dec)
+                out_e, grads_e, _, _ = one_step(step, enc, dec)
+                torch.cuda.synchronize()
+                assert torch.allclose(out_g, out_e, rtol=1e-5, atol=1e-6)
+        assert g_enc.graphs == 1 and g_dec.graphs == 1
+    finally:
+        devis_amd.argument_builders.unpatch_transformer(ns, previous, dvt)
+    assert Stack.__dict__["prepare_data"].__qualname__.endswith("Stack.prepare_data") and dvt.torch is torch

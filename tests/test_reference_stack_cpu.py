@@ -133,15 +133,32 @@ def test_devis_transformer_on_devis_amd_equals_the_one_on_the_reference_ops(tmp_
         shapes = torch.tensor(PYRAMID, dtype=torch.long)
         vr = out_a["valid_ratios"]
         want = dt.DeformableTransformerEncoder.get_reference_points(shapes, vr, device=vr.device)
-        previous = ops_pkg.patch_transformer(dt)
+        srcs, masks, pos, _ = _inputs()
+        with torch.no_grad():
+            prepared = model_a.prepare_data(srcs, masks, pos)          # the reference's own method (deformable_transformer.py:69-94)
+        previous = ops_pkg.patch_transformer(dt, mod_a)
         try:
             got = dt.DeformableTransformerEncoder.get_reference_points(shapes, vr, device=vr.device)
             assert torch.equal(got, want)
+            # the replacement prepare_data on the REAL class -- the same six results, bit for bit, with the two
+            # pyramid tensors interned (the same objects on every call, their host values known to the binding)
+            with torch.no_grad():
+                mine, mine2 = model_a.prepare_data(srcs, masks, pos), model_a.prepare_data(srcs, masks, pos)
+            assert len(mine) == len(prepared) == 6
+            for x, y in zip(mine, prepared):
+                assert x.dtype == y.dtype and torch.equal(x, y)
+            assert mine[3] is mine2[3] and mine[4] is mine2[4] and mine[3] is not prepared[3]
+            assert native.known_host_values(mine[3]) == tuple(v for hw in PYRAMID for v in hw)
+            # ... and the stacks' temporal offsets (devis_transformer.py:100, 149) come out interned through the module's `torch`
+            a1 = mod_a.torch.tensor([1, 2], device=vr.device)
+            assert a1 is mod_a.torch.tensor([1, 2], device=vr.device) and a1.tolist() == [1, 2]
+            assert mod_a.torch.tensor([1.5], device=vr.device).dtype == torch.float32 and mod_a.torch.cat is torch.cat
             with torch.no_grad():
                 again = model_a(*_inputs())[0]
             assert torch.equal(again, out_a["hs"])                 # the patched stack computes the same thing
         finally:
-            dt.DeformableTransformerEncoder.get_reference_points = previous
+            ops_pkg.argument_builders.unpatch_transformer(dt, previous, mod_a)
+        assert mod_a.torch is torch and dt.DeformableTransformer.prepare_data.__qualname__ == "DeformableTransformer.prepare_data"
         assert type(model_a.encoder.layers[0].self_attn).__module__.startswith("src.models.ops.modules")
 
     with _Imported(b, extension=_oracle_extension()) as mod_b:
