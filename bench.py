@@ -132,6 +132,7 @@ ROUTE_KERNELS = [   # msda_last_route() phrase -> kernel symbol
     ("forward (slab kernel)", "msda_fwd_slab_kernel"),
     ("forward (tile kernel)", "msda_fwd_tile_kernel"), ("forward (generic kernel)", "msda_fwd_generic_kernel"),
     ("slab kernel, grad_loc/grad_attn", "msda_bwd_slab_kernel"), ("tile kernel, grad_loc/grad_attn", "msda_bwd_tile_kernel"),
+    ("matrix-pipe scatter", "msda_bwd_value_mfma_kernel"),
     ("group-granular", "msda_bwd_value_grp_kernel"), ("owner-computes scatter", "msda_bwd_value_own_kernel"),
     ("per-point culling", "msda_bwd_value_points_kernel"),
     ("LDS scatter kernel)", "msda_bwd_value_lds_kernel"), ("global atomics", "msda_bwd_tile_kernel<atomics>"),
@@ -166,9 +167,17 @@ def algorithmic_bytes(args, e, gv_bytes=4, le=None):
     C = M * D
     points = T * q * M * (L * P + W * L * P)
     le = le or e        # bytes per sampling-location / attention-weight element (4 beside a 16-bit value with --sampling fp32)
-    return {"fwd": T * S * C * e + points * 3 * le + T * q * C * e,
-            "bwd_gather": T * S * C * e + T * q * C * e + points * 3 * le + points * 3 * le,
-            "bwd_scatter": points * 3 * le + T * q * C * e + T * S * C * gv_bytes}
+    out = {"fwd": T * S * C * e + points * 3 * le + T * q * C * e,
+           "bwd_gather": T * S * C * e + T * q * C * e + points * 3 * le + points * 3 * le,
+           "bwd_scatter": points * 3 * le + T * q * C * e + T * S * C * gv_bytes}
+    # the scatter as TWO kernels (round 6): the owner-computes kernel on the leading levels, the matrix-pipe kernel on the `coarse`
+    # trailing ones -- each reads the points of its own levels and every grad_out row, and writes its own levels' pixels
+    for coarse in (1, 2):
+        px = sum(h * w for h, w in shapes[L - coarse:])
+        pts = points * coarse // L
+        out["bwd_scatter_mfma_%d" % coarse] = pts * 3 * le + T * q * C * e + T * px * C * gv_bytes
+        out["bwd_scatter_owner_%d" % coarse] = (points - pts) * 3 * le + T * q * C * e + T * (S - px) * C * gv_bytes
+    return out
 
 
 def _event_ms(fn, reps, warm=3):
@@ -328,6 +337,24 @@ def other_configs(args, device):
             with devis_amd.graph_stream(device):
                 entry["graphed_with_parameter_gradients_ms"] = round(_event_ms(lambda: mstep(helper), 20, 5), 4)
             assert layer.eager_calls == 0
+            # ... and the same layer fed the way DeVIS's own stack feeds it once `devis_amd.patch_transformer(dt, dvt)` is in place
+            # (SURVEY 8 row f-4): the pyramid from the feature maps' Python sizes on every call (interned: the same device pair, its host
+            # values known to the binding), each frame's temporal offsets through the module's `torch.tensor` (interned), the
+            # repeated temporal shapes and start indices rebuilt on the device every call (graph inputs) -- one graph, no host sync
+            from devis_amd import argument_builders as _ab
+            itorch = _ab._InterningTorch(torch)
+
+            def wired(a, b, c):
+                shp_i, lsi_i = _ab.interned_pyramid(PYRAMIDS[args.pyramid], device)
+                offs_i = [itorch.tensor([t for t in range(-f, T_ - f) if t != 0], device=device) for f in range(T_)]
+                tsh_i = shp_i.repeat(T_ - 1, 1)
+                tlsi_i = torch.cat((tsh_i.new_zeros((1,)), tsh_i.prod(1).cumsum(0)[:-1]))
+                return layer(a, b, c, (shp_i, tsh_i), (lsi_i, tlsi_i), offs_i)[0]
+            with devis_amd.graph_stream(device):
+                mstep(wired)
+                before = layer.graphs
+                entry["graphed_from_patched_stack_wiring_ms"] = round(_event_ms(lambda: mstep(wired), 20, 5), 4)
+                entry["graphs_captured_by_that_wiring"] = layer.graphs - before + 1
 
             def mstep_params():
                 torch.autograd.grad((call(qry, refp, srcm) * wgt).sum(), [qry, srcm] + list(mod.parameters()))
@@ -766,17 +793,31 @@ def main():
         _native.reload_knobs()
         sca_ms, sca_med = time_kernel(bwd, 20)
         routes["scatter"] = _native.last_route()
-        sca_name = kernel_name(routes["scatter"], "scatter")
+        e = b["value"].element_size()
+        ab = algorithmic_bytes(args, e, gv.element_size(), b["loc_c"].element_size())
+        scatter_parts = [x.strip() for x in routes["scatter"].split(";") if "scatter" in x and "zero-fill" not in x]
+        kernels = {}
+        if len(scatter_parts) == 2 and "matrix-pipe" in scatter_parts[1]:
+            # two kernels: each timed alone (MSDA_SCATTER_PART, a measurement knob); the pair's time is reported beside them
+            coarse = 2 if sum(h * w for h, w in PYRAMIDS[args.pyramid][-2:]) <= 303 else 1
+            for part, key, label in ((1, "owner", " (grad_value scatter, levels [0, %d))" % (L - coarse)),
+                                     (2, "mfma", " (grad_value scatter, the %d coarse level(s) on the matrix pipe)" % coarse)):
+                os.environ["MSDA_SCATTER_PART"] = str(part)
+                _native.reload_knobs()
+                ms, med = time_kernel(bwd, 20)
+                kernels[kernel_name(scatter_parts[part - 1], "scatter") + label] = (ms, med, ab["bwd_scatter_%s_%d" % (key, coarse)])
+            os.environ.pop("MSDA_SCATTER_PART")
+            sca_name = "both scatter kernels"
+        else:
+            sca_name = kernel_name(routes["scatter"], "scatter")
+            kernels[sca_name + " (grad_value scatter)"] = (sca_ms, sca_med, ab["bwd_scatter"])
         os.environ.pop("MSDA_BWD_PHASES")
         os.environ.pop("MSDA_ENABLE_HOOKS")
         _native.reload_knobs()
-        e = b["value"].element_size()
-        ab = algorithmic_bytes(args, e, gv.element_size(), b["loc_c"].element_size())
-        kernels = {
+        kernels.update({
             fwd_name: (fwd_ms, fwd_med, ab["fwd"]),
             gat_name + " (grad_loc/grad_attn gather pass)": (gat_ms, gat_med, ab["bwd_gather"]),
-            sca_name + " (grad_value scatter)": (sca_ms, sca_med, ab["bwd_scatter"]),
-        }
+        })
         dom = max(kernels, key=lambda k: kernels[k][0])
         d_ms, _, d_bytes = kernels[dom]
         ach = d_bytes * args.clips / (d_ms * 1e-3) / 1e9
@@ -800,6 +841,29 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": d_bytes * args.clips, "avg_launch_ms": round(d_ms, 4),
                     "traffic_source": traffic_src}
+        # What the kernels ARE bound by (none of them is HBM-bound): busy fractions of the on-chip units from the committed PMC
+        # passes (profiles/onchip.json, scripts/make_onchip.py), quoted -- like `traffic` -- only for this configuration and this
+        # very build of the kernel sources; the L2 request rate uses the launch durations measured above.
+        onchip_all = None
+        try:
+            from devis_amd import build as _b
+            prof = json.load(open(os.path.join(ROOT, "profiles", "onchip.json")))
+            w = prof["workload"]
+            if (w["clips"], w["frames"], w["queries"], w["pyramid"], w["dtype"], w["locs"], w["pattern"]) == \
+                    (args.clips, args.frames, args.queries, args.pyramid, args.dtype, args.locs, args.pattern) \
+                    and args.value_layout == "dense" and prof.get("source_hash") == _b._source_hash():
+                onchip_all = {}
+                for name, (ms, _, _) in kernels.items():
+                    k = dict(prof["kernels"].get(name.split(" ")[0], {}))
+                    if not k:
+                        continue
+                    if "l2_requests" in k:
+                        k["l2_request_GBps"] = round(k["l2_requests"] * 128 / (ms * 1e-3) / 1e9, 1)
+                        k["l2_request_frac_of_34.5TBps"] = round(k["l2_request_GBps"] / 34500.0, 4)
+                    onchip_all[name] = k
+                roofline["onchip"] = dict(onchip_all.get(dom, {}), source=prof.get("source"))
+        except (OSError, KeyError, ValueError):
+            onchip_all = None
         # the fraction of the NOMINAL peak above, and of what a plain device-to-device copy reaches on this very box
         # (1 GiB read + 1 GiB written per copy, HIP events, median of 10)
         try:
@@ -816,7 +880,12 @@ def main():
                                  "algorithmic_GBps": round(v[2] * args.clips / (v[0] * 1e-3) / 1e9, 1),
                                  "frac_of_hbm_peak": round(v[2] * args.clips / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                              for k, v in kernels.items()},
+                 "scatter_pass": {"kernels": sca_name, "avg_ms": round(sca_ms, 4), "median_ms": round(sca_med, 4),
+                                  "algorithmic_GBps": round(ab["bwd_scatter"] * args.clips / (sca_ms * 1e-3) / 1e9, 1),
+                                  "frac_of_hbm_peak": round(ab["bwd_scatter"] * args.clips / (sca_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                 "forward_frac_of_hbm_peak_vs_north_star_0.60": round(ab["fwd"] * args.clips / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                  "forward_M_queries_per_s": round(args.clips * T * q / (fwd_ms * 1e-3) / 1e6, 2),
+                 "onchip": onchip_all,
                  "routes": routes}       # msda_last_route() of the three launches timed above: which kernel family ran, as the library says
 
     # ---- CPU baseline: the reference's pure-PyTorch path on the host cores (bounded sample) -----

@@ -66,6 +66,7 @@ struct Knobs {
     int scatter_lds_kb = 144, scatter_dbg = 0;
     int scatter_own = -1;               // owner-computes scatter: -1 auto, 0 off (the LDS-atomic scatter instead)
     int scatter_mfma = -1;              // matrix-pipe scatter of the coarse levels (msda_mfma.hip): -1 auto, 0 off, 1 wherever it applies
+    int scatter_part = 0;               // measurement: 1 = only the owner-computes kernel of a scatter that runs both, 2 = only the matrix-pipe kernel
     int scatter_own_levels = -1;        // measurement: the owner-computes scatter handles only the first n levels (grad_value of the others is NOT computed)
     int force_generic = 0;
     int gv_storage = 1;                 // 0: msda_grad_value_dtype always answers the arithmetic type (A/B measurements)
@@ -118,6 +119,7 @@ void load_knobs()
         k.scatter_own = env_int("MSDA_SCATTER_OWN", k.scatter_own);
         k.scatter_own_levels = env_int("MSDA_SCATTER_OWN_LEVELS", k.scatter_own_levels);
         k.scatter_mfma = env_int("MSDA_SCATTER_MFMA", k.scatter_mfma);
+        k.scatter_part = env_int("MSDA_SCATTER_PART", k.scatter_part);
         k.force_generic = env_int("MSDA_FORCE_GENERIC", 0) == 1;
         k.gv_storage = env_int("MSDA_GV_STORAGE", k.gv_storage);
         k.dbg = env_int("MSDA_DBG", 0);
@@ -684,8 +686,9 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             if (tiles && knobs().scatter_mfma < 0 && !(per_item <= 8192 && items >= 128 && (p.L - l0 == 2 || px >= 200))) { l0 = p.L; tiles = 0; }
         }
         if (l0 < p.L) pg.own_levels = l0;
-        rc = launch_scatter_grp(dtype, p.gv_storage != 0, pg, grid * (1024 / kOwnThreads), (knobs().scatter_dbg & (511 | 2048 | 4096)) | (fused_zero ? 512 : 0), stream);
-        if (rc || !tiles) return rc;
+        if (!(tiles && knobs().scatter_part == 2))
+            rc = launch_scatter_grp(dtype, p.gv_storage != 0, pg, grid * (1024 / kOwnThreads), (knobs().scatter_dbg & (511 | 2048 | 4096)) | (fused_zero ? 512 : 0), stream);
+        if (rc || !tiles || knobs().scatter_part == 1) return rc;
         return launch_scatter_mfma(dtype, p.gv_storage != 0, p, l0, tiles, stream);
     }
     if (p.gv_storage) return fail(MSDA_ERR_ARG, "msda backward: this call needs grad_value in the arithmetic type (see msda_grad_value_dtype)%s");

@@ -23,6 +23,8 @@ for grp in hbm sq mem; do
 done
 # profiles/hbm_traffic.json for this very build (bench.py quotes it only while the kernel sources are unchanged)
 python3 scripts/make_hbm_traffic.py "$O/pmc_hbm.txt" "profiles/$1_pmc_hbm_traffic.txt" > /dev/null && cp profiles/hbm_traffic.json "$O/hbm_traffic.json"
+# profiles/onchip.json (busy fractions of the on-chip units) for this very build, same rule
+python3 scripts/make_onchip.py "$O/pmc_sq.txt" "$O/pmc_mem.txt" "profiles/$1_pmc_sq.txt" "profiles/$1_pmc_mem.txt" > /dev/null && cp profiles/onchip.json "$O/onchip.json"
 tail -c 400 "$O/bench.json"; echo; head -12 "$O/kernel_stats.csv"; cat "$O/pmc_hbm.txt"
 prev=${2:-$(ls -t profiles/r*_bench.json 2>/dev/null | head -1)}
 if [ -n "$prev" ] && [ -f "$prev" ]; then
