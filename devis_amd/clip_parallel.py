@@ -66,13 +66,16 @@ class _AllGatherRows(Function):
 
 
 class _StartGatherRows(Function):
-    """:class:`_AllGatherRows` with the collective left IN FLIGHT: forward issues the all-gather with ``async_op=True`` (RCCL
+    """:class:`_AllGatherRows` with BOTH collectives left in flight: forward issues the all-gather with ``async_op=True`` (RCCL
     runs it on its own stream) and parks the work handle in ``pending``; the gathered tensor must not be read before
-    :class:`_FinishGatherRows` has waited on the handle.  backward: reduce-scatter (sum), as in :class:`_AllGatherRows`."""
+    :class:`_FinishGatherRows` has waited on the handle.  backward: the reduce-scatter (sum) was ISSUED by
+    :class:`_FinishGatherRows`'s backward -- which autograd runs right behind the kernel's -- and is only WAITED for here, where
+    its result is consumed: whatever autograd runs in between (the backward of the next clip's kernel in a batch, of the layer's
+    query-side GEMM and pre-op pass in the single-clip form) overlaps it."""
 
     @staticmethod
-    def forward(ctx, chunk, group, pending):
-        ctx.group = group
+    def forward(ctx, chunk, group, pending, pending_bwd):
+        ctx.group, ctx.pending_bwd = group, pending_bwd
         world = dist.get_world_size(group)
         chunk = chunk.contiguous()
         out = chunk.new_empty((world * chunk.shape[0],) + tuple(chunk.shape[1:]))
@@ -81,32 +84,46 @@ class _StartGatherRows(Function):
 
     @staticmethod
     def backward(ctx, grad):
-        return _AllGatherRows.backward(ctx, grad) + (None,)
+        if not ctx.pending_bwd:         # (the gradient did not pass through _FinishGatherRows: reduce here, synchronously)
+            return _AllGatherRows.backward(ctx, grad) + (None, None)
+        work, mine, keep = ctx.pending_bwd.pop()
+        work.wait()
+        del keep                        # the full-size gradient the collective was reading
+        return mine, None, None, None
 
 
 class _FinishGatherRows(Function):
-    """Identity that makes the current stream wait for the all-gather :class:`_StartGatherRows` started."""
+    """Identity that makes the current stream wait for the all-gather :class:`_StartGatherRows` started; its backward starts
+    the reduce-scatter of the gradient (``async_op=True``) and hands the work to :class:`_StartGatherRows`'s backward."""
 
     @staticmethod
-    def forward(ctx, full, pending):
+    def forward(ctx, full, pending, pending_bwd, group):
+        ctx.pending_bwd, ctx.group = pending_bwd, group
         while pending:
             pending.pop().wait()
         return full.view_as(full)
 
     @staticmethod
     def backward(ctx, grad):
-        return grad, None
+        group = ctx.group
+        world = dist.get_world_size(group)
+        grad = grad.contiguous()
+        mine = grad.new_empty((grad.shape[0] // world,) + tuple(grad.shape[1:]))
+        work = dist.reduce_scatter_tensor(mine, grad, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        ctx.pending_bwd.append((work, mine, grad))
+        return grad, None, None, None   # (a placeholder for the node in between: _StartGatherRows returns `mine`)
 
 
 class PendingValue:
     """The all-gather of one layer's ``value`` in flight (see :func:`start_gather_value`)."""
 
-    def __init__(self, full, pending, n_frames, spatial_size):
-        self._full, self._pending, self._shape = full, pending, (n_frames, spatial_size)
+    def __init__(self, full, pending, pending_bwd, group, n_frames, spatial_size):
+        self._full, self._pending, self._pending_bwd, self._group = full, pending, pending_bwd, group
+        self._shape = (n_frames, spatial_size)
 
     def wait(self):
         """The full ``[T, S, M, D]`` tensor, valid on the current stream from here on; differentiable."""
-        full = _FinishGatherRows.apply(self._full, self._pending)
+        full = _FinishGatherRows.apply(self._full, self._pending, self._pending_bwd, self._group)
         T, S = self._shape
         return full[: T * S].reshape((T, S) + tuple(full.shape[1:]))
 
@@ -115,9 +132,40 @@ def start_gather_value(value_chunk, n_frames, spatial_size, group=None):
     """Issue the all-gather of :func:`gather_value` WITHOUT waiting for it: whatever the caller enqueues next on its
     stream -- the layer's query-side GEMM and the fused pre-op pass (softmax + sampling locations), which do not
     depend on ``value`` -- runs while the shards travel over xGMI.  ``.wait()`` on the result returns the tensor."""
-    pending = []
-    full = _StartGatherRows.apply(value_chunk, group, pending)
-    return PendingValue(full, pending, n_frames, spatial_size)
+    pending, pending_bwd = [], []
+    full = _StartGatherRows.apply(value_chunk, group, pending, pending_bwd)
+    return PendingValue(full, pending, pending_bwd, group, n_frames, spatial_size)
+
+
+_agreed = {}            # (ids and versions of the tensors, group) -> the tensors (kept alive: their identity is the key)
+
+
+def check_ranks_agree(spatial_shapes, frame_table, group=None):
+    """Every rank of a sharded clip must hold the SAME pyramid and frame table: each samples the gathered ``value`` with its own
+    copy, and a mismatch (a rank fed another resize of the clip, another window) would not fail -- it would sample garbage.  The
+    first time a (spatial_shapes, frame_table) pair is seen, its values are all-gathered (a few dozen bytes) and compared on the
+    host: ONE collective and one synchronisation per new pair of tensors (none afterwards; interned tensors -- ``devis_amd.
+    patch_transformer`` -- make that once per run).  Raises RuntimeError on EVERY rank when they differ."""
+    key = (id(spatial_shapes), spatial_shapes._version, id(frame_table), frame_table._version, id(group))
+    if key in _agreed:
+        return
+    mine = torch.cat([spatial_shapes.reshape(-1).to(torch.int64), frame_table.reshape(-1).to(torch.int64)])
+    world = dist.get_world_size(group)
+    sizes = mine.new_empty((world,))
+    dist.all_gather_into_tensor(sizes, mine.new_tensor([mine.numel()]), group=group)
+    if len(set(sizes.tolist())) != 1:
+        raise RuntimeError("devis_amd.clip_parallel: the ranks of a sharded clip hold pyramids / frame tables of different sizes: %s"
+                           % sizes.tolist())
+    everyone = mine.new_empty((world * mine.numel(),))
+    dist.all_gather_into_tensor(everyone, mine, group=group)
+    rows = everyone.view(world, mine.numel()).tolist()
+    if any(r != rows[0] for r in rows):
+        bad = [i for i, r in enumerate(rows) if r != rows[0]]
+        raise RuntimeError("devis_amd.clip_parallel: spatial_shapes / frame_table differ between the ranks of a sharded clip "
+                           "(ranks %s against rank 0)" % bad)
+    if len(_agreed) > 64:
+        _agreed.clear()
+    _agreed[key] = (spatial_shapes, frame_table)
 
 
 def gather_value(value_chunk, n_frames, spatial_size, group=None):
@@ -129,18 +177,23 @@ def gather_value(value_chunk, n_frames, spatial_size, group=None):
 
 
 def sharded_temporal_attention(value_chunk, n_frames, spatial_size, spatial_shapes, level_start_index,
-                               frame_table, loc_curr, aw_curr, loc_temp, aw_temp, group=None, transport_dtype=None):
+                               frame_table, loc_curr, aw_curr, loc_temp, aw_temp, group=None, transport_dtype=None,
+                               check_agreement=True):
     """Mode 2 for one clip.  value_chunk: this rank's rows of the flattened value (see gather_value);
     loc_*/aw_* hold this rank's query range of every frame ([T, Lq_local, M, ...]) -- tensors, or ONE callable that
     produces the four of them (``loc_curr``; the others None): it is called while the all-gather is in flight, so the
-    layer's query-side GEMM and pre-op pass overlap the collective.  Returns this rank's output rows
-    [T, Lq_local, M*D].  One all-gather forward, one reduce-scatter backward.
+    layer's query-side GEMM and pre-op pass overlap the collective -- in both directions: the backward's reduce-scatter is
+    issued behind the kernel's backward and waited for where its result is consumed.  Returns this rank's output rows
+    [T, Lq_local, M*D].  One all-gather forward, one reduce-scatter backward.  ``check_agreement``: :func:`check_ranks_agree`
+    (one small collective + synchronisation the first time a pair of tensors is seen).
 
     ``transport_dtype`` (torch.bfloat16 / torch.float16, with an fp32 model): ``value`` crosses xGMI -- and is sampled -- in that
     16-bit type, its gradient comes back through the reduce-scatter in it; sampling locations, attention weights and their
     gradients stay float32 (ABI v11 ``MSDA_*_LOC32``), the output is returned in float32.  Halves the bytes of both
     collectives (SURVEY f-3: value in the dtype the transport prefers) at the price of ``value`` rounded once to 16 bits
     (outputs within 5e-3 of the fp32 ones, tests/dist_worker.py)."""
+    if check_agreement:
+        check_ranks_agree(spatial_shapes, frame_table, group)
     out_dtype = None
     if transport_dtype is not None and value_chunk.dtype != transport_dtype:
         if value_chunk.dtype != torch.float32 or transport_dtype not in (torch.bfloat16, torch.float16):
@@ -161,15 +214,18 @@ def sharded_temporal_attention(value_chunk, n_frames, spatial_size, spatial_shap
 
 
 def sharded_temporal_attention_batch(clips, n_frames, spatial_size, spatial_shapes, level_start_index, frame_table,
-                                     group=None, transport_dtype=None):
+                                     group=None, transport_dtype=None, check_agreement=True):
     """Mode 2 for SEVERAL clips at once (a training step's batch, bench.py --mode sharded): every clip's all-gather is
     issued before the first kernel, so the collectives of clips 1.. travel over xGMI while the kernels of the clips
     before them run -- xGMI is point-to-point and a ring all-gather of one clip's ``value`` is bound by one link, so
     the next clip's shards are the cheapest thing to overlap it with.  ``clips``: a list of
     ``(value_chunk, loc_curr, aw_curr, loc_temp, aw_temp)`` as :func:`sharded_temporal_attention` takes them.
-    Returns the list of this rank's output rows, one ``[T, Lq_local, M*D]`` per clip.  Only the FORWARD collectives are
-    overlapped: backward runs one reduce-scatter per clip where autograd reaches it, and the compute stream waits for each
-    (its result is the next node's input)."""
+    Returns the list of this rank's output rows, one ``[T, Lq_local, M*D]`` per clip.  The BACKWARD collectives overlap the
+    same way (round 6): autograd runs a clip's kernel backward, then ``_FinishGatherRows.backward`` issues that clip's
+    reduce-scatter with ``async_op=True``, then the previous clip's kernel backward -- while the reduce-scatter travels -- and
+    the results are waited for at the end, where the value_proj gradients consume them."""
+    if check_agreement:
+        check_ranks_agree(spatial_shapes, frame_table, group)
     pending, out_dtypes = [], []
     for value_chunk, *_ in clips:
         out_dtype = None

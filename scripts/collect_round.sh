@@ -10,4 +10,5 @@ for pair in kernel_stats.csv:bench_kernel_stats.csv pmc_hbm.txt:pmc_hbm_traffic.
   [ -f "$O/${pair%%:*}" ] && cp "$O/${pair%%:*}" "profiles/$1_${pair##*:}"
 done
 [ -f "$O/hbm_traffic.json" ] && cp "$O/hbm_traffic.json" profiles/hbm_traffic.json
+[ -f "$O/onchip.json" ] && cp "$O/onchip.json" profiles/onchip.json
 ls -la profiles/$1_* profiles/hbm_traffic.json

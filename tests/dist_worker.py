@@ -62,10 +62,11 @@ def main():
     ftab = torch.from_numpy(d["ftab"]).to(device)
 
     # the backward collective must be the reduce-scatter an 8-GPU node runs (not an all-reduce stand-in): count the calls
-    calls = {"rs": 0, "ar": 0}
+    calls = {"rs": 0, "ar": 0, "rs_async": 0}
     real_rs, real_ar = dist.reduce_scatter_tensor, dist.all_reduce
     def counting_rs(*a, **k):
         calls["rs"] += 1
+        calls["rs_async"] += 1 if k.get("async_op") else 0
         return real_rs(*a, **k)
     def counting_ar(*a, **k):
         calls["ar"] += 1
@@ -123,6 +124,18 @@ def main():
     assert all(same(a, b) for a, b in zip(gb, (gv, glc, gac, glt, gat))), "batched form differs"
     dist.reduce_scatter_tensor, dist.all_reduce = real_rs, real_ar
     assert calls["rs"] == 5 and calls["ar"] == 0, calls       # plain, overlapped, 16-bit transport, two batched clips
+    assert calls["rs_async"] == 3, calls                      # overlapped + two batched clips: issued async, waited where consumed
+    # ranks that do not agree on the frame table (or the pyramid) fail -- all of them -- instead of sampling garbage
+    if world > 1:
+        bad_ftab = ftab.clone()
+        if rank == 1:
+            bad_ftab[0, 0] = (int(bad_ftab[0, 0]) + 1) % T
+        try:
+            cp.sharded_temporal_attention(v_chunk, T, S, shapes, lsi, bad_ftab, lc, ac, lt, at)
+            raise AssertionError("mismatching frame tables went unnoticed")
+        except RuntimeError as e:
+            assert "differ between the ranks" in str(e) and "[1]" in str(e), str(e)
+        cp.check_ranks_agree(shapes, ftab)                        # the good pair: cached, no collective
     # the ranges tile the query axis
     r = [cp.shard_range(Lq, world, k) for k in range(world)]
     assert r[0][0] == 0 and r[-1][1] == Lq and all(r[i][1] == r[i + 1][0] for i in range(world - 1))
