@@ -1,6 +1,9 @@
 """Randomised GPU parity sweep: op and fused temporal op against the CPU oracle over shapes that hit every
 template variant (lanes per row G = 1..64 for fp32, 16-bit storage, heads not a multiple of 8, 1..8 points,
-1..6 levels, odd query counts, windows with repeated frames)."""
+1..6 levels, odd query counts, windows with repeated frames).  Round 6: ~1000 configurations in the driver's own
+`-m gpu` run (the 50 000-configuration soak of scripts/fuzz_long.py stays a builder-run log), with the forward tile
+kernel's waves-per-tile knob at 1 / 2 / 5 / 8, random route pins (a pin never changes results) and the matrix-pipe
+scatter forced on the shapes it applies to."""
 import numpy as np
 import pytest
 import torch
@@ -15,8 +18,13 @@ def _rand_shapes(rng, L):
     return [(int(rng.integers(1, 14)), int(rng.integers(1, 17))) for _ in range(L)]
 
 
-@pytest.mark.parametrize("seed", range(64))
-def test_op_random_config_fp32(seed):
+TILE_WAVES = {4: "1", 5: "2", 6: "5", 7: "8"}          # seed % 8 -> MSDA_FWD_TILE_WAVES (untested until round 6)
+
+
+@pytest.mark.parametrize("seed", range(400))
+def test_op_random_config_fp32(seed, monkeypatch):
+    if seed % 8 in TILE_WAVES:
+        monkeypatch.setenv("MSDA_FWD_TILE_WAVES", TILE_WAVES[seed % 8])
     rng = np.random.default_rng(1000 + seed)
     D = int(rng.choice([4, 8, 12, 16, 20, 32, 64, 128, 256, 6]))
     M = int(rng.choice([1, 2, 3, 5, 8, 16]))
@@ -32,8 +40,8 @@ def test_op_random_config_fp32(seed):
         assert _maxabs(a, b) <= 1e-4 * max(1.0, np.abs(b).max()), cfg
 
 
-@pytest.mark.parametrize("seed", range(40))
-def test_temporal_random_config(seed):
+@pytest.mark.parametrize("seed", range(400))
+def test_temporal_random_config(seed, monkeypatch):
     rng = np.random.default_rng(2000 + seed)
     D = int(rng.choice([8, 16, 32, 64]))
     M = int(rng.choice([2, 4, 8]))
@@ -43,6 +51,10 @@ def test_temporal_random_config(seed):
     ftab = rng.integers(0, T, size=(T, W)).astype(np.int32)
     Lq = int(rng.integers(1, 50))
     dtype = [torch.float32, torch.float32, torch.bfloat16, torch.float16][seed % 4]
+    mfma = seed >= 40 and seed % 3 == 0                           # (the first 40 seeds are round 5's sweep, unchanged)
+    if mfma:        # the matrix-pipe scatter, forced: its shape class (D = 32, <= 4 points, >= 16 queries, >= 2 levels)
+        D, L, Pc, Pt, Lq = 32, max(L, 2), min(Pc, 4), min(Pt, 4), max(Lq, 16)
+        monkeypatch.setenv("MSDA_SCATTER_MFMA", "1")
     d = make_temporal_inputs(seed, T, W, M, D, Lq, _rand_shapes(rng, L), Pc, Pt, ftab=ftab, dtype=np.float64)
     if dtype != torch.float32:
         d = round_to(d, dtype)
@@ -50,8 +62,42 @@ def test_temporal_random_config(seed):
     ref = temporal_reference(*(np.asarray(d[k], dtype=np.float64) if d[k].dtype.kind == "f" else d[k] for k in keys))
     got = _run_temporal(d, dtype)
     tol = {torch.float32: 1e-4, torch.bfloat16: 3e-2, torch.float16: 6e-3}[dtype]
-    cfg = dict(D=D, M=M, L=L, Pc=Pc, Pt=Pt, T=T, W=W, Lq=Lq, dtype=str(dtype))
+    cfg = dict(D=D, M=M, L=L, Pc=Pc, Pt=Pt, T=T, W=W, Lq=Lq, dtype=str(dtype), mfma=mfma)
     for i, (a, b) in enumerate(zip(got, ref)):
         if dtype == torch.float32 and i in (2, 4):
             continue    # grad_loc in fp32 vs an fp64 oracle: cell flips at pixel borders (checked in fp32 above)
         assert _maxabs(a, b) <= tol * max(1.0, np.abs(b).max()), (cfg, i)
+
+
+PIN_CHOICES = {"fwd_rs": (0, 1), "fwd_rs_nt": (1, 2, 4), "fwd_tile_waves": (1, 2, 3), "bwd_rs": (0, 1), "bwd_rs_tpw": (1, 2),
+               "bwd_rs_fsplit": (0, 2, 4), "scatter_order": (1, 2), "scatter_mfma": (0, 1)}
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_route_pins_never_change_results(seed):
+    """include/msda.h: "results never depend on a pin".  A decoder-shaped call (D = 32: every kernel family applies) with a random
+    subset of route settings pinned for its own key, forward and backward, against the oracle."""
+    from devis_amd import _native
+    rng = np.random.default_rng(3000 + seed)
+    T = int(rng.integers(2, 5))
+    W, M, Lq = T - 1, 8, int(rng.integers(16, 70))
+    pyr = [[(12, 20), (6, 10)], [(23, 40), (12, 20), (6, 10)], [(9, 7), (5, 4)], [(16, 16), (8, 8), (4, 4), (2, 2)]][seed % 4]
+    L = len(pyr)
+    d = make_temporal_inputs(seed, T, W, M, 32, Lq, pyr, 4, int(rng.integers(1, 5)), dtype=np.float32)
+    S = int(sum(h * w for h, w in pyr))
+    picks = {k: int(rng.choice(v)) for k, v in PIN_CHOICES.items() if rng.random() < 0.5}
+    _native.load()
+    keys = [_native.route_key(b, 0, 1, T, W, S, M, 32, L, Lq, 4, d["loc_t"].shape[4], pyr) for b in (False, True)]
+    for k in keys:
+        _native.pin_route(k, picks)
+    try:
+        got = _run_temporal(d, torch.float32)
+    finally:
+        for k in keys:
+            _native.pin_route(k, "")
+    keys_ = ("value", "shapes", "lsi", "ftab", "loc_c", "aw_c", "loc_t", "aw_t", "grad_out")
+    ref = temporal_reference(*(np.asarray(d[k], dtype=np.float64) if d[k].dtype.kind == "f" else d[k] for k in keys_))
+    for i, (a, b) in enumerate(zip(got, ref)):
+        if i in (2, 4):
+            continue            # grad_loc in fp32 against the fp64 oracle: cell flips at pixel borders (checked in fp32 elsewhere)
+        assert _maxabs(a, b) <= 1e-4 * max(1.0, np.abs(b).max()), (picks, i)

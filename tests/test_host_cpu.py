@@ -225,7 +225,7 @@ def test_route_table_keys_pins_and_files(tmp_path):
     try:
         _native.pin_route(kf, {"fwd_rs": 1, "fwd_rs_nt": 2})
         _native.pin_route(kf, "fwd_win=1")                         # replaces
-        _native.pin_route(kb, {"bwd_rs_fsplit": 4, "scatter_order": 1})
+        _native.pin_route(kb, {"bwd_rs_fsplit": 4, "scatter_order": 1, "scatter_mfma": 0})
         assert _native.route_count() == before + 2
         with pytest.raises(RuntimeError, match="cannot parse"):
             _native.pin_route(kb, "tiles=3")
