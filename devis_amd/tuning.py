@@ -34,7 +34,8 @@ PYRAMIDS = {
     "B": [(100, 167), (50, 84), (25, 42), (13, 21)],     # 800x1333
 }
 _KNOB_ENV = {"fwd_rs": "MSDA_FWD_RS", "fwd_rs_nt": "MSDA_FWD_RS_NT", "fwd_win": "MSDA_FWD_WIN", "fwd_tile_waves": "MSDA_FWD_TILE_WAVES",
-             "bwd_rs": "MSDA_BWD_RS", "bwd_rs_tpw": "MSDA_BWD_RS_TPW", "bwd_rs_fsplit": "MSDA_BWD_RS_FSPLIT", "bwd_win": "MSDA_BWD_WIN"}
+             "bwd_rs": "MSDA_BWD_RS", "bwd_rs_tpw": "MSDA_BWD_RS_TPW", "bwd_rs_fsplit": "MSDA_BWD_RS_FSPLIT", "bwd_win": "MSDA_BWD_WIN",
+             "scatter_mfma": "MSDA_SCATTER_MFMA"}
 FWD_ROUTES = (("tile", {"fwd_rs": 0, "fwd_win": 0}), ("tile3", {"fwd_rs": 0, "fwd_win": 0, "fwd_tile_waves": 3}),
               ("rs1", {"fwd_rs": 1, "fwd_rs_nt": 1, "fwd_win": 0}), ("rs2", {"fwd_rs": 1, "fwd_rs_nt": 2, "fwd_win": 0}),
               ("rs4", {"fwd_rs": 1, "fwd_rs_nt": 4, "fwd_win": 0}), ("win", {"fwd_win": 1}))
@@ -43,7 +44,9 @@ GATHER_ROUTES = (("tile", {"bwd_rs": 0, "bwd_win": 0}), ("rs1", {"bwd_rs": 1, "b
                  ("rs4", {"bwd_rs": 1, "bwd_rs_tpw": 4, "bwd_rs_fsplit": 0, "bwd_win": 0}),
                  ("fs2", {"bwd_rs": 1, "bwd_rs_fsplit": 2, "bwd_win": 0}), ("fs4", {"bwd_rs": 1, "bwd_rs_fsplit": 4, "bwd_win": 0}),
                  ("win", {"bwd_win": 1}))
-SCATTER_ROUTES = (("levels", {"scatter_order": 1}), ("image", {"scatter_order": 2}))
+# (round 6: + the matrix-pipe scatter of the coarse levels forced on / off, alone and with the image order)
+SCATTER_ROUTES = (("levels", {"scatter_order": 1}), ("image", {"scatter_order": 2}), ("mfma", {"scatter_mfma": 1}),
+                  ("nomfma", {"scatter_mfma": 0}), ("image+mfma", {"scatter_order": 2, "scatter_mfma": 1}))
 MARGIN = 0.95           # an alternative is pinned only when it takes less than this fraction of the rules' time (3 % pins flipped between two audits)
 
 
@@ -249,7 +252,7 @@ def tune(spatial_shapes, dtype=torch.float32, clips=1, Lq=300, kind="decoder", f
     if verbose:
         f, b = report["forward"], report["backward"]
         gather_pinned = bool(b["pinned"]) and any(k.startswith("bwd_") for k in b["pinned"])
-        scatter_pinned = bool(b["pinned"]) and "scatter_order" in b["pinned"]
+        scatter_pinned = bool(b["pinned"]) and ("scatter_order" in b["pinned"] or "scatter_mfma" in b["pinned"])
         print("%-14s %-5s%s clips %-3d Lq %-6d %s | fwd %.4f %s -> %s | gather %.4f %s -> %s | scatter %.4f %s -> %s" % (
             kind, str(dtype).split(".")[1], "+loc32" if loc_dtype != dtype else "", clips, d["Lq"], "x".join(str(v) for v in shapes[0]),
             f["auto_ms"], f["times"], f["best"] if f["pinned"] else "-",

@@ -27,6 +27,13 @@ CASES = {
     "decB": lambda: ab.temporal_case(8, "B", "uniform", 300, torch.float32, 20),
     "dec60": lambda: ab.temporal_case(16, "A", "uniform", 60, torch.float32, 30),
     "plain": lambda: ab.plain_case(bench.PYRAMIDS["A"], 48, 300, "uniform", torch.float32, 30),
+    "dec8": lambda: ab.temporal_case(8, "A", "uniform", 300, torch.float32, 30),
+    "dec2": lambda: ab.temporal_case(2, "A", "uniform", 300, torch.float32, 30),
+    "dec32": lambda: ab.temporal_case(32, "A", "uniform", 300, torch.float32, 10),
+    "dec180": lambda: ab.temporal_case(16, "A", "uniform", 180, torch.float32, 30),
+    # encoder-shaped calls (one query per pixel): few, very long items -- outside the automatic rule, forced here for the record
+    "encA": ab.CASES["encA"], "encA4": lambda: ab.temporal_case(4, "A", "local", 4820, torch.float32, 6),
+    "encB": ab.CASES["encB"], "cfg1": ab.CASES["cfg1"], "cfg4enc": ab.CASES["cfg4enc"],
 }
 
 
