@@ -672,7 +672,12 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
         // and at least 16 queries (a step is 16 groups).  Automatic for decoder-shaped batches: an item walks (1 + sources) x Lq
         // groups in 8 waves, so a handful of items of encoder length would be the kernel's whole duration.
         int l0 = p.L, tiles = 0;
-        if (knobs().scatter_mfma != 0 && p.shapes_host && p.Lq >= 16 && p.L >= 2 && pg.own_levels == p.L) {
+        // (its loads are buffer loads with 32-bit byte offsets inside one clip: grad_out and the point arrays of a clip below 2 GiB)
+        const long long lesz = (dtype == MSDA_BF16_LOC32 || dtype == MSDA_F16_LOC32) ? 4 : esz;
+        const long long clip_rows = (long long)p.frames * p.Lq;
+        const bool mfma_fits = clip_rows * p.M * p.D * esz < 0x7fffffffLL &&
+                               clip_rows * p.M * std::max((long long)p.LA * p.PA, (long long)p.LB * p.PB) * 2 * lesz < 0x7fffffffLL;
+        if (knobs().scatter_mfma != 0 && mfma_fits && p.shapes_host && p.Lq >= 16 && p.L >= 2 && pg.own_levels == p.L) {
             long long px = 0;
             for (int l = p.L - 1; l >= 1 && l >= p.L - 2; --l) {
                 const long long hw = p.shapes_host[2 * l] * p.shapes_host[2 * l + 1];

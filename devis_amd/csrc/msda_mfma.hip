@@ -115,7 +115,7 @@ msda_bwd_value_mfma_kernel(const Params p, int l0)
     const int g = lane >> 2, pt = lane & 3;               // builder role: point pt of group g of the step
     const int n = lane & 31, kh = lane >> 5;              // MFMA role: channel n / pixel n of a tile, k-chunk kh
     const unsigned wr_hi = lds_addr(Ahi) + (unsigned)((g >> 3) * NP) * 16u + (unsigned)(g & 7) * 2u;      // + pixel * 16
-    const unsigned trash = (unsigned)npix * 16u;          // row npix of the tile: written, never stored
+    const unsigned wr_trash = wr_hi + (unsigned)npix * 16u;       // row npix of the tile: written, never stored
     const unsigned char *rd_hi = Ahi + (kh * NP + n) * 16, *rd_lo = rd_hi + kTile;
     // lane parts of a point's index: current-frame points [.., M, LA, PA], temporal points [.., M, LB, PB]
     const unsigned lane_c = (unsigned)(g * p.M * p.LA * p.PA + pt), lane_t = (unsigned)(g * p.M * p.LB * p.PB + pt);
@@ -243,7 +243,11 @@ msda_bwd_value_mfma_kernel(const Params p, int l0)
 #pragma unroll
             for (int li = 0; li < NL; ++li) { xs[li] = raw.x[li]; ys[li] = raw.y[li]; as[li] = raw.a[li]; }
             advance(cur);
+#if defined(MSDA_MFMA_EXP) && (MSDA_MFMA_EXP & 4)        // timing only: no loads inside the loop (every step reuses the first one's)
+            asm volatile("" : "+v"(raw.x[0]), "+v"(raw.y[0]), "+v"(raw.a[0]));
+#else
             issue(cur, raw);                                  // the next step's loads fly under this step's work
+#endif
             unsigned cells[NL][4];
 #pragma unroll
             for (int li = 0; li < NL; ++li) {
@@ -266,17 +270,23 @@ msda_bwd_value_mfma_kernel(const Params p, int l0)
                 // ---- cells; corners outside the map (cuh:56-78) and skipped points go to the trash row
                 const bool rv0 = inr && (unsigned)hl < (unsigned)H[li], rv1 = inr && (unsigned)(hl + 1) < (unsigned)H[li];
                 const bool cv0 = (unsigned)wl < (unsigned)Wd[li], cv1 = (unsigned)(wl + 1) < (unsigned)Wd[li];
-                const unsigned c00 = (unsigned)(poff[li] + hl * Wd[li] + wl) * 16u, wrow = (unsigned)Wd[li] * 16u;
-                cells[li][0] = wr_hi + ((rv0 && cv0) ? c00 : trash); cells[li][1] = wr_hi + ((rv0 && cv1) ? c00 + 16u : trash);
-                cells[li][2] = wr_hi + ((rv1 && cv0) ? c00 + wrow : trash); cells[li][3] = wr_hi + ((rv1 && cv1) ? c00 + wrow + 16u : trash);
+                // (wr_hi folded into the two candidates first: one select per cell, no add behind it)
+                const unsigned c00 = wr_hi + (unsigned)(poff[li] + hl * Wd[li] + wl) * 16u, wrow = (unsigned)Wd[li] * 16u;
+                cells[li][0] = (rv0 && cv0) ? c00 : wr_trash; cells[li][1] = (rv0 && cv1) ? c00 + 16u : wr_trash;
+                cells[li][2] = (rv1 && cv0) ? c00 + wrow : wr_trash; cells[li][3] = (rv1 && cv1) ? c00 + wrow + 16u : wr_trash;
+                // hi = E(t) (round to nearest), lo = E(t - hi), two cells per packed conversion; the low half of a pair leaves with
+                // ds_write_b16, the high half with ds_write_b16_d16_hi: no shifts or masks between the conversion and the stores
                 const float tt[4] = {t00, t01, t10, t11};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const E hi = (E)tt[c];
-                    const E lo = (E)(tt[c] - (float)hi);
-                    const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, hi), lb = (unsigned)__builtin_bit_cast(unsigned short, lo);
+                for (int c = 0; c < 4; c += 2) {
+                    typedef __attribute__((ext_vector_type(2))) E E2;
+                    const E2 hi = {(E)tt[c], (E)tt[c + 1]};
+                    const E2 lo = {(E)(tt[c] - (float)hi[0]), (E)(tt[c + 1] - (float)hi[1])};
+                    const unsigned hb = __builtin_bit_cast(unsigned, hi), lb = __builtin_bit_cast(unsigned, lo);
                     asm volatile("ds_write_b16 %0, %1" : : "v"(cells[li][c]), "v"(hb) : "memory");
+                    asm volatile("ds_write_b16_d16_hi %0, %1" : : "v"(cells[li][c + 1]), "v"(hb) : "memory");
                     asm volatile("ds_write_b16 %0, %1 offset:%2" : : "v"(cells[li][c]), "v"(lb), "n"(kTile) : "memory");
+                    asm volatile("ds_write_b16_d16_hi %0, %1 offset:%2" : : "v"(cells[li][c + 1]), "v"(lb), "n"(kTile) : "memory");
                 }
             }
             // ---- the products, two pixel tiles at a time, the next pair's operands read under this pair's instructions (the LDS
@@ -295,6 +305,11 @@ msda_bwd_value_mfma_kernel(const Params p, int l0)
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 if (b + 1 < NB) read_pair(b + 1, fh[(b + 1) & 1], fl[(b + 1) & 1]);
+#if defined(MSDA_MFMA_EXP) && (MSDA_MFMA_EXP & 1)        // timing only: one product instead of the 20-30 (the operands still read)
+                if (b == 0) acc[0] = mma(fh[0][0], bhi, acc[0]);
+#pragma unroll
+                for (int u = 0; u < TB; ++u) if (b * TB + u < MT) { acc[b * TB + u][0] += (float)fh[b & 1][u][0] + (float)fl[b & 1][u][0] + (float)blo[0]; }
+#else
 #pragma unroll
                 for (int u = 0; u < TB; ++u) if (b * TB + u < MT) acc[b * TB + u] = mma(fh[b & 1][u], bhi, acc[b * TB + u]);
 #pragma unroll
@@ -303,6 +318,7 @@ msda_bwd_value_mfma_kernel(const Params p, int l0)
 #pragma unroll
                     for (int u = 0; u < TB; ++u) if (b * TB + u < MT) acc[b * TB + u] = mma(fh[b & 1][u], blo, acc[b * TB + u]);
                 }
+#endif
 #if MSDA_MFMA_SB
                 __builtin_amdgcn_sched_barrier(0);
 #endif
