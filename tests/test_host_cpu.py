@@ -46,7 +46,7 @@ def test_build_info_and_timing_only_guards(tmp_path, monkeypatch):
         probe = tmp_path / "probe.hip"
         probe.write_text('#include "msda_common.h"\n')
         base = [hipcc, "--offload-arch=gfx950", "-E", "-I", os.path.join(ROOT, "include"), "-I", build.CSRC, str(probe), "-o", os.devnull]
-        for macro in ("-DMSDA_RS_EXP=6", "-DMSDA_WIN_EXP=1"):
+        for macro in ("-DMSDA_RS_EXP=6", "-DMSDA_WIN_EXP=1", "-DMSDA_MFMA_EXP=5"):
             r = subprocess.run(base + [macro], capture_output=True, text=True)
             assert r.returncode != 0 and "MSDA_TIMING_ONLY_BUILD" in r.stderr, (macro, r.stderr[-400:])
             r = subprocess.run(base + [macro, "-DMSDA_TIMING_ONLY_BUILD"], capture_output=True, text=True)
