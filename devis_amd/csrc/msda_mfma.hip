@@ -265,7 +265,11 @@ msda_bwd_value_mfma_kernel(const Params p, int l0)
                     const float th0 = tent(quad_bcast<J>(h_im) - r0f) * quad_bcast<J>(a), th1 = tent(quad_bcast<J>(h_im) - r1f) * quad_bcast<J>(a); \
                     const float tw0 = tent(quad_bcast<J>(w_im) - c0f), tw1 = tent(quad_bcast<J>(w_im) - c1f); \
                     t00 = fmaf(th0, tw0, t00); t01 = fmaf(th0, tw1, t01); t10 = fmaf(th1, tw0, t10); t11 = fmaf(th1, tw1, t11); }
+#if defined(MSDA_MFMA_EXP) && (MSDA_MFMA_EXP & 16)       // timing only: one point of the quad instead of four
+                MSDA_MERGE(0)
+#else
                 MSDA_MERGE(0) MSDA_MERGE(1) MSDA_MERGE(2) MSDA_MERGE(3)
+#endif
 #undef MSDA_MERGE
                 // ---- cells; corners outside the map (cuh:56-78) and skipped points go to the trash row
                 const bool rv0 = inr && (unsigned)hl < (unsigned)H[li], rv1 = inr && (unsigned)(hl + 1) < (unsigned)H[li];
@@ -283,10 +287,14 @@ msda_bwd_value_mfma_kernel(const Params p, int l0)
                     const E2 hi = {(E)tt[c], (E)tt[c + 1]};
                     const E2 lo = {(E)(tt[c] - (float)hi[0]), (E)(tt[c + 1] - (float)hi[1])};
                     const unsigned hb = __builtin_bit_cast(unsigned, hi), lb = __builtin_bit_cast(unsigned, lo);
+#if defined(MSDA_MFMA_EXP) && (MSDA_MFMA_EXP & 8)        // timing only: the cells are computed and not written
+                    asm volatile("" : : "v"(cells[li][c]), "v"(cells[li][c + 1]), "v"(hb), "v"(lb));
+#else
                     asm volatile("ds_write_b16 %0, %1" : : "v"(cells[li][c]), "v"(hb) : "memory");
                     asm volatile("ds_write_b16_d16_hi %0, %1" : : "v"(cells[li][c + 1]), "v"(hb) : "memory");
                     asm volatile("ds_write_b16 %0, %1 offset:%2" : : "v"(cells[li][c]), "v"(lb), "n"(kTile) : "memory");
                     asm volatile("ds_write_b16_d16_hi %0, %1 offset:%2" : : "v"(cells[li][c + 1]), "v"(lb), "n"(kTile) : "memory");
+#endif
                 }
             }
             // ---- the products, two pixel tiles at a time, the next pair's operands read under this pair's instructions (the LDS
@@ -329,8 +337,12 @@ msda_bwd_value_mfma_kernel(const Params p, int l0)
             for (int li = 0; li < NL; ++li)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
+#if defined(MSDA_MFMA_EXP) && (MSDA_MFMA_EXP & 8)
+                    asm volatile("" : : "v"(cells[li][c]), "v"(zero));
+#else
                     asm volatile("ds_write_b16 %0, %1" : : "v"(cells[li][c]), "v"(zero) : "memory");
                     asm volatile("ds_write_b16 %0, %1 offset:%2" : : "v"(cells[li][c]), "v"(zero), "n"(kTile) : "memory");
+#endif
                 }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
