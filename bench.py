@@ -81,6 +81,12 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra keys for the other BASELINE configs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of an N > 1 run (nccl = RCCL; gloo only for --share-device test runs)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="TEST ONLY: every rank uses cuda:0 (exercises the N-rank protocol -- rendezvous, barriers, max-over-ranks, "
+                         "ranks_seen -- on a box with one GPU; RCCL refuses two ranks on one device, so it needs --dist-backend gloo; "
+                         "the line says so and its value is not a scaling figure)")
     return ap.parse_args()
 
 
@@ -585,9 +591,11 @@ def launch_ranks(n, argv, script=None, check_devices=True, timeout=None):
 
 def main():
     args = parse_args()
+    if args.share_device and args.dist_backend != "gloo":
+        sys.exit("bench.py: --share-device needs --dist-backend gloo (RCCL refuses two ranks on one device)")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher around us: be the launcher (a child process; this one has not touched the GPU)
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], check_devices=not args.share_device))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -597,13 +605,20 @@ def main():
                  "`python bench.py --gpus %d` start its own ranks)" % (args.gpus, world, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.share_device:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         sys.exit("bench.py: rank %d has no device (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # tensors of the few scalar reductions of the protocol: on the device for RCCL, on the host for gloo
+    red_dev = device if args.dist_backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)   # RCCL on ROCm
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)   # RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
     elif args.mode == "sharded":                            # single process: degenerate collectives
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -696,7 +711,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     ms_per_step = elapsed / args.steps * 1e3
@@ -733,7 +748,7 @@ def main():
         med = {k: sorted(v)[len(v) // 2] for k, v in times.items()}
         if world > 1:
             import torch.distributed as dist
-            tt = torch.tensor([med["dense"], med["padded"]], device=device, dtype=torch.float64)
+            tt = torch.tensor([med["dense"], med["padded"]], device=red_dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             med = {"dense": tt[0].item(), "padded": tt[1].item()}
         padded_line = {"layout": "value rows padded by one head slot (what devis_amd's value_proj writes)",
@@ -944,7 +959,7 @@ def main():
     ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
-        ones = torch.ones(1, device=device, dtype=torch.int32)
+        ones = torch.ones(1, device=red_dev, dtype=torch.int32)
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         ranks_seen = int(ones.item())
     others = None
@@ -970,6 +985,8 @@ def main():
                        else "one clip sharded x%d (all-gather value / reduce-scatter grad_value over RCCL, all gathers of a step in "
                             "flight before its first kernel, %s transport)" % (world, args.transport)},
             "roofline": roofline, "cpu_baseline": cpu, "ranks_seen": ranks_seen,
+            **({"test_run": "--share-device: all %d ranks on ONE GPU over gloo -- the N-rank protocol only, not a scaling figure" % world}
+               if args.share_device else {}),
             "prewarm_seconds": args.prewarm_seconds,
         }
         line.update(extra)

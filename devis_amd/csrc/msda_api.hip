@@ -688,13 +688,15 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             // Automatic rule (profiles/r06_logs/mfma_check.log; scatter pass, owner kernel alone -> with this kernel, ms): the two coarse
             // levels of the 360x640 pyramid cost the owner kernel 0.19 ms at 16 clips of 300 queries and this one 0.12 (0.563 -> 0.502;
             // bf16 0.564 -> 0.473; 4 / 8 / 32 clips 0.159 -> 0.148 / 0.289 -> 0.265 / 1.096 -> 1.064); the single 273-pixel level of the
-            // 800x1333 pyramid 0.553 -> 0.512; the 96-pixel last level of the SwinL pyramid a wash (0.683 -> 0.675: not worth a launch).
+            // 800x1333 pyramid 0.553 -> 0.512 (with the owner kernel's bands rotated unconditionally; see below).
             // It needs items to fill the chip -- 2 clips (96 items) 0.089 -> 0.110, one clip 0.053 -> 0.088 -- and items long enough to
             // pay for their zero-fill and reduction: the plain op on 48 images x 300 queries (19 steps per item) 0.100 -> 0.109.  Encoder-
             // shaped calls (one query per pixel: tens of thousands of groups per item) win once there are enough items -- 4 clips at
             // 360x640: 1.924 -> 1.733 -- and lose with one clip's 48 (0.556 -> 0.987; BASELINE configs[1], 64 items: 0.644 -> 0.688).
             const bool enough = items >= 128 && per_item >= 512 && (per_item <= 8192 || items >= 192);
-            if (tiles && knobs().scatter_mfma < 0 && !(enough && (p.L - l0 == 2 || px >= 200))) { l0 = p.L; tiles = 0; }
+            // (after the owner kernel's band rotation became conditional -- msda_scatter.hip -- the 96-pixel last level of the SwinL
+            // pyramid pays as well: 16 clips 0.679 -> 0.636; the 273-pixel one of 800x1333 is level: 0.514 -> 0.510)
+            if (tiles && knobs().scatter_mfma < 0 && !(enough && (p.L - l0 == 2 || px >= 64))) { l0 = p.L; tiles = 0; }
         }
         if (l0 < p.L) pg.own_levels = l0;
         if (!(tiles && knobs().scatter_part == 2))

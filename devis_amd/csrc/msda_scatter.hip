@@ -581,6 +581,15 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
     const int clips = p.groups / p.frames;
     const unsigned n_items = (unsigned)clips * (unsigned)p.frames * (unsigned)p.M * (unsigned)NB;      // (< 2^31: host)
     const bool dynamic = p.workspace != nullptr && (dbg & 16) == 0 && n_items < 16u * gridDim.x;
+    // static stride only: does the walk of one workgroup -- (item / M) in steps of gridDim / M -- share a factor with the band count?
+    // (then it meets the same few bands of every frame and prepare() rotates the bands by the (clip, frame) index)
+    unsigned stride_gcd = 1u;
+    {
+        unsigned a = max(gridDim.x / (unsigned)max(p.M, 1), 1u), b = (unsigned)max(NB, 1);
+        while (b) { const unsigned t = a % b; a = b; b = t; }
+        stride_gcd = a;
+    }
+    const bool rotate_bands = stride_gcd > 1u && (dbg & 4096) == 0;
     const bool clip_major = (long long)p.Lq * (1 + p.window) <= 4096;       // see prepare()
     const int lane8 = blockIdx.x % 8;
     const int strideA = p.M * p.LA * p.PA, strideB = p.M * p.LB * p.PB;      // loc/attn elements per query
@@ -636,14 +645,15 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
                 f = (int)(rest % F);
                 if (!clip_major) clip = (int)(rest / F);
             } else {
-                // static stride: the bands of one (clip, frame) adjacent, ROTATED by the (clip, frame) index -- a workgroup walks
-                // (item / M) in steps of gridDim / M (64), so with a band count that shares a factor with it (24 bands: every third
-                // band only) it saw the same few bands of every frame, all heavy or all light (round 6: the 800x1333 pyramid without
-                // its last level 0.51 -> 0.67 ms); the rotation walks all of them (MSDA_SCATTER_DBG = 4096: without it)
+                // static stride: the bands of one (clip, frame) adjacent.  A workgroup walks (item / M) in steps of gridDim / M (64):
+                // with a band count that shares a factor with it (24 bands: every third band only) it would meet the same few bands
+                // of every frame, all heavy or all light (round 6: the 800x1333 pyramid without its last level 0.51 -> 0.67 ms), so
+                // THEN the bands are rotated by the (clip, frame) index (0.445 ms; MSDA_SCATTER_DBG = 4096: never).  Without a common
+                // factor the plain order stays: rotating it cost the same pyramid WITH its last level (25 bands) 0.516 -> 0.553 ms.
                 m = (int)(item % M);
                 unsigned rest = item / M;
                 const unsigned fc = rest / (unsigned)NB;
-                part = (int)((rest + ((dbg & 4096) ? 0u : fc)) % (unsigned)NB);
+                part = (int)((rest + (rotate_bands ? fc : 0u)) % (unsigned)NB);
                 f = (int)(fc % F);
                 clip = (int)(fc / F);
                 while (l + 1 < L && s_first[l + 1] <= part) ++l;
