@@ -177,3 +177,46 @@ def test_matrix_pipe_scatter_fills_nan_when_the_host_copy_of_the_shapes_lied():
     torch.cuda.synchronize()
     first = real[0][0] * real[0][1]
     assert torch.isnan(gv[:, first:]).all() and not torch.isnan(gv[:, :first]).any()
+
+
+def test_matrix_pipe_scatter_replays_from_a_hip_graph(monkeypatch):
+    """The backward with the matrix-pipe kernel only enqueues work (buffer resources built in the kernel, no host reads, no
+    allocation): captured in a HIP graph together with the forward, its replay equals the eager call on new inputs."""
+    from devis_amd import _native
+    from devis_amd.functions import MSDeformAttnTemporalFunction
+    monkeypatch.setenv("MSDA_SCATTER_MFMA", "1")
+    T, Lq, clips = 4, 40, 2
+    ds = [make_temporal_inputs(950 + c, T, T - 1, 8, 32, Lq, PYR_A, 4, 4) for c in range(clips)]
+    cat = {k: (np.concatenate([x[k] for x in ds], 0) if k not in ("shapes", "lsi", "ftab") else ds[0][k]) for k in ds[0]}
+    dev = lambda k: torch.from_numpy(cat[k]).to(DEV)
+    shapes, lsi, ftab = dev("shapes"), dev("lsi"), dev("ftab")
+    static = [dev(k).requires_grad_(True) for k in ("value", "loc_c", "aw_c", "loc_t", "aw_t")]
+    go = dev("grad_out")
+    _native.shapes_hint(shapes)                         # the host copy, outside the capture
+
+    def step():
+        out = MSDeformAttnTemporalFunction.apply(static[0], shapes, lsi, ftab, *static[1:], clips)
+        return (out,) + torch.autograd.grad(out, static, go)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = step()
+    # new inputs into the captured tensors, replay, compare with an eager call on the same inputs
+    fresh = [make_temporal_inputs(970 + c, T, T - 1, 8, 32, Lq, PYR_A, 4, 4) for c in range(clips)]
+    with torch.no_grad():
+        for t, k in zip(static, ("value", "loc_c", "aw_c", "loc_t", "aw_t")):
+            t.copy_(torch.from_numpy(np.concatenate([x[k] for x in fresh], 0)).to(DEV))
+    graph.replay()
+    torch.cuda.synchronize()
+    got = [x.clone() for x in captured]
+    want, routes = _routes_of_backward(step)
+    torch.cuda.synchronize()
+    assert "matrix-pipe" in routes[0]
+    for i, (a, b) in enumerate(zip(got, want)):
+        tol = 2e-5 if i == 1 else 1e-6                  # (grad_value: the owner kernel's list order varies from run to run)
+        assert torch.allclose(a, b, rtol=0, atol=tol * max(1.0, float(b.abs().max()))), i
