@@ -27,9 +27,9 @@ class BuildWithHip(build_py):
 
 setup(
     name="devis-amd",
-    version="0.5.0",       # (also in pyproject.toml: setuptools < 61 does not read the [project] table)
+    version="0.6.0",       # (also in pyproject.toml: setuptools < 61 does not read the [project] table)
     packages=["devis_amd", "devis_amd.functions", "devis_amd.modules"],
-    package_data={"devis_amd": ["libmsda_hip.so", "libmsda_hip.srchash", "csrc/*", "include/*", "routes.json"]},
+    package_data={"devis_amd": ["libmsda_hip.so", "libmsda_hip.srchash", "csrc/*.hip", "csrc/*.h", "csrc/*.inc", "include/*.h", "routes.json"]},
     py_modules=["MultiScaleDeformableAttention"],
     package_dir={"": "integration", "devis_amd": "devis_amd"},
     cmdclass={"build_py": BuildWithHip},
