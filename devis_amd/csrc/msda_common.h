@@ -24,7 +24,7 @@
 // measure floors -- profiles/NEGATIVE_RESULTS.md) may only be compiled into a library that says what it is: the build must also
 // define MSDA_TIMING_ONLY_BUILD, which makes msda_build_info() / msda_last_route() announce it and every entry point refuse to
 // run unless MSDA_ENABLE_HOOKS=1 (msda_api.hip).  A stray -D alone does not compile.
-#if defined(MSDA_RS_EXP) || defined(MSDA_WIN_EXP) || defined(MSDA_MFMA_EXP)
+#if defined(MSDA_RS_EXP) || defined(MSDA_WIN_EXP) || defined(MSDA_MFMA_EXP) || defined(MSDA_MFMA_TRACE)
 #  if !defined(MSDA_TIMING_ONLY_BUILD)
 #    error "MSDA_RS_EXP / MSDA_WIN_EXP / MSDA_MFMA_EXP produce wrong results by construction: also pass -DMSDA_TIMING_ONLY_BUILD (the library then refuses to run without MSDA_ENABLE_HOOKS=1 and labels its routes)"
 #  endif

@@ -35,6 +35,17 @@
 #ifndef MSDA_MFMA_TB
 #define MSDA_MFMA_TB 2      // pixel tiles whose operands are read together (experiment builds: see profiles/r06_logs)
 #endif
+// Timing-only build (-DMSDA_MFMA_TRACE beside -DMSDA_TIMING_ONLY_BUILD; scripts/mfma_trace.py): cycle stamps at the phase boundaries
+// of an item; every wave leaves its per-phase sums in the first pixels of its frame's LEVEL-0 grad_value (run with MSDA_SCATTER_PART=2).
+#if defined(MSDA_MFMA_TRACE)
+#define MSDA_TR(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long tr_now = __builtin_readcyclecounter(); \
+                     tr[k] += (unsigned)(tr_now - tr_t); tr_t = tr_now; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define MSDA_TR(k)
+#endif
+#ifndef MSDA_MFMA_RED
+#define MSDA_MFMA_RED 2     // accumulator rows a wave sums at a time in the reduction
+#endif
 #ifndef MSDA_MFMA_SB
 #define MSDA_MFMA_SB 1      // scheduling barrier behind every batch of tiles (bounds the live operand registers)
 #endif
@@ -85,6 +96,7 @@ msda_bwd_value_mfma_kernel(const Params p, int l0)
     using V = typename X::V;
     constexpr int D = 32, NP = mfma_rows(MT), kTile = mfma_tile_bytes(MT), kPhase = mfma_phase_tiles(MT), kLds = mfma_lds_bytes(MT, NW);
     constexpr bool kSplitG = sizeof(T) == 4;
+    constexpr int kRedRows = MSDA_MFMA_RED;
     extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char *Ahi = lds + wave * (2 * kTile), *Alo = Ahi + kTile;
@@ -126,6 +138,10 @@ msda_bwd_value_mfma_kernel(const Params p, int l0)
 
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int m = item % p.M, gf = item / p.M, f = gf % p.frames, clip = gf / p.frames;
+#if defined(MSDA_MFMA_TRACE)
+        unsigned tr[16] = {};
+        unsigned long long tr_t = __builtin_readcyclecounter();
+#endif
         // the tiles are zero before any wave writes a cell (first item, and after every reduction, which borrows them)
         for (int i = tid * 16; i < kLds; i += NW * 64 * 16) *reinterpret_cast<u32x4 *>(lds + i) = u32x4{0u, 0u, 0u, 0u};
         // sources reading frame f: lane s of every wave holds source s (-1 = the frame's own current-frame points, else t * window
@@ -174,14 +190,21 @@ msda_bwd_value_mfma_kernel(const Params p, int l0)
         // last step of a source starts at Lq - 16 and masks the groups the step before it has done: every step reads 16 valid
         // rows.  Steps beyond the item's last repeat it (their loads are issued and never used).
         struct Cursor { int s, j, temporal, points; unsigned pts0, go0, pts_row; };
+        // (a source's constants are worked out once per item by the lane that holds it -- a division and five kernel arguments --
+        // and a wave entering a source reads them with four readlanes: it does so every second or third of its steps)
+        const int src_l = lane < nsrc ? my_src : -1;
+        const int t_l = src_l < 0 ? f : src_l / win, w_l = src_l < 0 ? 0 : src_l - t_l * win;
+        const int points_l = src_l < 0 ? p.PA : p.PB, levels_l = src_l < 0 ? p.LA : p.LB;
+        const unsigned pts_row_l = (unsigned)(p.M * levels_l * points_l);                          // point elements per query row
+        const unsigned pts0_l = (unsigned)(t_l * p.Lq) * pts_row_l + (unsigned)((m * levels_l + (src_l < 0 ? l0 : w_l * p.L + l0)) * points_l);
+        const unsigned go0_l = ((unsigned)(t_l * p.Lq) * (unsigned)MD + (unsigned)(m * D)) * (unsigned)sizeof(T);
         auto enter_source = [&](Cursor &c) {
-            const int src = __builtin_amdgcn_readlane(my_src, min(c.s, nsrc - 1));
-            const int t_src = src < 0 ? f : src / win, w_src = src < 0 ? 0 : src - t_src * win;
-            c.temporal = src < 0 ? 0 : 1;
-            c.points = src < 0 ? p.PA : p.PB;
-            c.pts_row = (unsigned)(p.M * (src < 0 ? p.LA : p.LB) * c.points);                     // point elements per query row
-            c.pts0 = (unsigned)(t_src * p.Lq) * c.pts_row + (unsigned)((m * (src < 0 ? p.LA : p.LB) + (src < 0 ? l0 : w_src * p.L + l0)) * c.points);
-            c.go0 = ((unsigned)(t_src * p.Lq) * (unsigned)MD + (unsigned)(m * D)) * (unsigned)sizeof(T);
+            const int sl = min(c.s, nsrc - 1);
+            c.temporal = sl > 0 ? 1 : 0;                    // (lane 0 holds the frame's own current-frame points)
+            c.points = __builtin_amdgcn_readlane(points_l, sl);
+            c.pts_row = (unsigned)__builtin_amdgcn_readlane((int)pts_row_l, sl);
+            c.pts0 = (unsigned)__builtin_amdgcn_readlane((int)pts0_l, sl);
+            c.go0 = (unsigned)__builtin_amdgcn_readlane((int)go0_l, sl);
         };
         auto advance = [&](Cursor &c) {
             c.j += NW;
@@ -225,7 +248,13 @@ msda_bwd_value_mfma_kernel(const Params p, int l0)
         enter_source(cur);
         Raw raw;
         issue(cur, raw);
+        MSDA_TR(0)
         for (int st = wave; st < nsteps; st += NW) {
+#if defined(MSDA_MFMA_TRACE)
+            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+            MSDA_TR(1)
+            ++tr[15];
+#endif
             const bool act = g >= 16 * cur.j - min(16 * cur.j, p.Lq - 16) && pt < cur.points;
             // ---- this step's values out of the load registers: the B operand G[k = 8 kh + j][n], the points
             V bhi, blo;
@@ -248,6 +277,7 @@ msda_bwd_value_mfma_kernel(const Params p, int l0)
 #else
             issue(cur, raw);                                  // the next step's loads fly under this step's work
 #endif
+            MSDA_TR(2)
             unsigned cells[NL][4];
 #pragma unroll
             for (int li = 0; li < NL; ++li) {
@@ -299,6 +329,7 @@ msda_bwd_value_mfma_kernel(const Params p, int l0)
             }
             // ---- the products, two pixel tiles at a time, the next pair's operands read under this pair's instructions (the LDS
             // operations of one wave complete in order: these reads see the cells written above)
+            MSDA_TR(3)
             constexpr int TB = MSDA_MFMA_TB < MT ? MSDA_MFMA_TB : MT, NB = (MT + TB - 1) / TB;
             V fh[2][TB], fl[2][TB];
             auto read_pair = [&](int b, V (&h)[TB], V (&l)[TB]) {
@@ -331,6 +362,7 @@ msda_bwd_value_mfma_kernel(const Params p, int l0)
                 __builtin_amdgcn_sched_barrier(0);
 #endif
             }
+            MSDA_TR(4)
             // ---- cells back to zero
             const unsigned zero = 0u;
 #pragma unroll
@@ -344,33 +376,68 @@ msda_bwd_value_mfma_kernel(const Params p, int l0)
                     asm volatile("ds_write_b16 %0, %1 offset:%2" : : "v"(cells[li][c]), "v"(zero), "n"(kTile) : "memory");
 #endif
                 }
+            MSDA_TR(5)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+#if defined(MSDA_MFMA_TRACE)
+        __syncthreads();
+        MSDA_TR(6)
+#endif
 
-        // ---- the waves' accumulators -> one, through the LDS, kPhase tiles at a time; wave w adds up tile (phase * kPhase + w)
+        // ---- the waves' accumulators -> one, through the LDS, kPhase tiles at a time
         GV *gmap = static_cast<GV *>(p.grad_value) + ((long long)gf * p.S + lsi0) * MD + m * D;
 #pragma unroll
         for (int ph = 0; ph * kPhase < MT; ++ph) {
             __syncthreads();
+            MSDA_TR(7)
 #pragma unroll
             for (int t = 0; t < kPhase; ++t)
                 if (ph * kPhase + t < MT)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) red[((wave * kPhase + t) * 16 + r) * 64 + lane] = acc[ph * kPhase + t][r];
+            MSDA_TR(8)
             __syncthreads();
-            for (int tw = wave; tw < kPhase && ph * kPhase + tw < MT; tw += NW) {
-                const int t = ph * kPhase + tw;
-#pragma unroll 2        // (fully unrolled the 16 x NW loads are all hoisted: 128 registers at the kernel's tightest point)
-                for (int r = 0; r < 16; ++r) {
+            MSDA_TR(9)
+            // the phase's nt x 16 accumulator rows (64 lanes each) dealt over ALL the waves -- 2 nt consecutive rows of one tile per
+            // wave -- and summed kRedRows rows at a time (8 LDS loads in flight per row), the partial sums added in wave order
+            static_assert(NW == 8 && MT % 2 == 0 && kPhase % 2 == 0, "a wave's rows: a multiple of four inside one tile");
+            const int nt = MT - ph * kPhase < kPhase ? MT - ph * kPhase : kPhase, per = 2 * nt;      // (constants once ph is unrolled)
+            int row0 = wave * per;
+            asm volatile("" : "+s"(row0));                      // (opaque, like the lane's part below: nothing of the stores' addresses hoisted)
+            const int tw = row0 >> 4, r0 = row0 & 15, t = ph * kPhase + tw;
+            const float *src = red + (tw * 16 + r0) * 64 + lane;
+            int kh4 = 4 * kh, lane_off = 4 * kh * MD + n;
+            asm volatile("" : "+v"(kh4), "+v"(lane_off));       // (opaque: or the item loop keeps every store's 64-bit offset in registers)
+#pragma unroll
+            for (int i = 0; i < per; i += kRedRows) {
+                float part[NW][kRedRows];
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+#pragma unroll
+                    for (int k = 0; k < kRedRows; ++k) part[w][k] = src[(w * kPhase * 16 + i + k) * 64];
+#pragma unroll
+                for (int k = 0; k < kRedRows; ++k) {
                     float v = 0.f;
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) v += red[((w * kPhase + tw) * 16 + r) * 64 + lane];
-                    const int pix = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    if (pix < npix) Store<GV>::put(gmap + (long long)pix * MD + n, v);
+                    for (int w = 0; w < NW; ++w) v += part[w][k];
+                    const int r = r0 + i + k, pixs = 32 * t + (r & 3) + 8 * (r >> 2);       // (uniform; the lane's pixel: + 4 kh)
+                    if (pixs + kh4 < npix) Store<GV>::put(gmap + (long long)pixs * MD + lane_off, v);
                 }
+                __builtin_amdgcn_sched_barrier(0);          // (without it every batch's loads are hoisted to the top: 64 registers more)
             }
+            MSDA_TR(10)
         }
         __syncthreads();                                    // the reduction buffer is the tiles: zeroed again at the top
+#if defined(MSDA_MFMA_TRACE)
+        MSDA_TR(11)
+        if (lane < 16) {
+            unsigned v = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v = lane == k ? tr[k] : v;
+            float *t0 = reinterpret_cast<float *>(p.grad_value) + ((long long)gf * p.S + wave) * MD + m * D + lane;
+            *t0 = __uint_as_float(v);
+        }
+#endif
     }
 }
 
