@@ -62,6 +62,7 @@ struct Knobs {
     int bwd_atomic = 0;                 // MSDA_BWD_MODE=atomic: one-kernel backward with global atomics
     int bwd_phases = 3;                 // 1 = gather pass only, 2 = scatter pass only, 3 = both
     int bwd_cull = 1;                   // 0: no culling structure, 2: (min, max) intervals instead of per-point records
+    int bwd_all_records = 0;            // measurement: the gather pass leaves records for every level (a later scatter-only call may walk them)
     int bwd_summary = 1;                // 64-query block summaries for long candidate ranges
     int scatter_lds_kb = 144, scatter_dbg = 0;
     int scatter_own = -1;               // owner-computes scatter: -1 auto, 0 off (the LDS-atomic scatter instead)
@@ -113,6 +114,7 @@ void load_knobs()
         k.bwd_atomic = (mode && !strcmp(mode, "atomic")) ? 1 : 0;
         k.bwd_phases = env_int("MSDA_BWD_PHASES", k.bwd_phases);
         k.bwd_cull = env_int("MSDA_BWD_CULL", k.bwd_cull);
+        k.bwd_all_records = env_int("MSDA_BWD_ALL_RECORDS", k.bwd_all_records);
         k.bwd_summary = env_int("MSDA_BWD_SUMMARY", k.bwd_summary);
         k.scatter_lds_kb = env_int("MSDA_SCATTER_LDS_KB", k.scatter_lds_kb);
         k.scatter_dbg = env_int("MSDA_SCATTER_DBG", k.scatter_dbg);
@@ -572,6 +574,44 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             return fail(MSDA_ERR_HIP, "msda backward: hipMemsetAsync(grad_value) failed%s");
         return launch_bwd_tile(dtype, G, true, p, (unsigned)blocks, lds, stream);
     }
+    // Which levels the owner-computes scatter walks and which go to the matrix pipe is settled BEFORE the gather pass: the gather
+    // pass leaves culling records only for the levels the owner kernel will walk (16 clips: 0.400 -> 0.394 ms, 22 MB of stores less).
+    int l0 = p.L, mfma_tiles = 0;
+    const bool owner_route = owner_scatter_applicable(p, esz) && (p.cull_points || !p.bbox);
+    if (owner_route) {
+        // The coarse levels -- the last one or two of the pyramid, together at most ~300 pixels -- on the matrix pipe (msda_mfma.hip):
+        // the owner-computes kernel then runs on levels [0, l0).  Needs the host copy of the shapes (a true copy: include/msda.h)
+        // and at least 16 queries (a step is 16 groups).  Automatic for decoder-shaped batches: an item walks (1 + sources) x Lq
+        // groups in 8 waves, so a handful of items of encoder length would be the kernel's whole duration.
+        // (its loads are buffer loads with 32-bit byte offsets inside one clip: grad_out and the point arrays of a clip below 2 GiB)
+        const long long lesz = (dtype == MSDA_BF16_LOC32 || dtype == MSDA_F16_LOC32) ? 4 : esz;
+        const long long clip_rows = (long long)p.frames * p.Lq;
+        const bool mfma_fits = clip_rows * p.M * p.D * esz < 0x7fffffffLL &&
+                               clip_rows * p.M * std::max((long long)p.LA * p.PA, (long long)p.LB * p.PB) * 2 * lesz < 0x7fffffffLL;
+        if (knobs().scatter_mfma != 0 && mfma_fits && p.shapes_host && p.Lq >= 16 && p.L >= 2 && !(knobs().scatter_own_levels >= 0 && knobs().scatter_own_levels < p.L)) {
+            long long px = 0;
+            for (int l = p.L - 1; l >= 1 && l >= p.L - 2; --l) {
+                const long long hw = p.shapes_host[2 * l] * p.shapes_host[2 * l + 1];
+                if (p.shapes_host[2 * l] <= 0 || p.shapes_host[2 * l + 1] <= 0 || !mfma_scatter_tiles(px + hw)) break;
+                px += hw; l0 = l; mfma_tiles = mfma_scatter_tiles(px);
+            }
+            const long long items = (long long)p.groups * p.M, per_item = (long long)p.Lq * (1 + p.window);
+            // Automatic rule (profiles/r06_logs/mfma_check.log; scatter pass, owner kernel alone -> with this kernel, ms): the two coarse
+            // levels of the 360x640 pyramid cost the owner kernel 0.19 ms at 16 clips of 300 queries and this one 0.12 (0.563 -> 0.502;
+            // bf16 0.564 -> 0.473; 4 / 8 / 32 clips 0.159 -> 0.148 / 0.289 -> 0.265 / 1.096 -> 1.064); the single 273-pixel level of the
+            // 800x1333 pyramid 0.553 -> 0.512 (with the owner kernel's bands rotated unconditionally; see below).
+            // It needs items to fill the chip -- 2 clips (96 items) 0.089 -> 0.110, one clip 0.053 -> 0.088 -- and items long enough to
+            // pay for their zero-fill and reduction: the plain op on 48 images x 300 queries (19 steps per item) 0.100 -> 0.109.  Encoder-
+            // shaped calls (one query per pixel: tens of thousands of groups per item) win once there are enough items -- 4 clips at
+            // 360x640: 1.924 -> 1.733 -- and lose with one clip's 48 (0.556 -> 0.987; BASELINE configs[1], 64 items: 0.644 -> 0.688).
+            const bool enough = items >= 128 && per_item >= 512 && (per_item <= 8192 || items >= 192);
+            // (after the owner kernel's band rotation became conditional -- msda_scatter.hip -- the 96-pixel last level of the SwinL
+            // pyramid pays as well: 16 clips 0.679 -> 0.636; the 273-pixel one of 800x1333 is level: 0.514 -> 0.510)
+            if (mfma_tiles && knobs().scatter_mfma < 0 && !(enough && (p.L - l0 == 2 || px >= 64))) { l0 = p.L; mfma_tiles = 0; }
+        }
+    }
+    Params pq = p;                                 // the gather pass's view: records for levels [0, own_levels)
+    if (l0 < p.L && !knobs().bwd_all_records) pq.own_levels = l0;
     // MSDA_BWD_PHASES (measurement hook for bench.py): 1 = gather pass only, 2 = scatter pass only
     // (needs the workspace a previous gather pass filled), 3 = both (default)
     const int phases = knobs().bwd_phases;
@@ -580,7 +620,7 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
         bool done = false;
         WinPlan w;
         if ((p.cull_points || !p.bbox) && window_route(knobs().bwd_win, w)) {
-            rc = launch_bwd_win(dtype, p, w, stream);
+            rc = launch_bwd_win(dtype, pq, w, stream);
             if (rc) return rc;
             done = true;
         }
@@ -633,28 +673,28 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
                 }
             }
             if ((want || want_small) && fparts > 0 && p.frames > 1 && clips * p.M * p.frames * fparts <= 0x7fffffffLL) {
-                rc = launch_bwd_rs(dtype, l0_host, p, fparts, (unsigned)(clips * p.M * p.frames * fparts), stream, 1);
+                rc = launch_bwd_rs(dtype, l0_host, pq, fparts, (unsigned)(clips * p.M * p.frames * fparts), stream, 1);
                 if (rc) return rc;
                 done = true;
             } else if (want && clips * p.M * parts <= 0x7fffffffLL) {
-                rc = launch_bwd_rs(dtype, l0_host, p, parts, (unsigned)(clips * p.M * parts), stream);
+                rc = launch_bwd_rs(dtype, l0_host, pq, parts, (unsigned)(clips * p.M * parts), stream);
                 if (rc) return rc;
                 done = true;
             }
         }
         if (!done) {
-            rc = launch_bwd_tile(dtype, G, false, p, (unsigned)blocks, lds, stream);
+            rc = launch_bwd_tile(dtype, G, false, pq, (unsigned)blocks, lds, stream);
             if (rc) return rc;
         }
         if (p.cull_points && p.bsum) {       // block summaries of the per-point records just written
-            rc = launch_cull_summary(p, stream);
+            rc = launch_cull_summary(pq, stream);
             if (rc) return rc;
         }
     }
     if (!(phases & 2)) return rc;
     unsigned grid = (unsigned)device_cus();      // persistent: one 1024-thread workgroup per CU
     grid -= grid % 8;                            // multiple of the XCD count: item % M stays put
-    if (owner_scatter_applicable(p, esz) && (p.cull_points || !p.bbox)) {
+    if (owner_route) {
         // owner-computes scatter: no float atomics; pixels outside its bands are zero-filled first
         // When every level's row fits a band (the host copy of the shapes says so) no pixel takes the float-atomic branch, and the
         // zero-fill of the pixels outside the levels -- normally none -- rides in the scatter kernel's prologue (bit 512) instead of
@@ -667,42 +707,11 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
         }
         Params pg = p;
         if (knobs().scatter_own_levels >= 0 && knobs().scatter_own_levels < p.L) pg.own_levels = knobs().scatter_own_levels;     // (measurement only: wrong results)
-        // The coarse levels -- the last one or two of the pyramid, together at most ~300 pixels -- on the matrix pipe (msda_mfma.hip):
-        // the owner-computes kernel then runs on levels [0, l0).  Needs the host copy of the shapes (a true copy: include/msda.h)
-        // and at least 16 queries (a step is 16 groups).  Automatic for decoder-shaped batches: an item walks (1 + sources) x Lq
-        // groups in 8 waves, so a handful of items of encoder length would be the kernel's whole duration.
-        int l0 = p.L, tiles = 0;
-        // (its loads are buffer loads with 32-bit byte offsets inside one clip: grad_out and the point arrays of a clip below 2 GiB)
-        const long long lesz = (dtype == MSDA_BF16_LOC32 || dtype == MSDA_F16_LOC32) ? 4 : esz;
-        const long long clip_rows = (long long)p.frames * p.Lq;
-        const bool mfma_fits = clip_rows * p.M * p.D * esz < 0x7fffffffLL &&
-                               clip_rows * p.M * std::max((long long)p.LA * p.PA, (long long)p.LB * p.PB) * 2 * lesz < 0x7fffffffLL;
-        if (knobs().scatter_mfma != 0 && mfma_fits && p.shapes_host && p.Lq >= 16 && p.L >= 2 && pg.own_levels == p.L) {
-            long long px = 0;
-            for (int l = p.L - 1; l >= 1 && l >= p.L - 2; --l) {
-                const long long hw = p.shapes_host[2 * l] * p.shapes_host[2 * l + 1];
-                if (p.shapes_host[2 * l] <= 0 || p.shapes_host[2 * l + 1] <= 0 || !mfma_scatter_tiles(px + hw)) break;
-                px += hw; l0 = l; tiles = mfma_scatter_tiles(px);
-            }
-            const long long items = (long long)p.groups * p.M, per_item = (long long)p.Lq * (1 + p.window);
-            // Automatic rule (profiles/r06_logs/mfma_check.log; scatter pass, owner kernel alone -> with this kernel, ms): the two coarse
-            // levels of the 360x640 pyramid cost the owner kernel 0.19 ms at 16 clips of 300 queries and this one 0.12 (0.563 -> 0.502;
-            // bf16 0.564 -> 0.473; 4 / 8 / 32 clips 0.159 -> 0.148 / 0.289 -> 0.265 / 1.096 -> 1.064); the single 273-pixel level of the
-            // 800x1333 pyramid 0.553 -> 0.512 (with the owner kernel's bands rotated unconditionally; see below).
-            // It needs items to fill the chip -- 2 clips (96 items) 0.089 -> 0.110, one clip 0.053 -> 0.088 -- and items long enough to
-            // pay for their zero-fill and reduction: the plain op on 48 images x 300 queries (19 steps per item) 0.100 -> 0.109.  Encoder-
-            // shaped calls (one query per pixel: tens of thousands of groups per item) win once there are enough items -- 4 clips at
-            // 360x640: 1.924 -> 1.733 -- and lose with one clip's 48 (0.556 -> 0.987; BASELINE configs[1], 64 items: 0.644 -> 0.688).
-            const bool enough = items >= 128 && per_item >= 512 && (per_item <= 8192 || items >= 192);
-            // (after the owner kernel's band rotation became conditional -- msda_scatter.hip -- the 96-pixel last level of the SwinL
-            // pyramid pays as well: 16 clips 0.679 -> 0.636; the 273-pixel one of 800x1333 is level: 0.514 -> 0.510)
-            if (tiles && knobs().scatter_mfma < 0 && !(enough && (p.L - l0 == 2 || px >= 64))) { l0 = p.L; tiles = 0; }
-        }
         if (l0 < p.L) pg.own_levels = l0;
-        if (!(tiles && knobs().scatter_part == 2))
+        if (!(mfma_tiles && knobs().scatter_part == 2))
             rc = launch_scatter_grp(dtype, p.gv_storage != 0, pg, grid * (1024 / kOwnThreads), (knobs().scatter_dbg & (511 | 2048 | 4096)) | (fused_zero ? 512 : 0), stream);
-        if (rc || !tiles || knobs().scatter_part == 1) return rc;
-        return launch_scatter_mfma(dtype, p.gv_storage != 0, p, l0, tiles, stream);
+        if (rc || !mfma_tiles || knobs().scatter_part == 1) return rc;
+        return launch_scatter_mfma(dtype, p.gv_storage != 0, p, l0, mfma_tiles, stream);
     }
     if (p.gv_storage) return fail(MSDA_ERR_ARG, "msda backward: this call needs grad_value in the arithmetic type (see msda_grad_value_dtype)%s");
     // LDS-atomic scatter: 144 KiB of 8-byte accumulators per workgroup

@@ -409,6 +409,8 @@ msda_cull_summary_kernel(const Params p)
     const int lane = threadIdx.x % kWave;
     for (int64_t e = (int64_t)blockIdx.x * 4 + threadIdx.x / kWave; e < total; e += (int64_t)gridDim.x * 4) {
         const int64_t gmv = e / nblk;
+        const int vl = (int)(gmv % VL), lvl = vl < p.LA ? vl : (vl - p.LA) % p.L;
+        if (lvl >= p.own_levels) continue;          // (no records were left for the levels the owner-computes scatter will not walk)
         const int q = (int)(e - gmv * nblk) * kCullBlock + lane;
         int mn = 0x7fffffff, mx = -0x7fffffff - 1;
         if (q < p.Lq) {

@@ -22,6 +22,8 @@ bench.PYRAMIDS["S"] = SWIN
 def knobs(**env):
     for k in ("MSDA_BWD_PHASES", "MSDA_SCATTER_OWN", "MSDA_SCATTER_DBG"):
         os.environ.pop(k, None)
+    # (probes run a gather pass under one route and scatter-only calls under others: records for every level, always)
+    os.environ["MSDA_BWD_ALL_RECORDS"] = "1"
     os.environ.update({k: str(v) for k, v in env.items()})
     _native.reload_knobs()
 

@@ -122,6 +122,37 @@ def test_matrix_pipe_scatter_is_automatic_on_the_bench_batch_and_off_for_one_cli
         _native._load_shipped_routes()
 
 
+def test_gather_pass_leaves_records_only_for_the_owner_kernels_levels(monkeypatch):
+    """Round 6: with the coarse levels on the matrix pipe the gather pass writes culling records for levels [0, l0) only
+    (msda_api.hip: the plan is made before the gather pass).  The same results with every record written
+    (MSDA_BWD_ALL_RECORDS=1, a measurement hook), on a decoder batch that takes the route by itself."""
+    from devis_amd import _native
+    monkeypatch.delenv("MSDA_SCATTER_MFMA", raising=False)
+    _native.clear_routes()
+    try:
+        ds = [make_temporal_inputs(900 + c, 6, 5, 8, 32, 300, PYR_A, 4, 4) for c in range(4)]
+        cat = {k: (np.concatenate([x[k] for x in ds], 0) if k not in ("shapes", "lsi", "ftab") else ds[0][k]) for k in ds[0]}
+        got, routes = _routes_of_backward(lambda: _run_temporal(cat, torch.float32, clips=4))
+        assert "matrix-pipe" in routes[0], routes
+        monkeypatch.setenv("MSDA_BWD_ALL_RECORDS", "1")
+        _native.reload_knobs()
+        every = _run_temporal(cat, torch.float32, clips=4)
+        for i, (a, b) in enumerate(zip(got, every)):
+            if i == 1:      # grad_value: the owner-computes kernel's lists are linked in arrival order -- last-bit differences run to run
+                assert _maxabs(a, b) <= 1e-6 * np.abs(b).max()
+                lsi2 = int(cat["lsi"][2])
+                assert np.array_equal(a[:, lsi2:], b[:, lsi2:])            # the matrix-pipe levels: a fixed summation order
+            else:
+                assert np.array_equal(a, b)
+        ref = _ref(ds[2])
+        n = ds[2]["value"].shape[0]
+        assert _maxabs(got[1][2 * n:3 * n], ref[1]) <= 2e-5 * np.abs(ref[1]).max()
+    finally:
+        monkeypatch.delenv("MSDA_BWD_ALL_RECORDS", raising=False)
+        _native.reload_knobs()
+        _native._load_shipped_routes()
+
+
 def test_matrix_pipe_scatter_plain_op_duplicates_and_borders(monkeypatch):
     """The plain operator (no frame table, one source), with what the merge must get right: all points of a group on ONE pixel
     cell, points exactly on cell borders and on the map's edge rows / columns, points outside the map, zero attention."""
