@@ -18,9 +18,13 @@ ROUTES = [{}, {"MSDA_SCATTER_DBG": "16"}, {"MSDA_BWD_CULL": "2"}, {"MSDA_BWD_CUL
           {"MSDA_BWD_RS": "1", "MSDA_BWD_RS_FSPLIT": "4"}, {"MSDA_BWD_RS": "1", "MSDA_BWD_RS_TPW": "2", "MSDA_BWD_RS_FSPLIT": "0"},
           # the tile forward with 1 / 2 / 5 / 8 waves per tile (auto picks 3 or 1: the LDS clamp loop and the other counts ran nowhere)
           {"MSDA_FWD_RS": "0", "MSDA_FWD_TILE_WAVES": "1"}, {"MSDA_FWD_RS": "0", "MSDA_FWD_TILE_WAVES": "2"},
-          {"MSDA_FWD_RS": "0", "MSDA_FWD_TILE_WAVES": "5"}, {"MSDA_FWD_RS": "0", "MSDA_FWD_TILE_WAVES": "8"}]
+          {"MSDA_FWD_RS": "0", "MSDA_FWD_TILE_WAVES": "5"}, {"MSDA_FWD_RS": "0", "MSDA_FWD_TILE_WAVES": "8"},
+          # round 6: the matrix-pipe scatter wherever it applies (D = 32, >= 2 levels, >= 16 queries, coarse levels <= 303 px), with and
+          # without the resident-slab gather pass (which then leaves culling records for the owner kernel's levels only)
+          {"MSDA_SCATTER_MFMA": "1"}, {"MSDA_SCATTER_MFMA": "1", "MSDA_BWD_RS": "1"}, {"MSDA_SCATTER_MFMA": "1", "MSDA_BWD_RS": "1", "MSDA_BWD_RS_FSPLIT": "2"},
+          {"MSDA_SCATTER_MFMA": "1", "MSDA_BWD_RS": "0"}, {"MSDA_SCATTER_MFMA": "1", "MSDA_BWD_ALL_RECORDS": "1"}]
 KEYS = ["MSDA_SCATTER_DBG", "MSDA_BWD_CULL", "MSDA_SCATTER_LDS_KB", "MSDA_SCATTER_OWN", "MSDA_FWD_RS", "MSDA_BWD_RS", "MSDA_BWD_MODE", "MSDA_FWD_RS_NT",
-        "MSDA_BWD_RS_FSPLIT", "MSDA_BWD_RS_TPW", "MSDA_FWD_TILE_WAVES"]
+        "MSDA_BWD_RS_FSPLIT", "MSDA_BWD_RS_TPW", "MSDA_FWD_TILE_WAVES", "MSDA_SCATTER_MFMA", "MSDA_BWD_ALL_RECORDS"]
 def maxabs(a, b): return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max()) if a.size else 0.0
 def layout(v, kind):
     if kind == 1: return _native.head_major(v)
