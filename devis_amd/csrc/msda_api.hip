@@ -575,7 +575,7 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
         return launch_bwd_tile(dtype, G, true, p, (unsigned)blocks, lds, stream);
     }
     // Which levels the owner-computes scatter walks and which go to the matrix pipe is settled BEFORE the gather pass: the gather
-    // pass leaves culling records only for the levels the owner kernel will walk (16 clips: 0.400 -> 0.394 ms, 22 MB of stores less).
+    // pass leaves culling records only for the levels the owner kernel will walk band by band (16 clips: 0.400 -> 0.394 ms, 22 MB of stores less).
     int l0 = p.L, mfma_tiles = 0;
     const bool owner_route = owner_scatter_applicable(p, esz) && (p.cull_points || !p.bbox);
     if (owner_route) {
@@ -610,8 +610,18 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
             if (mfma_tiles && knobs().scatter_mfma < 0 && !(enough && (p.L - l0 == 2 || px >= 64))) { l0 = p.L; mfma_tiles = 0; }
         }
     }
-    Params pq = p;                                 // the gather pass's view: records for levels [0, own_levels)
-    if (l0 < p.L && !knobs().bwd_all_records) pq.own_levels = l0;
+    // Culling records: not for the matrix-pipe levels, and not for levels of ONE band (the host copy of the shapes says so: every
+    // group is a candidate of the only band, the owner kernel takes all its points) -- the 23x40 level of the 360x640 pyramid.
+    unsigned rec_mask = ~0u;
+    if (owner_route && !knobs().bwd_all_records) {
+        for (int l = l0; l < p.L && l < 32; ++l) rec_mask &= ~(1u << l);
+        for (int l = 0; p.shapes_host && l < l0 && l < 32; ++l) {
+            const long long H = p.shapes_host[2 * l], W = p.shapes_host[2 * l + 1];
+            if (H > 0 && W > 0 && W <= kOwnPix && H <= kOwnPix / W) rec_mask &= ~(1u << l);
+        }
+    }
+    Params pq = p;                                 // the gather pass's view
+    pq.rec_mask = rec_mask;
     // MSDA_BWD_PHASES (measurement hook for bench.py): 1 = gather pass only, 2 = scatter pass only
     // (needs the workspace a previous gather pass filled), 3 = both (default)
     const int phases = knobs().bwd_phases;
@@ -708,6 +718,7 @@ int launch_fast(int dtype, const Params &p, bool bwd, hipStream_t stream)
         Params pg = p;
         if (knobs().scatter_own_levels >= 0 && knobs().scatter_own_levels < p.L) pg.own_levels = knobs().scatter_own_levels;     // (measurement only: wrong results)
         if (l0 < p.L) pg.own_levels = l0;
+        pg.rec_mask = rec_mask;
         if (!(mfma_tiles && knobs().scatter_part == 2))
             rc = launch_scatter_grp(dtype, p.gv_storage != 0, pg, grid * (1024 / kOwnThreads), (knobs().scatter_dbg & (511 | 2048 | 4096)) | (fused_zero ? 512 : 0), stream);
         if (rc || !mfma_tiles || knobs().scatter_part == 1) return rc;
@@ -752,6 +763,7 @@ int run(int dtype, const Params &p_in, bool bwd, hipStream_t stream)
                                   "with MSDA_ENABLE_HOOKS=1%s");
     Params p = p_in;
     p.own_levels = p.L;
+    p.rec_mask = ~0u;
     const RouteScope pinned(bwd, dtype, p);     // (the pinned settings of this call shape, if any, are what knobs() answers below)
     p.dbg = knobs().dbg;
     // culling records per point (4 x int16) when the owner-computes scatter will read them; (min, max) intervals for the

@@ -270,6 +270,8 @@ struct Params {
     int gv_storage;             // bwd: grad_value is in the STORAGE type (16-bit), not the arithmetic type (owner-computes scatter only)
     int own_levels;             // bwd: the owner-computes scatter handles levels [0, own_levels); the trailing (coarse) levels are
                                 // the matrix-pipe scatter's (msda_mfma.hip).  = L when that kernel does not run
+    unsigned rec_mask;          // bwd: bit l = the gather pass leaves culling records for level l and the owner-computes scatter reads
+                                // them; clear for the matrix-pipe levels and for levels that are ONE band (every group a candidate)
 };
 
 struct Level { int H, W, start, pad; };   // start = first pixel of the level inside the CLIP slab

@@ -795,7 +795,7 @@ msda_bwd_rs_kernel(const Params p, int slab_bytes, int parts, int frame_split)
                             typedef float f32x4 __attribute__((ext_vector_type(4)));
                             __builtin_nontemporal_store((f32x4){wa[0], wa[1], wa[2], wa[3]}, reinterpret_cast<f32x4 *>(gaw + idx0 + 4 * cor));
                         }
-                        if (records && cor < p.own_levels)       // (levels the owner-computes scatter will not walk need no records)
+                        if (records && ((p.rec_mask >> cor) & 1u))     // (not for levels the owner-computes scatter does not walk or walks whole)
                             *reinterpret_cast<int2 *>(p.bbox + (((group * p.M + m) * VL + vl0 + cor) * p.Lq + q0 + j) * 2) =
                                 make_int2((wr[0] & 0xffff) | (wr[1] << 16), (wr[2] & 0xffff) | (wr[3] << 16));
                     }

@@ -410,7 +410,7 @@ msda_cull_summary_kernel(const Params p)
     for (int64_t e = (int64_t)blockIdx.x * 4 + threadIdx.x / kWave; e < total; e += (int64_t)gridDim.x * 4) {
         const int64_t gmv = e / nblk;
         const int vl = (int)(gmv % VL), lvl = vl < p.LA ? vl : (vl - p.LA) % p.L;
-        if (lvl >= p.own_levels) continue;          // (no records were left for the levels the owner-computes scatter will not walk)
+        if (!((p.rec_mask >> lvl) & 1u)) continue;  // (no records were left for this level: Params::rec_mask)
         const int q = (int)(e - gmv * nblk) * kCullBlock + lane;
         int mn = 0x7fffffff, mx = -0x7fffffff - 1;
         if (q < p.Lq) {
@@ -902,6 +902,8 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
         // of the survivor list, so nothing has to move
         int listed = 0;
         const int lo = min(r0 - 1, 32767), hi = min(r1, 32767);
+        // (a level without records -- one band, Params::rec_mask -- has every point of every group as a candidate, like a call without a table)
+        const bool has_rec = p.bbox != nullptr && ((p.rec_mask >> l) & 1u);
         auto load_records = [&](int gi0, int2 &iv, unsigned &ent, bool &live) {
             const int gi = gi0 + tid;
             live = gi < ng;
@@ -910,13 +912,13 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             if (live) {
                 const int k = gi / p.Lq, q = gi - k * p.Lq;
                 ent = ((unsigned)k << 26) | (unsigned)q;              // (q < 2^22: host)
-                if (p.bbox) iv = *reinterpret_cast<const int2 *>(p.bbox + (s_src_tab[k] + q) * 2);
+                if (has_rec) iv = *reinterpret_cast<const int2 *>(p.bbox + (s_src_tab[k] + q) * 2);
             }
         };
         // Long candidate ranges (encoder shapes, Lq = S): a pre-pass over the 64-query block summaries marks the cull
         // batches that hold a block whose tap rows can reach the band; with local sampling all but a few are skipped.
         const int nbat = (ng + kOwnThreads - 1) / kOwnThreads;
-        const bool skipping = p.bsum != nullptr && nbat > 4 && nbat <= 32 * kLiveWords;
+        const bool skipping = has_rec && p.bsum != nullptr && nbat > 4 && nbat <= 32 * kLiveWords;
         if (skipping) {
             if (tid < kLiveWords) s_live[per_item(tid)] = 0u;
             __syncthreads();
@@ -954,7 +956,7 @@ msda_bwd_value_grp_kernel(const Params p, int dbg)
             const int bnext = next_live(bcur + 1);
             unsigned pm = 0u;
             if (live) {
-                if (p.bbox) {
+                if (has_rec) {
                     const int hr[4] = {(int)(short)(iv.x & 0xffff), iv.x >> 16, (int)(short)(iv.y & 0xffff), iv.y >> 16};
 #pragma unroll
                     for (int jp = 0; jp < 4; ++jp) pm |= (hr[jp] >= lo && hr[jp] <= hi) ? (1u << jp) : 0u;
