@@ -31,7 +31,8 @@ if __name__ == "__main__":
     dev = torch.device("cuda:0")
     _native.clear_routes()
     tag = os.path.basename(os.environ.get("MSDA_LIB", "libmsda_hip.so"))
-    cases = [(torch.bfloat16, "A", "decoder", 16), (torch.float16, "A", "decoder", 16), (torch.bfloat16, "A", "encoder", 1),
+    # (round 6: with an argument, the fp32 headline batch -- two workgroups per CU then hold levels 2-3 only, level 1 comes from memory)
+    cases = [(torch.float32, "A", "decoder", 16)] if len(sys.argv) > 1 else [(torch.bfloat16, "A", "decoder", 16), (torch.float16, "A", "decoder", 16), (torch.bfloat16, "A", "encoder", 1),
              (torch.float16, "S", "decoder", 6)]
     for dt, pyr, kind, clips in cases:
         fwd, bwd, d, so = tuning._case(tuning.PYRAMIDS[pyr], dt, dt, clips, 300, kind, 6, 8, 32, 4, dev)
